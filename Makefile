@@ -1,0 +1,32 @@
+# Builds libmygram_gpu.so (HIP kernels for gfx950 + host C ABI) and the CPU oracle.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := mygram-db_amd/csrc
+LIB := mygram-db_amd/libmygram_gpu.so
+# -ffp-contract=off: BM25 arithmetic must round exactly like the reference's fp64 expression (no fused multiply-add)
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Iinclude
+HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
+
+OBJS := $(CSRC)/mgx_kernels.o $(CSRC)/mgx_api.o $(CSRC)/mgx_columns.o $(CSRC)/mgx_tools.o
+
+all: $(LIB) oracle
+
+$(CSRC)/mgx_kernels.o: $(CSRC)/mgx_kernels.hip $(CSRC)/mgx_internal.hpp $(CSRC)/mgx_launch.hpp
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(CSRC)/mgx_api.o: $(CSRC)/mgx_api.cpp $(CSRC)/mgx_internal.hpp $(CSRC)/mgx_launch.hpp $(CSRC)/mgx_host.hpp include/mygram_gpu.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(CSRC)/mgx_columns.o: $(CSRC)/mgx_columns.cpp $(CSRC)/mgx_host.hpp include/mygram_gpu.h
+	g++ $(CXXFLAGS) -pthread -c $< -o $@
+$(CSRC)/mgx_tools.o: $(CSRC)/mgx_tools.cpp include/mygram_tools.h
+	g++ $(CXXFLAGS) -pthread -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle clean
+.PHONY: all oracle clean

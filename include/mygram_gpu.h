@@ -1,0 +1,255 @@
+/*
+ * mygram_gpu.h — C ABI of libmygram_gpu.so: MygramDB's in-memory query hot path on AMD MI355X (gfx950).
+ *
+ * This is the ONLY boundary HIP code is reached through. There is no FFI around this path in the reference; the
+ * seam it replaces is the set of public C++ methods below (paths relative to the reference tree). The C++17 shim in
+ * mygram-db_amd/csrc/shim/ re-exposes them with the reference's exact signatures on top of this ABI.
+ *
+ *   Index::SearchAnd            src/index/index.h:127-128  (impl src/index/index.cpp:199-368)   -> mgx_and / mgx_batch_*
+ *   Index::FilterByNgrams       src/index/index.h:138-139  (impl index.cpp:370-416)             -> mgx_retain
+ *   Index::SearchOr             src/index/index.h:147      (impl index.cpp:418-448)             -> mgx_or
+ *   Index::SearchNot            src/index/index.h:156-157  (impl index.cpp:450-486)             -> mgx_not
+ *   Index::SearchByThreshold    src/index/index.h:172      (impl index.cpp:488-578)             -> mgx_threshold
+ *   Index::EstimatePostingSize  src/index/index.h:286      (impl index.cpp:756-759)             -> mgx_posting_size
+ *   BM25Scorer::ScoreDocuments  src/index/bm25_scorer.h:79-82 (impl bm25_scorer.cpp:47-99)      -> mgx_score_documents
+ *   ResultSorter::SortByScore   src/query/result_sorter.h:75-76 (impl result_sorter.cpp:661-716)-> mgx_sort_by_score
+ *   search_pipeline::Execute    src/server/search_pipeline.h:121-124 (impl search_pipeline.cpp:795-869),
+ *     + BM25 glue src/server/handlers/search_handler.cpp:405-470                                -> mgx_batch_* (batched; new)
+ *
+ * House style follows the reference's own C API (src/client/mygramclient_c.h:5-16,49-60,186-223): every function
+ * returns 0 on success and a non-zero mygram::utils::ErrorCode value (src/utils/error.h:35+) on failure;
+ * mgx_last_error() returns a thread-local message; handles are opaque; descriptor structs carry
+ * struct_size/version; library-allocated outputs are released with the matching free; on failure pointer
+ * out-parameters are NULL and numeric ones zero; no C++ exception crosses this ABI.
+ *
+ * There is NO CPU fallback behind these entry points: if no gfx950 device is usable they fail with
+ * MGX_ERR_INTERNAL and a message. Document ids are uint32 (src/types/doc_id.h:31); result lists are ascending and
+ * unique unless stated otherwise.
+ */
+#ifndef MYGRAM_GPU_H_
+#define MYGRAM_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_ABI_VERSION 1U
+
+/* Values of mygram::utils::ErrorCode used on this path (src/utils/error.h:37-48,100). */
+#define MGX_OK 0
+#define MGX_ERR_INVALID_ARGUMENT 2
+#define MGX_ERR_OUT_OF_RANGE 3
+#define MGX_ERR_NOT_IMPLEMENTED 4
+#define MGX_ERR_INTERNAL 5
+#define MGX_ERR_INDEX_NOT_FOUND 4000
+
+int mgx_abi_version(void);
+/* Thread-local message of the last failing call on this thread; valid until that thread's next failing call. */
+const char* mgx_last_error(void);
+/* Releases any buffer this library returned through an out-pointer (docid/score arrays). NULL is allowed. */
+void mgx_free(void* p);
+/* Number of usable gfx950 devices (0 when there is none; never fails). */
+int mgx_device_count(void);
+
+/* =====================================================================================================
+ * Host-side column builder: normalized texts -> the column arrays the device index is made of.
+ * Restates what Index::AddDocument (index.cpp:39-74) + BM25 ingest bookkeeping
+ * (src/mysql/binlog_event_processor.cpp:98-99) produce, plus the build-owned tf column that makes
+ * BM25Scorer::CountTermOccurrences (bm25_scorer.cpp:27-45) a lookup for terms that are exactly one n-gram long.
+ * Pure host code (multi-threaded); no device needed.
+ * ===================================================================================================== */
+
+typedef struct mgx_columns mgx_columns;
+
+typedef struct mgx_build_params {
+  uint32_t struct_size; /* sizeof(mgx_build_params) */
+  uint32_t version;     /* MGX_ABI_VERSION */
+  int32_t ngram_size;           /* Index(ngram_size, ...) */
+  int32_t kanji_ngram_size;     /* <=0 => ngram_size (index.cpp:31) */
+  int32_t cross_boundary_ngrams;
+  int32_t n_threads;            /* 0 => hardware concurrency */
+} mgx_build_params;
+
+typedef struct mgx_columns_view {
+  uint64_t n_grams;
+  const uint8_t* key_bytes;  /* gram keys, concatenated, sorted bytewise ascending; gram id = rank */
+  const uint32_t* key_off;   /* n_grams+1 */
+  const uint64_t* offsets;   /* n_grams+1, CSR into docids/tf */
+  const uint32_t* docids;    /* ascending per gram */
+  const uint8_t* tf;         /* non-overlapping occurrence count of the gram's bytes in the doc text, saturated at 255 */
+  uint64_t n_postings;
+  uint32_t first_doc_id;     /* doc d has local slot d - first_doc_id */
+  uint64_t n_docs;           /* slots */
+  const uint32_t* doc_len;   /* n_docs: CountCodePoints(text) (string_utils.cpp:655-669); 0 for empty text */
+  uint64_t bm25_doc_count;   /* docs with non-empty text (server_types.h:157-193) */
+  uint64_t bm25_total_len;   /* sum of their doc_len */
+} mgx_columns_view;
+
+/* Docs are first_doc_id, first_doc_id+1, ...; doc i's normalized text is text_bytes[text_off[i] .. text_off[i+1]). */
+int mgx_columns_build(const mgx_build_params* params, const uint8_t* text_bytes, const uint64_t* text_off,
+                      uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out);
+int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out);
+/* Gram dictionary lookup (host-side replacement of Index::TakePostingSnapshot's map lookup, index.cpp:728-747).
+ * *found = 0 and *gram_id = 0 for an unknown gram. */
+int mgx_columns_lookup(const mgx_columns* cols, const uint8_t* gram, size_t len, uint32_t* gram_id, int* found);
+void mgx_columns_destroy(mgx_columns* cols);
+
+/* =====================================================================================================
+ * Device index
+ * ===================================================================================================== */
+
+typedef struct mgx_index mgx_index;
+
+typedef struct mgx_index_desc {
+  uint32_t struct_size; /* sizeof(mgx_index_desc) */
+  uint32_t version;     /* MGX_ABI_VERSION */
+  int32_t device;       /* HIP device ordinal */
+  uint32_t tile_shift;  /* log2 docids per tile; 0 => default (14) */
+  /* the doc-id range this index (or shard) owns: local slot = doc_id - first_doc_id, 0 <= slot < n_docs */
+  uint32_t first_doc_id;
+  uint64_t n_docs;
+  uint64_t n_grams;
+  const uint64_t* offsets; /* host, n_grams+1 */
+  const uint32_t* docids;  /* host, offsets[n_grams]; every id inside the owned range, ascending per gram */
+  const uint8_t* tf;       /* host, parallel to docids; NULL => BM25 scoring unavailable */
+  const uint32_t* doc_len; /* host, n_docs; NULL => BM25 scoring unavailable */
+  /* posting lists at least this dense (|L| / n_docs) are ALSO kept as precomputed bitmaps in HBM and read in that
+   * form by the set-algebra kernels (what Roaring bitset containers are to the reference, posting_list.cpp:800-834).
+   * 0 => default (1/32: the bitmap is then never larger than the u32 list); >= 2 => disabled. */
+  double dense_threshold;
+} mgx_index_desc;
+
+/* Host arrays are copied; the caller keeps ownership. */
+int mgx_index_create(const mgx_index_desc* desc, mgx_index** out);
+void mgx_index_destroy(mgx_index* idx);
+int mgx_posting_size(const mgx_index* idx, uint32_t gram_id, uint64_t* out);
+/* Device bytes held by the index (postings, tf, doc_len, skip tables, dense bitmaps). */
+int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out);
+/* Registers one FilterIndex (column,value) doc set (src/storage/filter_index.h:39-124) as a device bitmap usable
+ * as a filter operand; docids ascending, inside the owned range. */
+int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id);
+
+/* =====================================================================================================
+ * Batched search (new: the reference executes one query per request, request_dispatcher.cpp:93-193)
+ * ===================================================================================================== */
+
+#define MGX_SORT_DOCID 0u /* no SORT _score: docid order; `reverse` selects descending (SearchAnd limit/reverse) */
+#define MGX_SORT_SCORE 1u /* SORT _score: BM25 + ResultSorter::SortByScore */
+
+#define MGX_MAX_TERMS 64u /* query_parser.h:270-272 */
+
+/* One search term = the AND of its (deduplicated) n-grams, as search_pipeline::GenerateTermInfos leaves it
+ * (search_pipeline.cpp:569-603). Unknown grams must be resolved by the caller: a positive term with an unknown
+ * gram makes the whole query empty before it reaches the device (Execute :804-810), a NOT term with one is dropped. */
+typedef struct mgx_term {
+  const uint32_t* gram_ids;
+  uint32_t n_grams;
+  /* FUZZY terms (search_pipeline.cpp:1697-1702): docs in at least `threshold` of the distinct grams;
+   * 0 => plain AND of all grams. */
+  uint32_t threshold;
+  double idf; /* BM25Scorer::ComputeIDF(N, df) for MGX_SORT_SCORE; scored terms must have n_grams == 1 */
+} mgx_term;
+
+typedef struct mgx_filter {
+  uint32_t bitmap_id; /* from mgx_index_add_filter_bitmap */
+  uint32_t negate;    /* 0: EQ (AND), 1: NE (ANDNOT) — search_pipeline.cpp:1196-1237 */
+} mgx_filter;
+
+typedef struct mgx_query {
+  /* positive terms, ALREADY in the order search_pipeline.cpp:2012-2014 leaves them (estimated_size ascending):
+   * BM25 sums term contributions in this order (bm25_scorer.cpp:77-86) */
+  const mgx_term* terms;
+  uint32_t n_terms;
+  const mgx_term* not_terms; /* ApplyNotFilter, search_pipeline.cpp:871-932 */
+  uint32_t n_not_terms;
+  const mgx_filter* filters;
+  uint32_t n_filters;
+  uint32_t sort;    /* MGX_SORT_* */
+  uint32_t limit;   /* 0 => all */
+  uint32_t offset;  /* MGX_SORT_SCORE only */
+  uint32_t reverse; /* MGX_SORT_DOCID: descending docids; MGX_SORT_SCORE: 1 => SortOrder::DESC */
+  double k1, b;     /* BM25Params (bm25_scorer.h:20-23) */
+  uint64_t total_docs;    /* BM25Stats::doc_count; only documents the caller's idf values already encode */
+  double avg_doc_length;  /* BM25Stats::avg_doc_length() */
+} mgx_query;
+
+typedef struct mgx_batch mgx_batch;
+
+typedef struct mgx_query_result {
+  uint64_t total;             /* results.size() before pagination (search_handler.cpp:471) */
+  uint64_t total_candidates;  /* SearchPipelineResult funnel (search_pipeline.h:58-65) */
+  uint64_t after_intersection;
+  uint64_t after_not;
+  uint64_t after_filters;
+  uint32_t n_docs;            /* entries returned for this query */
+  uint32_t docs_begin;        /* index of its first entry in mgx_result_view.docs / .scores */
+} mgx_query_result;
+
+typedef struct mgx_result_view {
+  uint32_t n_queries;
+  const mgx_query_result* queries;
+  const uint32_t* docs;   /* concatenated per query, in rank order */
+  const double* scores;   /* parallel to docs for MGX_SORT_SCORE queries (0.0 otherwise) */
+} mgx_result_view;
+
+/* Compiles and uploads a batch; the batch can be executed any number of times. */
+int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queries, mgx_batch** out);
+/* Enqueues the whole batch on `hip_stream` (a hipStream_t; NULL = the default stream). Asynchronous. */
+int mgx_batch_execute(mgx_batch* batch, void* hip_stream);
+/* Waits for the last execute and copies the (small) results to host memory owned by the batch. */
+int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);
+/* Multi-GPU exchange (one rank per doc-range shard; only for batches whose queries are all MGX_SORT_SCORE).
+ * Copies the per-query top-(offset+limit) of the last execute into CALLER-owned DEVICE buffers on `hip_stream`:
+ * keys_out[n_queries*stride] (order-preserving u64 of the fp64 score, best first), docs_out[n_queries*stride],
+ * counts_out[n_queries], totals_out[n_queries] (match count of this shard). Call with keys_out == NULL to only
+ * learn *stride. */
+int mgx_batch_export_topk(mgx_batch* batch, uint64_t* keys_out, uint32_t* docs_out, uint32_t* counts_out,
+                          uint64_t* totals_out, uint32_t* stride, void* hip_stream);
+/* Merges the exported lists of `n_shards` ranks, gathered as [shard][query][stride] / [shard][query] DEVICE arrays
+ * (e.g. by one RCCL all-gather per array), into the final page and total of every query, on `hip_stream`; read the
+ * result with mgx_batch_fetch. */
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* keys, const uint32_t* docs,
+                           const uint32_t* counts, const uint64_t* totals, void* hip_stream);
+/* Algorithmic bytes of one execute (4*sum|L_i| + R*(T+4) + 12*min(k,R), summed over queries); R is
+ * taken from the last fetched execute. */
+int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes, uint64_t* topk_bytes);
+/* Average duration (ms) of the dominant kernel over the executes since the last call, measured with HIP events on
+ * the stream the kernel ran on; *n receives how many launches were averaged. Enables event recording from now on. */
+int mgx_batch_kernel_time_ms(mgx_batch* batch, double* avg_ms, uint32_t* n);
+void mgx_batch_destroy(mgx_batch* batch);
+
+/* =====================================================================================================
+ * Single operators (what the shim's Index / BM25Scorer / ResultSorter methods call)
+ * ===================================================================================================== */
+
+/* Index::SearchAnd(terms, limit, reverse): every gram known (the caller returns {} otherwise). */
+int mgx_and(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint64_t limit, int reverse, uint32_t** out_docs,
+            uint64_t* out_n);
+/* Index::SearchOr: unknown grams already dropped by the caller. */
+int mgx_or(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t** out_docs, uint64_t* out_n);
+/* Index::SearchNot(all_docs, terms): all_docs ascending. */
+int mgx_not(mgx_index* idx, const uint32_t* all_docs, uint64_t n_all, const uint32_t* gram_ids, uint32_t n,
+            uint32_t** out_docs, uint64_t* out_n);
+/* Index::SearchByThreshold over DISTINCT known grams (the caller dedupes and handles the delegate/empty rules,
+ * index.cpp:489-523). */
+int mgx_threshold(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t threshold, uint32_t** out_docs,
+                  uint64_t* out_n);
+/* Index::FilterByNgrams: keeps caller order and duplicates. */
+int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids, uint32_t n,
+               uint32_t** out_docs, uint64_t* out_n);
+/* BM25Scorer::ScoreDocuments for single-gram terms: one score per candidate, in candidate order. A candidate
+ * outside the index or with empty text scores 0.0 (bm25_scorer.cpp:73-89). */
+int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids,
+                        const double* idfs, uint32_t n_terms, double avg_doc_length, double k1, double b,
+                        double* scores_out);
+/* ResultSorter::SortByScore. */
+int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* scores, uint64_t n, int descending,
+                      uint32_t limit, uint32_t offset, uint32_t** out_docs, uint64_t* out_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYGRAM_GPU_H_ */

@@ -1,0 +1,28 @@
+/*
+ * mygram_tools.h — bench/test tooling exported by libmygram_gpu.so next to the product ABI (mygram_gpu.h).
+ * Not a reference interface: the reference benchmarks against a MySQL-loaded table (support/seed/benchmark.py,
+ * e2e/lib/data_generator.py); with no database here the corpus is synthetic, deterministic (seed 42 by default,
+ * like e2e/lib/data_generator.py:26) and identical for every consumer (device index, CPU oracle, every rank).
+ */
+#ifndef MYGRAM_TOOLS_H_
+#define MYGRAM_TOOLS_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgxt_corpus mgxt_corpus;
+
+/* Documents global_first .. global_first+n_docs-1 of the infinite synthetic ASCII corpus `seed`:
+ * doc = 4..16 words, word = Zipf(s=1) rank over a 20,000-word vocabulary (word length 2..10, letters Zipf-weighted),
+ * single spaces, already normalized (lower-case ASCII). A doc's text depends only on (seed, its global number), so
+ * any shard of the corpus can be generated independently. */
+int mgxt_corpus_generate(uint64_t seed, uint64_t global_first, uint64_t n_docs, int n_threads, mgxt_corpus** out);
+int mgxt_corpus_view(const mgxt_corpus* c, const uint8_t** text_bytes, const uint64_t** text_off, uint64_t* n_docs);
+void mgxt_corpus_destroy(mgxt_corpus* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

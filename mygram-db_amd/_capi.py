@@ -1,0 +1,139 @@
+"""ctypes bindings of libmygram_gpu.so (include/mygram_gpu.h, include/mygram_tools.h).
+
+The library is the product; this module only declares its C ABI for Python callers (tests, bench, the multi-GPU
+driver). It fails loudly if the library is missing: there is no Python or CPU fallback for any operator.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmygram_gpu.so")
+
+ABI_VERSION = 1
+SORT_DOCID, SORT_SCORE = 0, 1
+
+# every symbol include/mygram_gpu.h and include/mygram_tools.h declare
+EXPORTS = [
+    "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
+    "mgx_columns_build", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
+    "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
+    "mgx_index_add_filter_bitmap",
+    "mgx_batch_prepare", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
+    "mgx_batch_merge_shards", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
+    "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
+    "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy",
+]
+
+
+class BuildParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32), ("ngram_size", C.c_int32),
+                ("kanji_ngram_size", C.c_int32), ("cross_boundary_ngrams", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class ColumnsView(C.Structure):
+    _fields_ = [("n_grams", C.c_uint64), ("key_bytes", C.c_void_p), ("key_off", C.c_void_p),
+                ("offsets", C.c_void_p), ("docids", C.c_void_p), ("tf", C.c_void_p), ("n_postings", C.c_uint64),
+                ("first_doc_id", C.c_uint32), ("n_docs", C.c_uint64), ("doc_len", C.c_void_p),
+                ("bm25_doc_count", C.c_uint64), ("bm25_total_len", C.c_uint64)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32), ("device", C.c_int32),
+                ("tile_shift", C.c_uint32), ("first_doc_id", C.c_uint32), ("n_docs", C.c_uint64),
+                ("n_grams", C.c_uint64), ("offsets", C.c_void_p), ("docids", C.c_void_p), ("tf", C.c_void_p),
+                ("doc_len", C.c_void_p), ("dense_threshold", C.c_double)]
+
+
+class Term(C.Structure):
+    _fields_ = [("gram_ids", C.c_void_p), ("n_grams", C.c_uint32), ("threshold", C.c_uint32), ("idf", C.c_double)]
+
+
+class Filter(C.Structure):
+    _fields_ = [("bitmap_id", C.c_uint32), ("negate", C.c_uint32)]
+
+
+class Query(C.Structure):
+    _fields_ = [("terms", C.c_void_p), ("n_terms", C.c_uint32), ("not_terms", C.c_void_p),
+                ("n_not_terms", C.c_uint32), ("filters", C.c_void_p), ("n_filters", C.c_uint32),
+                ("sort", C.c_uint32), ("limit", C.c_uint32), ("offset", C.c_uint32), ("reverse", C.c_uint32),
+                ("k1", C.c_double), ("b", C.c_double), ("total_docs", C.c_uint64), ("avg_doc_length", C.c_double)]
+
+
+class QueryResult(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("total_candidates", C.c_uint64), ("after_intersection", C.c_uint64),
+                ("after_not", C.c_uint64), ("after_filters", C.c_uint64), ("n_docs", C.c_uint32),
+                ("docs_begin", C.c_uint32)]
+
+
+class ResultView(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("queries", C.POINTER(QueryResult)), ("docs", C.POINTER(C.c_uint32)),
+                ("scores", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def load():
+    """Loads libmygram_gpu.so. Raises (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `make` (or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise ImportError("libmygram_gpu.so does not export %s" % name)
+    vp, sz = C.c_void_p, C.c_size_t
+    u32, u64, i32, f64 = C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    L.mgx_abi_version.restype = i32
+    L.mgx_last_error.restype = C.c_char_p
+    L.mgx_free.argtypes = [vp]
+    L.mgx_free.restype = None
+    L.mgx_device_count.restype = i32
+    L.mgx_columns_build.argtypes = [C.POINTER(BuildParams), vp, vp, u32, u64, C.POINTER(vp)]
+    L.mgx_columns_view_get.argtypes = [vp, C.POINTER(ColumnsView)]
+    L.mgx_columns_lookup.argtypes = [vp, C.c_char_p, sz, C.POINTER(u32), C.POINTER(i32)]
+    L.mgx_columns_destroy.argtypes = [vp]
+    L.mgx_columns_destroy.restype = None
+    L.mgx_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(vp)]
+    L.mgx_index_destroy.argtypes = [vp]
+    L.mgx_index_destroy.restype = None
+    L.mgx_posting_size.argtypes = [vp, u32, C.POINTER(u64)]
+    L.mgx_index_memory_bytes.argtypes = [vp, C.POINTER(u64)]
+    L.mgx_index_add_filter_bitmap.argtypes = [vp, vp, u64, C.POINTER(u32)]
+    L.mgx_batch_prepare.argtypes = [vp, C.POINTER(Query), u32, C.POINTER(vp)]
+    L.mgx_batch_execute.argtypes = [vp, vp]
+    L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
+    L.mgx_batch_export_topk.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u32), vp]
+    L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]
+    L.mgx_batch_destroy.argtypes = [vp]
+    L.mgx_batch_destroy.restype = None
+    pp32, p64 = C.POINTER(C.POINTER(u32)), C.POINTER(u64)
+    L.mgx_and.argtypes = [vp, vp, u32, u64, i32, pp32, p64]
+    L.mgx_or.argtypes = [vp, vp, u32, pp32, p64]
+    L.mgx_not.argtypes = [vp, vp, u64, vp, u32, pp32, p64]
+    L.mgx_threshold.argtypes = [vp, vp, u32, u32, pp32, p64]
+    L.mgx_retain.argtypes = [vp, vp, u64, vp, u32, pp32, p64]
+    L.mgx_score_documents.argtypes = [vp, vp, u64, vp, vp, u32, f64, f64, f64, vp]
+    L.mgx_sort_by_score.argtypes = [vp, vp, vp, u64, i32, u32, u32, pp32, p64]
+    L.mgxt_corpus_generate.argtypes = [u64, u64, u64, i32, C.POINTER(vp)]
+    L.mgxt_corpus_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.mgxt_corpus_destroy.argtypes = [vp]
+    L.mgxt_corpus_destroy.restype = None
+    _lib = L
+    return L
+
+
+class MgxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mgx error %d: %s" % (code, message))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise MgxError(rc, load().mgx_last_error().decode("utf-8", "replace"))

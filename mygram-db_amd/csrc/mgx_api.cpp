@@ -1,0 +1,1212 @@
+// mgx_api.cpp — host side of libmygram_gpu.so: the C ABI of include/mygram_gpu.h.
+//
+// Responsibilities: device index construction (upload + skip rows + dense bitmaps), compiling queries into tile
+// programs (the planning rules of search_pipeline::Execute, src/server/search_pipeline.cpp:795-869, and
+// ApplyNotFilter :871-932 / ApplyFiltersWithBitmap :1196-1237 become instruction sequences), launching the kernels
+// of mgx_kernels.hip, and returning results in the reference's shapes. No CPU compute path exists here: every
+// operator either runs on the device or fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mygram_gpu.h"
+#include "mgx_host.hpp"
+#include "mgx_internal.hpp"
+#include "mgx_launch.hpp"
+
+namespace mgx {
+
+static thread_local std::string g_last_error;
+void SetError(const std::string& msg) { g_last_error = msg; }
+int Fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define MGX_HIP(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e__ = (expr);                                                                      \
+    if (e__ != hipSuccess)                                                                        \
+      return ::mgx::Fail(MGX_ERR_INTERNAL, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+  } while (0)
+#define MGX_LAUNCH(expr)                                                                                    \
+  do {                                                                                                      \
+    int e__ = (expr);                                                                                       \
+    if (e__ != 0)                                                                                           \
+      return ::mgx::Fail(MGX_ERR_INTERNAL,                                                                  \
+                         std::string(#expr) + ": " + hipGetErrorString(static_cast<hipError_t>(e__)));      \
+  } while (0)
+
+// Owning device buffer.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      Free();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { Free(); }
+  void Free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t Alloc(size_t n) {
+    Free();
+    bytes = n;
+    return hipMalloc(&p, n ? n : 16);
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+template <typename T>
+static hipError_t Upload(DevBuf& b, const T* host, size_t count, size_t pad_count = 0) {
+  hipError_t e = b.Alloc((count + pad_count) * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (pad_count) {
+    e = hipMemset(static_cast<char*>(b.p) + count * sizeof(T), 0xFF, pad_count * sizeof(T));
+    if (e != hipSuccess) return e;
+  }
+  if (count) e = hipMemcpy(b.p, host, count * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+}  // namespace mgx
+
+using mgx::DevBuf;
+
+// =================================================================================================================
+// index
+// =================================================================================================================
+
+struct mgx_index {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;  // serialises the single-operator entry points and filter registration
+  mgx::DevIndex dev{};
+  DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
+  std::vector<uint64_t> h_offsets;
+  std::vector<uint32_t> h_skip_row;  // per gram
+  std::vector<uint32_t> h_bm_row;    // per gram
+  uint32_t n_filter_rows = 0, filter_cap_rows = 0;
+  uint64_t n_grams = 0;
+  bool can_score = false;
+  uint64_t words_per_row = 0;  // n_tiles * 256
+};
+
+extern "C" {
+
+int mgx_abi_version(void) { return MGX_ABI_VERSION; }
+const char* mgx_last_error(void) { return mgx::g_last_error.c_str(); }
+void mgx_free(void* p) { std::free(p); }
+
+int mgx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+// ---- columns ----------------------------------------------------------------------------------------------------
+
+int mgx_columns_build(const mgx_build_params* params, const uint8_t* text_bytes, const uint64_t* text_off,
+                      uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out) {
+  if (out) *out = nullptr;
+  if (!params || !out || !text_off || (n_docs && !text_bytes && text_off[n_docs] != 0))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_build: null argument");
+  if (params->struct_size < sizeof(mgx_build_params) || params->version != MGX_ABI_VERSION)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_build: bad struct_size/version");
+  if (static_cast<uint64_t>(first_doc_id) + n_docs > 0xFFFFFFFFull)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_columns_build: doc ids exceed uint32");
+  try {
+    mgx::Columns* c = nullptr;
+    std::string err;
+    int rc = mgx::BuildColumns(*params, text_bytes, text_off, first_doc_id, n_docs, &c, &err);
+    if (rc != MGX_OK) return mgx::Fail(rc, err);
+    *out = reinterpret_cast<mgx_columns*>(c);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_columns_build: ") + e.what());
+  }
+}
+
+int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out) {
+  if (!cols || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_view_get: null argument");
+  mgx::ColumnsView(reinterpret_cast<const mgx::Columns*>(cols), out);
+  return MGX_OK;
+}
+
+int mgx_columns_lookup(const mgx_columns* cols, const uint8_t* gram, size_t len, uint32_t* gram_id, int* found) {
+  if (gram_id) *gram_id = 0;
+  if (found) *found = 0;
+  if (!cols || !gram_id || !found || (!gram && len))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_lookup: null argument");
+  uint32_t id = 0;
+  if (mgx::ColumnsLookup(reinterpret_cast<const mgx::Columns*>(cols), gram, len, &id)) {
+    *gram_id = id;
+    *found = 1;
+  }
+  return MGX_OK;
+}
+
+void mgx_columns_destroy(mgx_columns* cols) { mgx::DestroyColumns(reinterpret_cast<mgx::Columns*>(cols)); }
+
+// ---- index ------------------------------------------------------------------------------------------------------
+
+static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
+  auto idx = std::make_unique<mgx_index>();
+  idx->device = d->device;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return mgx::Fail(MGX_ERR_INTERNAL, "no HIP device available: libmygram_gpu has no CPU fallback");
+  }
+  if (d->device < 0 || d->device >= ndev) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: bad device");
+  MGX_HIP(hipSetDevice(d->device));
+  MGX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
+
+  const uint64_t G = d->n_grams;
+  const uint64_t P = G ? d->offsets[G] : 0;
+  const uint64_t n_docs = d->n_docs;
+  if (n_docs == 0 || n_docs > 0xFFFFFFFFull || static_cast<uint64_t>(d->first_doc_id) + n_docs > 0x100000000ull)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_create: n_docs must be in [1, 2^32) and ids fit uint32");
+  const uint32_t n_tiles = static_cast<uint32_t>((n_docs + mgx::kTileDocs - 1) >> mgx::kTileShift);
+  idx->n_grams = G;
+  idx->h_offsets.assign(d->offsets, d->offsets + G + 1);
+  idx->words_per_row = static_cast<uint64_t>(n_tiles) * mgx::kWordsPerTile;
+  idx->can_score = d->tf != nullptr && d->doc_len != nullptr;
+
+  MGX_HIP(mgx::Upload(idx->d_offsets, d->offsets, G + 1));
+  MGX_HIP(mgx::Upload(idx->d_docids, d->docids, P, 4));
+  if (idx->can_score) {
+    MGX_HIP(mgx::Upload(idx->d_tf, d->tf, P, 4));
+    MGX_HIP(mgx::Upload(idx->d_doc_len, d->doc_len, n_docs));
+  }
+
+  // which grams get a skip row / a dense bitmap
+  double dense_thr = d->dense_threshold == 0.0 ? 1.0 / 32.0 : d->dense_threshold;
+  const uint64_t skip_min = std::max<uint64_t>(64, static_cast<uint64_t>(n_tiles) + 1);
+  idx->h_skip_row.assign(G, mgx::kNoRow);
+  idx->h_bm_row.assign(G, mgx::kNoRow);
+  std::vector<uint32_t> skip_grams, bm_grams;
+  std::vector<uint64_t> bm_lo, bm_hi;
+  for (uint64_t g = 0; g < G; ++g) {
+    const uint64_t len = d->offsets[g + 1] - d->offsets[g];
+    if (len > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "a posting list exceeds 2^32 entries");
+    const bool dense = len > 0 && static_cast<double>(len) >= dense_thr * static_cast<double>(n_docs);
+    if (dense) {
+      idx->h_bm_row[g] = static_cast<uint32_t>(bm_grams.size());
+      bm_grams.push_back(static_cast<uint32_t>(g));
+      bm_lo.push_back(d->offsets[g]);
+      bm_hi.push_back(d->offsets[g + 1]);
+    }
+    if (dense || len >= skip_min) {
+      idx->h_skip_row[g] = static_cast<uint32_t>(skip_grams.size());
+      skip_grams.push_back(static_cast<uint32_t>(g));
+    }
+  }
+  MGX_HIP(mgx::Upload(idx->d_skip_row, idx->h_skip_row.data(), G));
+  {
+    DevBuf d_rows;
+    MGX_HIP(mgx::Upload(d_rows, skip_grams.data(), skip_grams.size()));
+    MGX_HIP(idx->d_tile_off.Alloc(skip_grams.size() * (static_cast<size_t>(n_tiles) + 1) * sizeof(uint32_t)));
+    MGX_LAUNCH(mgx::LaunchBuildTileOff(idx->d_offsets.as<uint64_t>(), idx->d_docids.as<uint32_t>(),
+                                       d_rows.as<uint32_t>(), static_cast<uint32_t>(skip_grams.size()), n_tiles,
+                                       d->first_doc_id, idx->d_tile_off.as<uint32_t>(), idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+  }
+  if (!bm_grams.empty()) {
+    DevBuf d_lo, d_hi;
+    MGX_HIP(mgx::Upload(d_lo, bm_lo.data(), bm_lo.size()));
+    MGX_HIP(mgx::Upload(d_hi, bm_hi.data(), bm_hi.size()));
+    MGX_HIP(idx->d_gram_bitmaps.Alloc(bm_grams.size() * idx->words_per_row * sizeof(uint64_t)));
+    MGX_HIP(hipMemsetAsync(idx->d_gram_bitmaps.p, 0, idx->d_gram_bitmaps.bytes, idx->stream));
+    MGX_LAUNCH(mgx::LaunchBuildBitmaps(idx->d_docids.as<uint32_t>(), d_lo.as<uint64_t>(), d_hi.as<uint64_t>(),
+                                       static_cast<uint32_t>(bm_grams.size()), d->first_doc_id, idx->words_per_row,
+                                       idx->d_gram_bitmaps.as<uint64_t>(), idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+  }
+
+  mgx::DevIndex& v = idx->dev;
+  v.offsets = idx->d_offsets.as<uint64_t>();
+  v.docids = idx->d_docids.as<uint32_t>();
+  v.tf = idx->d_tf.as<uint8_t>();
+  v.doc_len = idx->d_doc_len.as<uint32_t>();
+  v.skip_row = idx->d_skip_row.as<uint32_t>();
+  v.tile_off = idx->d_tile_off.as<uint32_t>();
+  v.gram_bitmaps = idx->d_gram_bitmaps.as<uint64_t>();
+  v.filter_bitmaps = nullptr;
+  v.first_doc_id = d->first_doc_id;
+  v.n_docs = static_cast<uint32_t>(n_docs);
+  v.n_tiles = n_tiles;
+  v.n_items = (n_tiles + mgx::kTilesPerItem - 1) / mgx::kTilesPerItem;
+  *out = idx.release();
+  return MGX_OK;
+}
+
+int mgx_index_create(const mgx_index_desc* desc, mgx_index** out) {
+  if (out) *out = nullptr;
+  if (!desc || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: null argument");
+  if (desc->struct_size < sizeof(mgx_index_desc) || desc->version != MGX_ABI_VERSION)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: bad struct_size/version");
+  if (desc->tile_shift != 0 && desc->tile_shift != static_cast<uint32_t>(mgx::kTileShift))
+    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_index_create: only tile_shift 14 is built");
+  if (!desc->offsets || (desc->n_grams && desc->offsets[desc->n_grams] && !desc->docids))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: null posting arrays");
+  try {
+    return IndexCreateImpl(desc, out);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_create: ") + e.what());
+  }
+}
+
+void mgx_index_destroy(mgx_index* idx) {
+  if (!idx) return;
+  (void)hipSetDevice(idx->device);
+  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  delete idx;
+}
+
+int mgx_posting_size(const mgx_index* idx, uint32_t gram_id, uint64_t* out) {
+  if (out) *out = 0;
+  if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_posting_size: null argument");
+  if (gram_id >= idx->n_grams) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_posting_size: unknown gram id");
+  *out = idx->h_offsets[gram_id + 1] - idx->h_offsets[gram_id];
+  return MGX_OK;
+}
+
+int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
+  if (out) *out = 0;
+  if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
+  *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
+         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes;
+  return MGX_OK;
+}
+
+int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id) {
+  if (out_bitmap_id) *out_bitmap_id = 0;
+  if (!idx || !out_bitmap_id || (n && !docids))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_add_filter_bitmap: null argument");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  MGX_HIP(hipSetDevice(idx->device));
+  for (uint64_t i = 0; i < n; ++i) {
+    if (docids[i] < idx->dev.first_doc_id || docids[i] - idx->dev.first_doc_id >= idx->dev.n_docs)
+      return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_add_filter_bitmap: doc id outside the index range");
+  }
+  if (idx->n_filter_rows == idx->filter_cap_rows) {
+    const uint32_t ncap = idx->filter_cap_rows ? idx->filter_cap_rows * 2 : 8;
+    DevBuf nb;
+    MGX_HIP(nb.Alloc(static_cast<size_t>(ncap) * idx->words_per_row * sizeof(uint64_t)));
+    if (idx->n_filter_rows)
+      MGX_HIP(hipMemcpy(nb.p, idx->d_filter_bitmaps.p,
+                        static_cast<size_t>(idx->n_filter_rows) * idx->words_per_row * sizeof(uint64_t),
+                        hipMemcpyDeviceToDevice));
+    idx->d_filter_bitmaps = std::move(nb);
+    idx->filter_cap_rows = ncap;
+    idx->dev.filter_bitmaps = idx->d_filter_bitmaps.as<uint64_t>();
+  }
+  const uint32_t row = idx->n_filter_rows;
+  uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->words_per_row;
+  MGX_HIP(hipMemsetAsync(dst, 0, idx->words_per_row * sizeof(uint64_t), idx->stream));
+  if (n) {
+    DevBuf d_ids, d_lo, d_hi;
+    MGX_HIP(mgx::Upload(d_ids, docids, n));
+    const uint64_t lo = 0, hi = n;
+    MGX_HIP(mgx::Upload(d_lo, &lo, 1));
+    MGX_HIP(mgx::Upload(d_hi, &hi, 1));
+    MGX_LAUNCH(mgx::LaunchBuildBitmaps(d_ids.as<uint32_t>(), d_lo.as<uint64_t>(), d_hi.as<uint64_t>(), 1,
+                                       idx->dev.first_doc_id, idx->words_per_row, dst, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+  } else {
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+  }
+  idx->n_filter_rows++;
+  *out_bitmap_id = row;
+  return MGX_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================================
+// query compilation
+// =================================================================================================================
+
+namespace mgx {
+
+// One compiled query, before upload.
+struct QuerySpec {
+  std::vector<DevLeaf> leaves;
+  std::vector<uint32_t> prog;
+  std::vector<DevScoreTerm> score;
+  std::vector<uint32_t> explicit_ids;  // for kLeafExplicit leaves (offsets are relative to this vector)
+  uint32_t mode = kModeBitmap;
+  uint32_t limit = 0, offset = 0, reverse = 0;
+  uint32_t stack_depth = 0;
+  double k1 = 1.2, b = 0.75, avgdl = 0.0;
+  uint64_t list_postings = 0;  // sum of |L| over gram operands (algorithmic bytes = 4x)
+};
+
+struct Compiler {
+  const mgx_index* idx;
+  QuerySpec* q;
+  std::unordered_map<uint32_t, uint32_t> gram_leaf;
+  uint32_t sp = 0;
+
+  uint32_t GramLeaf(uint32_t g) {
+    auto it = gram_leaf.find(g);
+    if (it != gram_leaf.end()) return it->second;
+    DevLeaf lf{};
+    lf.a = g;
+    if (idx->h_bm_row[g] != kNoRow) {
+      lf.kind = kLeafGramBitmap;
+      lf.b = idx->h_bm_row[g];
+    } else {
+      lf.kind = kLeafList;
+    }
+    const uint32_t id = static_cast<uint32_t>(q->leaves.size());
+    q->leaves.push_back(lf);
+    gram_leaf[g] = id;
+    q->list_postings += idx->h_offsets[g + 1] - idx->h_offsets[g];
+    return id;
+  }
+  void Emit(Op op, uint32_t arg = 0) {
+    q->prog.push_back(MakeInstr(op, arg));
+    if (op == kOpPush) {
+      ++sp;
+      q->stack_depth = std::max(q->stack_depth, sp);
+    } else if (op == kOpPopAnd || op == kOpPopOr || op == kOpPopAndNot) {
+      --sp;
+    }
+  }
+  // acc = the term's doc set: AND of its grams, or "at least threshold of them"
+  // (SearchTermDocuments, search_pipeline.cpp:438-446; fuzzy terms :1697-1702)
+  void LoadTerm(const mgx_term& t) {
+    if (t.threshold != 0 && t.threshold < t.n_grams) {
+      Emit(kOpThreshBegin);
+      for (uint32_t i = 0; i < t.n_grams; ++i) Emit(kOpThreshAdd, GramLeaf(t.gram_ids[i]));
+      Emit(kOpThreshEnd, t.threshold);
+    } else {
+      Emit(kOpLoad, GramLeaf(t.gram_ids[0]));
+      for (uint32_t i = 1; i < t.n_grams; ++i) Emit(kOpAnd, GramLeaf(t.gram_ids[i]));
+    }
+  }
+};
+
+static int ValidateTerm(const mgx_index* idx, const mgx_term& t, const char* what) {
+  if (t.n_grams == 0 || !t.gram_ids) return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": term without grams");
+  if (t.n_grams > 127) return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": more than 127 grams in a term");
+  for (uint32_t i = 0; i < t.n_grams; ++i)
+    if (t.gram_ids[i] >= idx->n_grams) return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": unknown gram id");
+  return MGX_OK;
+}
+
+// search_pipeline::Execute (:812-853) as a tile program. Counter slots: 0 total_candidates, 1 after_intersection,
+// 2 after_not, 3 after_filters.
+static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* out) {
+  if (in.n_terms == 0 || !in.terms) return Fail(MGX_ERR_INVALID_ARGUMENT, "query without positive terms");
+  if (in.n_terms > MGX_MAX_TERMS || in.n_not_terms > MGX_MAX_TERMS || in.n_filters > MGX_MAX_TERMS)
+    return Fail(MGX_ERR_OUT_OF_RANGE, "more than 64 terms / NOT terms / filters (query_parser.h:270-272)");
+  Compiler c{idx, out, {}, 0};
+  for (uint32_t i = 0; i < in.n_terms; ++i) {
+    int rc = ValidateTerm(idx, in.terms[i], "term");
+    if (rc) return rc;
+  }
+  for (uint32_t i = 0; i < in.n_not_terms; ++i) {
+    int rc = ValidateTerm(idx, in.not_terms[i], "NOT term");
+    if (rc) return rc;
+  }
+  c.LoadTerm(in.terms[0]);
+  c.Emit(kOpCount, 0);
+  for (uint32_t i = 1; i < in.n_terms; ++i) {
+    const mgx_term& t = in.terms[i];
+    if (t.threshold != 0 && t.threshold < t.n_grams) {
+      c.Emit(kOpPush);
+      c.LoadTerm(t);
+      c.Emit(kOpPopAnd);
+    } else {
+      for (uint32_t g = 0; g < t.n_grams; ++g) c.Emit(kOpAnd, c.GramLeaf(t.gram_ids[g]));
+    }
+  }
+  c.Emit(kOpCount, 1);
+  for (uint32_t i = 0; i < in.n_not_terms; ++i) {
+    const mgx_term& t = in.not_terms[i];
+    if (t.n_grams == 1 && !(t.threshold != 0 && t.threshold < t.n_grams)) {
+      c.Emit(kOpAndNot, c.GramLeaf(t.gram_ids[0]));
+    } else {
+      c.Emit(kOpPush);
+      c.LoadTerm(t);
+      c.Emit(kOpPopAndNot);
+    }
+  }
+  c.Emit(kOpCount, 2);
+  for (uint32_t i = 0; i < in.n_filters; ++i) {
+    if (in.filters[i].bitmap_id >= idx->n_filter_rows) return Fail(MGX_ERR_OUT_OF_RANGE, "unknown filter bitmap id");
+    DevLeaf lf{};
+    lf.kind = kLeafFilterBitmap;
+    lf.b = in.filters[i].bitmap_id;
+    const uint32_t id = static_cast<uint32_t>(out->leaves.size());
+    out->leaves.push_back(lf);
+    c.Emit(in.filters[i].negate ? kOpAndNot : kOpAnd, id);
+  }
+  c.Emit(kOpCount, 3);
+
+  out->limit = in.limit;
+  out->offset = in.offset;
+  out->reverse = in.reverse;
+  out->k1 = in.k1;
+  out->b = in.b;
+  out->avgdl = in.avg_doc_length;
+  if (in.sort == MGX_SORT_SCORE) {
+    if (!idx->can_score) return Fail(MGX_ERR_NOT_IMPLEMENTED, "index was created without tf/doc_len columns");
+    const uint64_t needed = static_cast<uint64_t>(in.offset) + in.limit;
+    if (in.limit == 0 || needed > kMaxNeeded)
+      return Fail(MGX_ERR_NOT_IMPLEMENTED,
+                  "fused SORT _score handles 0 < offset+limit <= 1024; page deeper through mgx_score_documents + "
+                  "mgx_sort_by_score");
+    if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 16 scored terms");
+    out->mode = kModeScore;
+    for (uint32_t i = 0; i < in.n_terms; ++i) {
+      const mgx_term& t = in.terms[i];
+      if (t.n_grams != 1)
+        return Fail(MGX_ERR_NOT_IMPLEMENTED,
+                    "BM25 on the device needs every scored term to be exactly one n-gram long (tf column)");
+      DevScoreTerm st{};
+      st.leaf = c.GramLeaf(t.gram_ids[0]);
+      st.idf = t.idf;
+      out->score.push_back(st);
+    }
+  } else if (in.sort == MGX_SORT_DOCID) {
+    out->mode = kModeBitmap;
+  } else {
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "unknown sort");
+  }
+  if (out->leaves.size() > kMaxLeaves)
+    return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct operand lists in one query");
+  return MGX_OK;
+}
+
+}  // namespace mgx
+
+// =================================================================================================================
+// batch
+// =================================================================================================================
+
+struct mgx_batch {
+  mgx_index* idx = nullptr;
+  uint32_t n_queries = 0;
+  std::vector<mgx::QuerySpec> specs;
+  // per mode: the queries of that mode, in batch order
+  struct Group {
+    std::vector<uint32_t> qids;  // batch index of each member
+    mgx::DevBatch dev{};
+    mgx::LdsPlan plan{};
+    DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident;
+    std::vector<unsigned long long> h_counters;
+  };
+  Group score, bitmap;
+  // score group outputs
+  DevBuf d_cand_keys, d_cand_docs, d_cand_n, d_top_keys, d_top_docs, d_top_n, d_page_docs, d_page_scores, d_page_n;
+  DevBuf d_total_override;
+  uint32_t top_stride = 0, page_stride = 0;
+  bool merged_shards = false;
+  // bitmap group outputs
+  DevBuf d_rbits, d_tile_cnt, d_tile_start, d_totals, d_take, d_out_off, d_reverse, d_out;
+  // host results
+  std::vector<mgx_query_result> h_results;
+  std::vector<uint32_t> h_docs;
+  std::vector<double> h_scores;
+  bool executed = false;
+  hipStream_t last_stream = nullptr;
+  // kernel timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  uint64_t list_bytes = 0;
+};
+
+namespace mgx {
+
+static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
+  const uint32_t n = static_cast<uint32_t>(g.qids.size());
+  if (n == 0) return MGX_OK;
+  std::vector<DevQuery> dq(n);
+  std::vector<DevLeaf> leaves;
+  std::vector<uint32_t> prog;
+  std::vector<DevScoreTerm> score;
+  std::vector<uint32_t> expl;
+  uint32_t max_leaves = 0, max_score = 0, max_stack = 0, max_instr = 0, max_cap = 64;
+  for (uint32_t i = 0; i < n; ++i) {
+    const QuerySpec& s = b->specs[g.qids[i]];
+    DevQuery& q = dq[i];
+    std::memset(&q, 0, sizeof(q));
+    q.leaf_begin = static_cast<uint32_t>(leaves.size());
+    q.n_leaves = static_cast<uint32_t>(s.leaves.size());
+    q.prog_begin = static_cast<uint32_t>(prog.size());
+    q.n_instr = static_cast<uint32_t>(s.prog.size());
+    q.score_begin = static_cast<uint32_t>(score.size());
+    q.n_score = static_cast<uint32_t>(s.score.size());
+    q.mode = s.mode;
+    q.limit = s.limit;
+    q.offset = s.offset;
+    q.needed = s.offset + s.limit;
+    uint32_t cap = 64;
+    while (cap < q.needed) cap <<= 1;
+    q.cap = cap;
+    q.descending = s.reverse;
+    q.stack_depth = s.stack_depth;
+    q.out_slot = i;
+    q.k1 = s.k1;
+    q.b = s.b;
+    q.one_minus_b = 1.0 - s.b;
+    q.k1_plus_1 = s.k1 + 1.0;
+    q.avgdl_clamped = std::max(s.avgdl, 1.0);  // bm25_scorer.cpp:81
+    const uint32_t ebase = static_cast<uint32_t>(expl.size());
+    for (DevLeaf lf : s.leaves) {
+      if (lf.kind == kLeafExplicit) lf.a += ebase;
+      leaves.push_back(lf);
+    }
+    prog.insert(prog.end(), s.prog.begin(), s.prog.end());
+    score.insert(score.end(), s.score.begin(), s.score.end());
+    expl.insert(expl.end(), s.explicit_ids.begin(), s.explicit_ids.end());
+    while (expl.size() % 4) expl.push_back(0xFFFFFFFFu);
+    max_leaves = std::max(max_leaves, q.n_leaves);
+    max_score = std::max(max_score, q.n_score);
+    max_stack = std::max(max_stack, q.stack_depth);
+    max_instr = std::max(max_instr, q.n_instr);
+    max_cap = std::max(max_cap, q.cap);
+    b->list_bytes += 4 * s.list_postings;
+  }
+  g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode);
+  if (g.plan.bytes > 160 * 1024) return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
+  MGX_HIP(Upload(g.d_queries, dq.data(), dq.size()));
+  MGX_HIP(Upload(g.d_leaves, leaves.data(), leaves.size()));
+  MGX_HIP(Upload(g.d_prog, prog.data(), prog.size()));
+  MGX_HIP(Upload(g.d_score, score.data(), score.size()));
+  MGX_HIP(Upload(g.d_explicit, expl.data(), expl.size(), 4));
+  MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 8 * sizeof(unsigned long long)));
+  std::vector<uint32_t> ident(n);
+  for (uint32_t i = 0; i < n; ++i) ident[i] = i;
+  MGX_HIP(Upload(g.d_ident, ident.data(), n));
+  g.h_counters.assign(static_cast<size_t>(n) * 8, 0);
+  DevBatch& d = g.dev;
+  d.queries = g.d_queries.as<DevQuery>();
+  d.leaves = g.d_leaves.as<DevLeaf>();
+  d.prog = g.d_prog.as<uint32_t>();
+  d.score_terms = g.d_score.as<DevScoreTerm>();
+  d.explicit_pool = g.d_explicit.as<uint32_t>();
+  d.n_queries = n;
+  d.counters = g.d_counters.as<unsigned long long>();
+  if (score_mode) {
+    uint32_t max_needed = 1, max_limit = 1;
+    for (const DevQuery& q : dq) {
+      max_needed = std::max(max_needed, q.needed);
+      max_limit = std::max(max_limit, q.limit);
+    }
+    const size_t items = b->idx->dev.n_items;
+    d.cand_stride = max_needed;
+    b->top_stride = max_needed;
+    b->page_stride = max_limit;
+    MGX_HIP(b->d_cand_keys.Alloc(static_cast<size_t>(n) * items * max_needed * 8));
+    MGX_HIP(b->d_cand_docs.Alloc(static_cast<size_t>(n) * items * max_needed * 4));
+    MGX_HIP(b->d_cand_n.Alloc(static_cast<size_t>(n) * items * 4));
+    MGX_HIP(b->d_top_keys.Alloc(static_cast<size_t>(n) * max_needed * 8));
+    MGX_HIP(b->d_top_docs.Alloc(static_cast<size_t>(n) * max_needed * 4));
+    MGX_HIP(b->d_top_n.Alloc(static_cast<size_t>(n) * 4));
+    MGX_HIP(b->d_page_docs.Alloc(static_cast<size_t>(n) * max_limit * 4));
+    MGX_HIP(b->d_page_scores.Alloc(static_cast<size_t>(n) * max_limit * 8));
+    MGX_HIP(b->d_page_n.Alloc(static_cast<size_t>(n) * 4));
+    MGX_HIP(b->d_total_override.Alloc(static_cast<size_t>(n) * 8));
+    d.cand_keys = b->d_cand_keys.as<uint64_t>();
+    d.cand_docs = b->d_cand_docs.as<uint32_t>();
+    d.cand_n = b->d_cand_n.as<uint32_t>();
+  } else {
+    const size_t tiles = b->idx->dev.n_tiles;
+    MGX_HIP(b->d_rbits.Alloc(static_cast<size_t>(n) * tiles * kWordsPerTile * 8));
+    MGX_HIP(b->d_tile_cnt.Alloc(static_cast<size_t>(n) * tiles * 4));
+    MGX_HIP(b->d_tile_start.Alloc(static_cast<size_t>(n) * tiles * 8));
+    MGX_HIP(b->d_totals.Alloc(static_cast<size_t>(n) * 8));
+    MGX_HIP(b->d_take.Alloc(static_cast<size_t>(n) * 8));
+    MGX_HIP(b->d_out_off.Alloc(static_cast<size_t>(n) * 8));
+    std::vector<uint32_t> rev(n);
+    for (uint32_t i = 0; i < n; ++i) rev[i] = b->specs[g.qids[i]].reverse;
+    MGX_HIP(Upload(b->d_reverse, rev.data(), n));
+    d.rbits = b->d_rbits.as<uint64_t>();
+    d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
+  }
+  return MGX_OK;
+}
+
+static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_batch** out) {
+  auto b = std::make_unique<mgx_batch>();
+  b->idx = idx;
+  b->n_queries = static_cast<uint32_t>(specs.size());
+  b->specs = std::move(specs);
+  for (uint32_t i = 0; i < b->n_queries; ++i)
+    (b->specs[i].mode == kModeScore ? b->score : b->bitmap).qids.push_back(i);
+  MGX_HIP(hipSetDevice(idx->device));
+  int rc = UploadGroup(b.get(), b->score, true);
+  if (rc) return rc;
+  rc = UploadGroup(b.get(), b->bitmap, false);
+  if (rc) return rc;
+  b->h_results.assign(b->n_queries, mgx_query_result{});
+  *out = b.release();
+  return MGX_OK;
+}
+
+static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
+  mgx_index* idx = b->idx;
+  MGX_HIP(hipSetDevice(idx->device));
+  b->merged_shards = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (b->timing) {
+    MGX_HIP(hipEventCreate(&ev0));
+    MGX_HIP(hipEventCreate(&ev1));
+  }
+  bool timed = false;
+  if (!b->score.qids.empty()) {
+    mgx_batch::Group& g = b->score;
+    MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
+    if (b->timing) {
+      MGX_HIP(hipEventRecord(ev0, s));
+    }
+    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
+    if (b->timing) {
+      MGX_HIP(hipEventRecord(ev1, s));
+      timed = true;
+    }
+    const uint32_t n = static_cast<uint32_t>(g.qids.size());
+    MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, idx->dev.n_items, g.dev.cand_keys,
+                               g.dev.cand_docs, g.dev.cand_n, g.dev.cand_stride, /*q_mul=*/idx->dev.n_items,
+                               /*j_mul=*/1, b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
+                               b->d_top_n.as<uint32_t>(), b->top_stride, b->d_page_docs.as<uint32_t>(),
+                               b->d_page_scores.as<double>(), b->d_page_n.as<uint32_t>(), b->page_stride, s));
+  }
+  if (!b->bitmap.qids.empty()) {
+    mgx_batch::Group& g = b->bitmap;
+    MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
+    if (b->timing && !timed) {
+      MGX_HIP(hipEventRecord(ev0, s));
+    }
+    MGX_LAUNCH(LaunchTileEval(kModeBitmap, idx->dev, g.dev, g.plan, s));
+    if (b->timing && !timed) {
+      MGX_HIP(hipEventRecord(ev1, s));
+      timed = true;
+    }
+    MGX_LAUNCH(LaunchScanTiles(g.dev.tile_cnt, static_cast<uint32_t>(g.qids.size()), idx->dev.n_tiles,
+                               b->d_tile_start.as<uint64_t>(), b->d_totals.as<uint64_t>(), s));
+  }
+  if (b->timing) {
+    if (timed) {
+      b->events.emplace_back(ev0, ev1);
+    } else {
+      (void)hipEventDestroy(ev0);
+      (void)hipEventDestroy(ev1);
+    }
+  }
+  b->executed = true;
+  b->last_stream = s;
+  return MGX_OK;
+}
+
+static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
+  mgx_index* idx = b->idx;
+  MGX_HIP(hipSetDevice(idx->device));
+  hipStream_t s = b->last_stream;
+  MGX_HIP(hipStreamSynchronize(s));
+  b->h_docs.clear();
+  b->h_scores.clear();
+  // ---- score group ----
+  std::vector<uint32_t> page_n, page_docs;
+  std::vector<double> page_scores;
+  std::vector<unsigned long long> override_tot;
+  if (!b->score.qids.empty()) {
+    mgx_batch::Group& g = b->score;
+    const size_t n = g.qids.size();
+    page_n.resize(n);
+    page_docs.resize(n * b->page_stride);
+    page_scores.resize(n * b->page_stride);
+    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, g.d_counters.bytes, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(page_n.data(), b->d_page_n.p, n * 4, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(page_docs.data(), b->d_page_docs.p, page_docs.size() * 4, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(page_scores.data(), b->d_page_scores.p, page_scores.size() * 8, hipMemcpyDeviceToHost));
+    if (b->merged_shards) {
+      override_tot.resize(n);
+      MGX_HIP(hipMemcpy(override_tot.data(), b->d_total_override.p, n * 8, hipMemcpyDeviceToHost));
+    }
+  }
+  // ---- bitmap group: totals -> page sizes -> expand ----
+  std::vector<uint64_t> totals, take, out_off;
+  std::vector<uint32_t> bm_docs;
+  if (!b->bitmap.qids.empty()) {
+    mgx_batch::Group& g = b->bitmap;
+    const size_t n = g.qids.size();
+    totals.resize(n);
+    take.resize(n);
+    out_off.resize(n);
+    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, g.d_counters.bytes, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(totals.data(), b->d_totals.p, n * 8, hipMemcpyDeviceToHost));
+    uint64_t at = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const QuerySpec& sp = b->specs[g.qids[i]];
+      take[i] = sp.limit == 0 ? totals[i] : std::min<uint64_t>(totals[i], sp.limit);
+      out_off[i] = at;
+      at += take[i];
+    }
+    if (at > 0xFFFFFFFFull) return Fail(MGX_ERR_OUT_OF_RANGE, "batch result exceeds 2^32 doc ids");
+    bm_docs.resize(at);
+    if (at) {
+      if (b->d_out.bytes < at * 4) MGX_HIP(b->d_out.Alloc(at * 4));
+      MGX_HIP(hipMemcpyAsync(b->d_take.p, take.data(), n * 8, hipMemcpyHostToDevice, s));
+      MGX_HIP(hipMemcpyAsync(b->d_out_off.p, out_off.data(), n * 8, hipMemcpyHostToDevice, s));
+      MGX_LAUNCH(LaunchExpand(g.dev.rbits, b->d_tile_start.as<uint64_t>(), b->d_totals.as<uint64_t>(),
+                              b->d_take.as<uint64_t>(), b->d_out_off.as<uint64_t>(), b->d_reverse.as<uint32_t>(),
+                              static_cast<uint32_t>(n), idx->dev.n_tiles, idx->dev.first_doc_id,
+                              b->d_out.as<uint32_t>(), s));
+      MGX_HIP(hipMemcpyAsync(bm_docs.data(), b->d_out.p, at * 4, hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+    }
+  }
+  // ---- assemble in batch order ----
+  std::vector<uint32_t> pos_in_group(b->n_queries, 0);
+  for (size_t i = 0; i < b->score.qids.size(); ++i) pos_in_group[b->score.qids[i]] = static_cast<uint32_t>(i);
+  for (size_t i = 0; i < b->bitmap.qids.size(); ++i) pos_in_group[b->bitmap.qids[i]] = static_cast<uint32_t>(i);
+  for (uint32_t qi = 0; qi < b->n_queries; ++qi) {
+    mgx_query_result& r = b->h_results[qi];
+    const uint32_t gi = pos_in_group[qi];
+    const bool sc = b->specs[qi].mode == kModeScore;
+    const unsigned long long* c = (sc ? b->score : b->bitmap).h_counters.data() + static_cast<size_t>(gi) * 8;
+    r.total_candidates = c[0];
+    r.after_intersection = c[1];
+    r.after_not = c[2];
+    r.after_filters = c[3];
+    r.total = c[4];
+    r.docs_begin = static_cast<uint32_t>(b->h_docs.size());
+    if (sc) {
+      if (b->merged_shards) r.total = override_tot[gi];
+      r.n_docs = page_n[gi];
+      for (uint32_t k = 0; k < r.n_docs; ++k) {
+        b->h_docs.push_back(page_docs[static_cast<size_t>(gi) * b->page_stride + k]);
+        b->h_scores.push_back(page_scores[static_cast<size_t>(gi) * b->page_stride + k]);
+      }
+    } else {
+      r.n_docs = static_cast<uint32_t>(take[gi]);
+      for (uint64_t k = 0; k < take[gi]; ++k) {
+        b->h_docs.push_back(bm_docs[out_off[gi] + k]);
+        b->h_scores.push_back(0.0);
+      }
+    }
+  }
+  out->n_queries = b->n_queries;
+  out->queries = b->h_results.data();
+  out->docs = b->h_docs.data();
+  out->scores = b->h_scores.data();
+  return MGX_OK;
+}
+
+}  // namespace mgx
+
+extern "C" {
+
+int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queries, mgx_batch** out) {
+  if (out) *out = nullptr;
+  if (!idx || !out || (n_queries && !queries))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_prepare: null argument");
+  try {
+    std::vector<mgx::QuerySpec> specs(n_queries);
+    for (uint32_t i = 0; i < n_queries; ++i) {
+      int rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
+      if (rc) {
+        mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
+        return rc;
+      }
+    }
+    return mgx::PrepareFromSpecs(idx, std::move(specs), out);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_prepare: ") + e.what());
+  }
+}
+
+int mgx_batch_execute(mgx_batch* batch, void* hip_stream) {
+  if (!batch) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_execute: null batch");
+  try {
+    return mgx::ExecuteImpl(batch, static_cast<hipStream_t>(hip_stream));
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_execute: ") + e.what());
+  }
+}
+
+int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out) {
+  if (out) std::memset(out, 0, sizeof(*out));
+  if (!batch || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_fetch: null argument");
+  if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_fetch: batch was never executed");
+  try {
+    return mgx::FetchImpl(batch, out);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_fetch: ") + e.what());
+  }
+}
+
+int mgx_batch_export_topk(mgx_batch* batch, uint64_t* keys_out, uint32_t* docs_out, uint32_t* counts_out,
+                          uint64_t* totals_out, uint32_t* stride, void* hip_stream) {
+  if (!batch || !stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null argument");
+  if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: every query must be MGX_SORT_SCORE");
+  *stride = batch->top_stride;
+  if (!keys_out) return MGX_OK;  // size query
+  if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: not executed");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t n = batch->score.qids.size();
+  MGX_HIP(hipSetDevice(batch->idx->device));
+  MGX_HIP(hipMemcpyAsync(keys_out, batch->d_top_keys.p, n * batch->top_stride * 8, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(docs_out, batch->d_top_docs.p, n * batch->top_stride * 4, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(counts_out, batch->d_top_n.p, n * 4, hipMemcpyDeviceToDevice, s));
+  // totals: counter slot 4 of every query
+  MGX_HIP(hipMemcpy2DAsync(totals_out, 8, static_cast<char*>(batch->score.d_counters.p) + 4 * 8, 64, 8, n,
+                           hipMemcpyDeviceToDevice, s));
+  return MGX_OK;
+}
+
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* keys, const uint32_t* docs,
+                           const uint32_t* counts, const uint64_t* totals, void* hip_stream) {
+  if (!batch || !keys || !docs || !counts || !totals || n_shards == 0)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: null argument");
+  if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: every query must be MGX_SORT_SCORE");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
+  MGX_HIP(hipSetDevice(batch->idx->device));
+  MGX_LAUNCH(mgx::LaunchMergeTopK(batch->score.dev.queries, batch->score.d_ident.as<uint32_t>(), n, n_shards, keys,
+                                  docs, counts, batch->top_stride, /*q_mul=*/1, /*j_mul=*/n, nullptr, nullptr, nullptr,
+                                  0, batch->d_page_docs.as<uint32_t>(), batch->d_page_scores.as<double>(),
+                                  batch->d_page_n.as<uint32_t>(), batch->page_stride, s));
+  MGX_LAUNCH(mgx::LaunchSumTotals(totals, n_shards, n, batch->d_total_override.as<uint64_t>(), s));
+  batch->merged_shards = true;
+  batch->last_stream = s;
+  return MGX_OK;
+}
+
+int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes,
+                                uint64_t* topk_bytes) {
+  if (!batch || !list_bytes || !score_bytes || !topk_bytes)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_algorithmic_bytes: null argument");
+  *list_bytes = batch->list_bytes;
+  uint64_t sb = 0, tb = 0;
+  for (uint32_t qi = 0; qi < batch->n_queries; ++qi) {
+    const mgx::QuerySpec& sp = batch->specs[qi];
+    const uint64_t R = batch->h_results[qi].total;
+    if (sp.mode == mgx::kModeScore) {
+      sb += R * (sp.score.size() + 4);
+      tb += 12 * std::min<uint64_t>(R, static_cast<uint64_t>(sp.offset) + sp.limit);
+    } else {
+      tb += 4 * std::min<uint64_t>(R, sp.limit ? sp.limit : R);
+    }
+  }
+  *score_bytes = sb;
+  *topk_bytes = tb;
+  return MGX_OK;
+}
+
+int mgx_batch_kernel_time_ms(mgx_batch* batch, double* avg_ms, uint32_t* n) {
+  if (avg_ms) *avg_ms = 0.0;
+  if (n) *n = 0;
+  if (!batch || !avg_ms || !n) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_kernel_time_ms: null argument");
+  MGX_HIP(hipSetDevice(batch->idx->device));
+  double sum = 0.0;
+  uint32_t cnt = 0;
+  for (auto& ev : batch->events) {
+    MGX_HIP(hipEventSynchronize(ev.second));
+    float ms = 0.f;
+    MGX_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+    sum += ms;
+    ++cnt;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  batch->events.clear();
+  batch->timing = true;
+  *avg_ms = cnt ? sum / cnt : 0.0;
+  *n = cnt;
+  return MGX_OK;
+}
+
+void mgx_batch_destroy(mgx_batch* batch) {
+  if (!batch) return;
+  (void)hipSetDevice(batch->idx->device);
+  for (auto& ev : batch->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  delete batch;
+}
+
+// =================================================================================================================
+// single operators
+// =================================================================================================================
+
+static int RunSingle(mgx_index* idx, mgx::QuerySpec&& spec, uint32_t** out_docs, uint64_t* out_n) {
+  *out_docs = nullptr;
+  *out_n = 0;
+  std::lock_guard<std::mutex> lock(idx->mu);
+  std::vector<mgx::QuerySpec> specs;
+  specs.push_back(std::move(spec));
+  mgx_batch* b = nullptr;
+  int rc = mgx::PrepareFromSpecs(idx, std::move(specs), &b);
+  if (rc) return rc;
+  std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> guard(b, mgx_batch_destroy);
+  rc = mgx::ExecuteImpl(b, idx->stream);
+  if (rc) return rc;
+  mgx_result_view v{};
+  rc = mgx::FetchImpl(b, &v);
+  if (rc) return rc;
+  const uint32_t n = v.queries[0].n_docs;
+  uint32_t* o = static_cast<uint32_t*>(std::malloc((n ? n : 1) * sizeof(uint32_t)));
+  if (!o) return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
+  if (n) std::memcpy(o, v.docs, n * sizeof(uint32_t));
+  *out_docs = o;
+  *out_n = n;
+  return MGX_OK;
+}
+
+static int CheckGrams(const mgx_index* idx, const uint32_t* g, uint32_t n, const char* what) {
+  if (n && !g) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": null gram ids");
+  for (uint32_t i = 0; i < n; ++i)
+    if (g[i] >= idx->n_grams) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": unknown gram id");
+  return MGX_OK;
+}
+
+#define MGX_SINGLE_PROLOGUE(name)                                                                    \
+  if (out_docs) *out_docs = nullptr;                                                                 \
+  if (out_n) *out_n = 0;                                                                             \
+  if (!idx || !out_docs || !out_n) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, name ": null argument"); \
+  {                                                                                                  \
+    int rc_ = CheckGrams(idx, gram_ids, n, name);                                                    \
+    if (rc_) return rc_;                                                                             \
+  }
+
+int mgx_and(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint64_t limit, int reverse, uint32_t** out_docs,
+            uint64_t* out_n) {
+  MGX_SINGLE_PROLOGUE("mgx_and");
+  if (n == 0) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_and: no grams (the caller returns {} for empty terms)");
+  if (limit > 0xFFFFFFFFull) limit = 0;
+  try {
+    mgx::QuerySpec q;
+    mgx::Compiler c{idx, &q, {}, 0};
+    c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
+    for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpAnd, c.GramLeaf(gram_ids[i]));
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_and: more than 40 lists");
+    q.limit = static_cast<uint32_t>(limit);
+    q.reverse = reverse ? 1 : 0;
+    return RunSingle(idx, std::move(q), out_docs, out_n);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_and: ") + e.what());
+  }
+}
+
+int mgx_or(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t** out_docs, uint64_t* out_n) {
+  MGX_SINGLE_PROLOGUE("mgx_or");
+  if (n == 0) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_or: no grams");
+  try {
+    mgx::QuerySpec q;
+    mgx::Compiler c{idx, &q, {}, 0};
+    c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
+    for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpOr, c.GramLeaf(gram_ids[i]));
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_or: more than 40 lists");
+    return RunSingle(idx, std::move(q), out_docs, out_n);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_or: ") + e.what());
+  }
+}
+
+int mgx_not(mgx_index* idx, const uint32_t* all_docs, uint64_t n_all, const uint32_t* gram_ids, uint32_t n,
+            uint32_t** out_docs, uint64_t* out_n) {
+  MGX_SINGLE_PROLOGUE("mgx_not");
+  if (n_all && !all_docs) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_not: null all_docs");
+  if (n_all > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_not: too many docs");
+  try {
+    mgx::QuerySpec q;
+    mgx::Compiler c{idx, &q, {}, 0};
+    // ids outside the index range cannot be in any posting list: they pass through untouched, in order
+    std::vector<uint32_t> below, above;
+    const uint64_t lo = idx->dev.first_doc_id, hi = lo + idx->dev.n_docs;
+    for (uint64_t i = 0; i < n_all; ++i) {
+      if (i && all_docs[i] <= all_docs[i - 1])
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_not: all_docs must be strictly ascending");
+      if (all_docs[i] < lo) below.push_back(all_docs[i]);
+      else if (all_docs[i] >= hi) above.push_back(all_docs[i]);
+      else q.explicit_ids.push_back(all_docs[i]);
+    }
+    mgx::DevLeaf lf{};
+    lf.kind = mgx::kLeafExplicit;
+    lf.a = 0;
+    lf.b = static_cast<uint32_t>(q.explicit_ids.size());
+    q.leaves.push_back(lf);
+    c.Emit(mgx::kOpLoad, 0);
+    for (uint32_t i = 0; i < n; ++i) c.Emit(mgx::kOpAndNot, c.GramLeaf(gram_ids[i]));
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_not: more than 40 lists");
+    uint32_t* mid = nullptr;
+    uint64_t n_mid = 0;
+    int rc = RunSingle(idx, std::move(q), &mid, &n_mid);
+    if (rc) return rc;
+    if (below.empty() && above.empty()) {
+      *out_docs = mid;
+      *out_n = n_mid;
+      return MGX_OK;
+    }
+    const uint64_t tot = below.size() + n_mid + above.size();
+    uint32_t* o = static_cast<uint32_t*>(std::malloc((tot ? tot : 1) * 4));
+    if (!o) {
+      std::free(mid);
+      return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
+    }
+    std::copy(below.begin(), below.end(), o);
+    std::copy(mid, mid + n_mid, o + below.size());
+    std::copy(above.begin(), above.end(), o + below.size() + n_mid);
+    std::free(mid);
+    *out_docs = o;
+    *out_n = tot;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_not: ") + e.what());
+  }
+}
+
+int mgx_threshold(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t threshold, uint32_t** out_docs,
+                  uint64_t* out_n) {
+  MGX_SINGLE_PROLOGUE("mgx_threshold");
+  if (n == 0 || threshold == 0 || threshold > n)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_threshold: need 1 <= threshold <= number of distinct grams");
+  if (n > 127) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_threshold: more than 127 grams");
+  try {
+    mgx::QuerySpec q;
+    mgx::Compiler c{idx, &q, {}, 0};
+    c.Emit(mgx::kOpThreshBegin);
+    for (uint32_t i = 0; i < n; ++i) c.Emit(mgx::kOpThreshAdd, c.GramLeaf(gram_ids[i]));
+    c.Emit(mgx::kOpThreshEnd, threshold);
+    if (q.leaves.size() != n) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_threshold: grams must be distinct");
+    if (q.leaves.size() > mgx::kMaxLeaves)
+      return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_threshold: more than 40 lists");
+    return RunSingle(idx, std::move(q), out_docs, out_n);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_threshold: ") + e.what());
+  }
+}
+
+int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids, uint32_t n,
+               uint32_t** out_docs, uint64_t* out_n) {
+  MGX_SINGLE_PROLOGUE("mgx_retain");
+  if (n_cand && !candidates) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_retain: null candidates");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    std::vector<uint8_t> keep(n_cand, 1);
+    if (n_cand && n) {
+      DevBuf d_c, d_g, d_k;
+      MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
+      MGX_HIP(mgx::Upload(d_g, gram_ids, n));
+      MGX_HIP(d_k.Alloc(n_cand));
+      MGX_LAUNCH(mgx::LaunchRetain(idx->dev, d_c.as<uint32_t>(), n_cand, d_g.as<uint32_t>(), n, d_k.as<uint8_t>(),
+                                   idx->stream));
+      MGX_HIP(hipMemcpyAsync(keep.data(), d_k.p, n_cand, hipMemcpyDeviceToHost, idx->stream));
+      MGX_HIP(hipStreamSynchronize(idx->stream));
+    }
+    uint32_t* o = static_cast<uint32_t*>(std::malloc((n_cand ? n_cand : 1) * 4));
+    if (!o) return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n_cand; ++i)
+      if (keep[i]) o[k++] = candidates[i];
+    *out_docs = o;
+    *out_n = k;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_retain: ") + e.what());
+  }
+}
+
+int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids,
+                        const double* idfs, uint32_t n_terms, double avg_doc_length, double k1, double b,
+                        double* scores_out) {
+  if (!idx || (n_cand && (!candidates || !scores_out)) || (n_terms && (!gram_ids || !idfs)))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_score_documents: null argument");
+  if (!idx->can_score) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "index was created without tf/doc_len columns");
+  for (uint32_t i = 0; i < n_terms; ++i)
+    if (gram_ids[i] != mgx::kNoRow && gram_ids[i] >= idx->n_grams)
+      return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_score_documents: unknown gram id");
+  if (n_cand == 0) return MGX_OK;
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    DevBuf d_c, d_g, d_i, d_s;
+    MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
+    MGX_HIP(mgx::Upload(d_g, gram_ids, n_terms));
+    MGX_HIP(mgx::Upload(d_i, idfs, n_terms));
+    MGX_HIP(d_s.Alloc(n_cand * 8));
+    MGX_LAUNCH(mgx::LaunchScoreCandidates(idx->dev, d_c.as<uint32_t>(), n_cand, d_g.as<uint32_t>(), d_i.as<double>(),
+                                          n_terms, k1, b, avg_doc_length, d_s.as<double>(), idx->stream));
+    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_score_documents: ") + e.what());
+  }
+}
+
+int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* scores, uint64_t n, int descending,
+                      uint32_t limit, uint32_t offset, uint32_t** out_docs, uint64_t* out_n) {
+  if (out_docs) *out_docs = nullptr;
+  if (out_n) *out_n = 0;
+  if (!idx || !out_docs || !out_n || (n && (!results || !scores)))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_sort_by_score: null argument");
+  const uint64_t start = std::min<uint64_t>(offset, n);
+  const uint64_t end = limit == 0 ? n : std::min<uint64_t>(start + limit, n);
+  uint32_t* o = static_cast<uint32_t*>(std::malloc(((end - start) ? (end - start) : 1) * 4));
+  if (!o) return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
+  *out_docs = o;
+  *out_n = end - start;
+  if (end == start) return MGX_OK;
+  if (n > 65536) {
+    std::free(o);
+    *out_docs = nullptr;
+    *out_n = 0;
+    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_sort_by_score: more than 65536 entries (use the fused batch path)");
+  }
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    DevBuf d_r, d_s, d_k, d_d, d_o;
+    MGX_HIP(mgx::Upload(d_r, results, n));
+    MGX_HIP(mgx::Upload(d_s, scores, n));
+    MGX_HIP(d_k.Alloc(n * 8));
+    MGX_HIP(d_d.Alloc(n * 4));
+    MGX_HIP(d_o.Alloc((end - start) * 4));
+    MGX_LAUNCH(mgx::LaunchSortByScore(d_r.as<uint32_t>(), d_s.as<double>(), n, descending,
+                                      static_cast<uint32_t>(start), static_cast<uint32_t>(end), d_k.as<uint64_t>(),
+                                      d_d.as<uint32_t>(), d_o.as<uint32_t>(), idx->stream));
+    MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,22 @@
+// mgx_host.hpp — host-side internals shared by the translation units of libmygram_gpu.so.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/mygram_gpu.h"
+
+namespace mgx {
+
+struct Columns;
+int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const uint64_t* text_off,
+                 uint32_t first_doc_id, uint64_t n_docs, Columns** out, std::string* err);
+void ColumnsView(const Columns* c, mgx_columns_view* v);
+bool ColumnsLookup(const Columns* c, const uint8_t* gram, size_t len, uint32_t* id);
+void DestroyColumns(Columns* c);
+
+// thread-local last-error message
+void SetError(const std::string& msg);
+int Fail(int code, const std::string& msg);
+
+}  // namespace mgx

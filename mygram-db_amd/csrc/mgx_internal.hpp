@@ -1,0 +1,133 @@
+// mgx_internal.hpp — structures shared by the host side of libmygram_gpu.so and its HIP kernels.
+//
+// Data layout in HBM (one index = one doc-range shard):
+//   offsets[G+1] u64, docids[P(+pad)] u32 (ascending per gram), tf[P] u8, doc_len[n_docs] u32 (by local slot),
+//   tile_off[rows][n_tiles+1] u32  : for every gram with a "skip row", the list-relative index of the first posting
+//                                    whose local slot is >= tile*16384 (the docid space is cut into 16384-doc tiles);
+//   gram_bitmaps[rows][n_tiles*256] u64 : dense grams additionally as one bit per local slot;
+//   filter_bitmaps[n][n_tiles*256] u64  : FilterIndex (column,value) doc sets.
+// Every set-algebra kernel works tile by tile on 16384-bit bitmaps held in LDS (one u64 word per thread of a
+// 256-thread workgroup), whatever representation the operand came from.
+#pragma once
+
+#include <cstdint>
+
+namespace mgx {
+
+constexpr int kBlock = 256;                       // threads per workgroup (4 wave64)
+constexpr int kTileShift = 14;                    // 16384 doc slots per tile
+constexpr uint32_t kTileDocs = 1u << kTileShift;  // = kBlock * 64 bits: one u64 bitmap word per thread
+constexpr int kWordsPerTile = kTileDocs / 64;     // 256
+constexpr int kTilesPerItem = 32;                 // tiles walked by one workgroup (a "supertile")
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+constexpr uint32_t kMaxLeaves = 40;               // operand bitmaps resident in LDS at once
+constexpr uint32_t kMaxScoreTerms = 16;
+constexpr uint32_t kMaxNeeded = 1024;             // offset+limit handled by the fused top-k
+constexpr uint32_t kMatchBuf = 2048;              // matches enumerated per scoring round
+
+// ---- operand kinds --------------------------------------------------------------------------------------------
+enum LeafKind : uint32_t {
+  kLeafList = 0,          // a = gram id (sorted u32 posting list, scattered into the LDS bitmap)
+  kLeafGramBitmap = 1,    // a = gram id, b = row in gram_bitmaps (precomputed dense bitmap, copied)
+  kLeafFilterBitmap = 2,  // b = row in filter_bitmaps
+  kLeafRange = 3,         // a = first local slot, b = one past the last local slot
+  kLeafExplicit = 4,      // a = offset, b = length of an ascending docid list in the batch's explicit pool
+};
+
+struct DevLeaf {
+  uint32_t kind, a, b, pad;
+};
+
+// ---- tile program: an accumulator machine over 64-bit bitmap words -------------------------------------------
+enum Op : uint32_t {
+  kOpLoad = 0,      // acc = W(leaf)
+  kOpAnd,           // acc &= W(leaf)
+  kOpOr,            // acc |= W(leaf)
+  kOpAndNot,        // acc &= ~W(leaf)
+  kOpPush,          // stack[sp++] = acc
+  kOpPopAnd,        // acc = stack[--sp] & acc
+  kOpPopOr,         // acc = stack[--sp] | acc
+  kOpPopAndNot,     // acc = stack[--sp] & ~acc
+  kOpCount,         // counter[arg] += popcount(acc)   (funnel counters)
+  kOpThreshBegin,   // bit-sliced counters = 0
+  kOpThreshAdd,     // counters += W(leaf)
+  kOpThreshEnd,     // acc = (counters >= arg)
+};
+inline constexpr uint32_t MakeInstr(Op op, uint32_t arg) { return (static_cast<uint32_t>(op) << 24) | (arg & 0xFFFFFFu); }
+
+struct DevScoreTerm {
+  uint32_t leaf;  // operand whose posting list carries the tf column
+  uint32_t pad;
+  double idf;
+};
+
+enum QueryMode : uint32_t {
+  kModeScore = 0,   // fused BM25 + per-workgroup top-k
+  kModeBitmap = 1,  // result bitmaps + per-tile counts to HBM (expanded to docids afterwards)
+};
+
+struct DevQuery {
+  uint32_t leaf_begin, n_leaves;
+  uint32_t prog_begin, n_instr;
+  uint32_t score_begin, n_score;
+  uint32_t mode;
+  uint32_t cap;       // C' : power of two >= needed, >= 32 (score mode)
+  uint32_t needed;    // offset + limit (0 => unbounded: not handled by the fused path)
+  uint32_t limit, offset;
+  uint32_t descending;
+  uint32_t stack_depth;
+  uint32_t out_slot;  // row of this query in the per-mode output arrays
+  double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;  // BM25 constants, pre-evaluated on the host
+};
+
+struct DevIndex {
+  const uint64_t* offsets;
+  const uint32_t* docids;
+  const uint8_t* tf;
+  const uint32_t* doc_len;
+  const uint32_t* skip_row;   // [G] row in tile_off, or kNoRow
+  const uint32_t* tile_off;   // [rows][n_tiles+1]
+  const uint64_t* gram_bitmaps;
+  const uint64_t* filter_bitmaps;
+  uint32_t first_doc_id;
+  uint32_t n_docs;
+  uint32_t n_tiles;
+  uint32_t n_items;           // ceil(n_tiles / kTilesPerItem)
+};
+
+struct DevBatch {
+  const DevQuery* queries;
+  const DevLeaf* leaves;
+  const uint32_t* prog;
+  const DevScoreTerm* score_terms;
+  const uint32_t* explicit_pool;
+  uint32_t n_queries;
+  // outputs
+  unsigned long long* counters;  // [n_queries][8]: funnel slots 0..3, slot 4 = final result count
+  // score mode: per (query, item) candidates, best first
+  uint64_t* cand_keys;   // [n_score_queries][n_items][cand_stride]
+  uint32_t* cand_docs;
+  uint32_t* cand_n;      // [n_score_queries][n_items]
+  uint32_t cand_stride;
+  // bitmap mode
+  uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]
+  uint32_t* tile_cnt;    // [n_bitmap_queries][n_tiles]
+};
+
+// LDS bytes the tile kernel needs for a launch whose queries have at most these shapes.
+struct LdsPlan {
+  uint32_t max_leaves, max_score, max_stack, max_instr, max_cap;
+  uint32_t bytes;
+};
+LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr, uint32_t max_cap,
+                bool score_mode);
+
+// Order-preserving key of a BM25 score for "larger is better" comparisons (scores are >= 0, so the IEEE bit pattern
+// orders like the value); ASC sorts flip both key and docid.
+inline uint64_t ScoreKeyHost(double s, bool descending) {
+  uint64_t u;
+  __builtin_memcpy(&u, &s, 8);
+  return descending ? u : ~u;
+}
+
+}  // namespace mgx

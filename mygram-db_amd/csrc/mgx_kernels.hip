@@ -1,0 +1,942 @@
+// mgx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the MygramDB query hot path.
+//
+// Kernel families (SURVEY.md §2.2 names in brackets):
+//   build_tile_off_kernel / build_bitmap_kernel  index-side precomputation (skip rows, dense bitmaps)
+//   tile_eval_kernel<kModeScore>   [K1+K2+K3+K5+K6+K7] set algebra over 16384-doc tiles + fused BM25 + top-k
+//   tile_eval_kernel<kModeBitmap>  [K1..K5] same algebra, result bitmaps + per-tile counts to HBM
+//   merge_topk_kernel              [K7/C1 merge] per-query merge of per-workgroup (or per-shard) sorted top-k lists
+//   scan_tiles_kernel / expand_kernel  result bitmaps -> ascending/descending docid pages
+//   retain_kernel                  [K4] Index::FilterByNgrams
+//   score_candidates_kernel        [K6] BM25Scorer::ScoreDocuments over an explicit candidate list
+//
+// All of them are HBM/LDS-bound integer work; none uses MFMA. One workgroup = 256 threads = 4 wave64; in the tile
+// kernels every thread owns one 64-bit word of each 16384-bit tile bitmap.
+#include <hip/hip_runtime.h>
+
+#include "mgx_internal.hpp"
+#include "mgx_launch.hpp"
+
+namespace mgx {
+
+// ---------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// LDS operations of one wave complete in issue order; this only has to stop the compiler from moving LDS accesses
+// of other lanes' data across it (and drains the wave's own outstanding LDS traffic).
+__device__ __forceinline__ void wave_lds_sync() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t n = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += n;
+  }
+  return v;
+}
+
+// first index in [lo, hi) whose docid is >= x
+__device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t* __restrict__ a, uint64_t lo, uint64_t hi,
+                                                    uint64_t x) {
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (static_cast<uint64_t>(a[mid]) < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint64_t score_key(double s, bool descending) {
+  uint64_t u = static_cast<uint64_t>(__double_as_longlong(s));
+  u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);  // total order of IEEE doubles as unsigned integers
+  return descending ? u : ~u;
+}
+__device__ __forceinline__ double key_score(uint64_t k, bool descending) {
+  uint64_t u = descending ? k : ~k;
+  u = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+  return __longlong_as_double(static_cast<long long>(u));
+}
+// ResultSorter::SortByScore comparator (result_sorter.cpp:681-686) in "larger is better" form:
+// DESC: higher score, then larger docid; ASC: lower score, then smaller docid (key and docid both flipped).
+__device__ __forceinline__ bool better(uint64_t ka, uint32_t da, uint64_t kb, uint32_t db) {
+  return ka > kb || (ka == kb && da > db);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS plan (shared with the host through PlanLds)
+// ---------------------------------------------------------------------------------------------------------------
+
+struct LdsOffsets {
+  uint32_t bm, stack, pref, prog, seg_lo, seg_hi, leaf, scan_tot, match, tk_keys, tk_docs, misc, total;
+};
+
+__host__ __device__ inline uint32_t align8(uint32_t x) { return (x + 7u) & ~7u; }
+
+__host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
+  LdsOffsets o;
+  uint32_t at = 0;
+  o.bm = at;        at += p.max_leaves * kBlock * 8;
+  o.stack = at;     at += p.max_stack * kBlock * 8;
+  o.seg_lo = at;    at += align8(p.max_leaves * 8);
+  o.seg_hi = at;    at += align8(p.max_leaves * 8);
+  o.leaf = at;      at += p.max_leaves * 16;
+  o.prog = at;      at += align8(p.max_instr * 4);
+  o.scan_tot = at;  at += 4 * 16 * 4;  // 4 waves x up to 16 packed scan lanes
+  o.misc = at;      at += 64;
+  o.pref = at;
+  o.match = at;
+  o.tk_keys = at;
+  o.tk_docs = at;
+  if (score_mode) {
+    at += align8((1 + p.max_score) * kBlock * 2);
+    o.match = at;    at += kMatchBuf * 2;
+    o.tk_keys = at;  at += 4 * 2 * p.max_cap * 8;
+    o.tk_docs = at;  at += 4 * 2 * p.max_cap * 4;
+  }
+  o.total = at;
+  return o;
+}
+
+LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr, uint32_t max_cap,
+                bool score_mode) {
+  LdsPlan p{max_leaves ? max_leaves : 1, max_score, max_stack, max_instr ? max_instr : 1, max_cap, 0};
+  p.bytes = carve(p, score_mode).total;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// index-side precomputation
+// ---------------------------------------------------------------------------------------------------------------
+
+// tile_off[row][t] = number of postings of gram rows_gram[row] whose local slot is < t * kTileDocs.
+__global__ void build_tile_off_kernel(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ docids,
+                                      const uint32_t* __restrict__ rows_gram, uint32_t n_rows, uint32_t n_tiles,
+                                      uint32_t first_doc_id, uint32_t* __restrict__ tile_off) {
+  uint64_t gid = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  uint64_t total = static_cast<uint64_t>(n_rows) * (n_tiles + 1);
+  if (gid >= total) return;
+  uint32_t row = static_cast<uint32_t>(gid / (n_tiles + 1));
+  uint32_t t = static_cast<uint32_t>(gid % (n_tiles + 1));
+  uint32_t g = rows_gram[row];
+  uint64_t lo = offsets[g], hi = offsets[g + 1];
+  uint64_t x = static_cast<uint64_t>(first_doc_id) + static_cast<uint64_t>(t) * kTileDocs;
+  tile_off[gid] = static_cast<uint32_t>(lower_bound_u32(docids, lo, hi, x) - lo);
+}
+
+// One workgroup-strided pass per row: bitmap[row][slot] = 1 for every posting of the row's doc list.
+__global__ void build_bitmap_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ row_lo,
+                                    const uint64_t* __restrict__ row_hi, uint32_t first_doc_id,
+                                    uint64_t words_per_row, unsigned long long* __restrict__ bitmaps) {
+  uint32_t row = blockIdx.y;
+  uint64_t lo = row_lo[row], hi = row_hi[row];
+  unsigned long long* bm = bitmaps + static_cast<uint64_t>(row) * words_per_row;
+  for (uint64_t p = lo + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < hi;
+       p += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    uint32_t slot = docids[p] - first_doc_id;
+    atomicOr(&bm[slot >> 6], 1ull << (slot & 63));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tile kernel
+// ---------------------------------------------------------------------------------------------------------------
+
+// Scatter the postings [lo, hi) of one sorted list into a 16384-bit LDS bitmap. Loads are 16 B per lane; a lane
+// merges its (up to 4, ascending) ids that fall in one 32-bit word before touching LDS, so a dense list costs about
+// one ds_or per lane instead of four.
+__device__ __forceinline__ void scatter_segment(const uint32_t* __restrict__ ids, uint64_t lo, uint64_t hi,
+                                                uint32_t tile_first_doc, uint32_t* __restrict__ bm32) {
+  uint64_t p0 = lo & ~3ull;
+  for (uint64_t p = p0 + 4ull * threadIdx.x; p < hi; p += 4ull * kBlock) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ids + p);
+    const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+    uint32_t curw = 0xFFFFFFFFu, curm = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint64_t q = p + j;
+      if (q >= lo && q < hi) {
+        uint32_t bit = e[j] - tile_first_doc;
+        uint32_t w = bit >> 5, m = 1u << (bit & 31);
+        if (w == curw) {
+          curm |= m;
+        } else {
+          if (curm) atomicOr(&bm32[curw], curm);
+          curw = w;
+          curm = m;
+        }
+      }
+    }
+    if (curm) atomicOr(&bm32[curw], curm);
+  }
+}
+
+// Per-wave running top-k in LDS: entries [0, cap) = best so far (sorted, best first, `have` valid),
+// entries [cap, 2cap) = pending survivors. Unused entries are (0,0), which every real entry beats.
+struct WaveTopK {
+  uint64_t* keys;
+  uint32_t* docs;
+  uint32_t cap, needed;
+  uint32_t have, pend;   // wave-uniform
+  uint64_t bound_key;    // valid when have >= needed
+  uint32_t bound_doc;
+};
+
+// In-LDS bitonic sort (best first) of all 2*cap entries by the 64 lanes of one wave, then keep the first cap.
+__device__ void wave_topk_truncate(WaveTopK& t) {
+  const uint32_t n = 2 * t.cap;
+  const int lane = lane_id();
+  wave_lds_sync();
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < n; i += 64) {
+        uint32_t l = i ^ j;
+        if (l > i) {
+          uint64_t ki = t.keys[i], kl = t.keys[l];
+          uint32_t di = t.docs[i], dl = t.docs[l];
+          bool first_block = (i & k) == 0;  // this block sorts best-first, the mirrored one worst-first
+          bool swap = first_block ? better(kl, dl, ki, di) : better(ki, di, kl, dl);
+          if (swap) {
+            t.keys[i] = kl; t.docs[i] = dl;
+            t.keys[l] = ki; t.docs[l] = di;
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+  uint32_t total = t.have + t.pend;
+  t.have = total < t.cap ? total : t.cap;
+  t.pend = 0;
+  for (uint32_t i = t.cap + lane; i < n; i += 64) {
+    t.keys[i] = 0;
+    t.docs[i] = 0;
+  }
+  wave_lds_sync();
+  if (t.have >= t.needed) {
+    t.bound_key = t.keys[t.needed - 1];
+    t.bound_doc = t.docs[t.needed - 1];
+  }
+}
+
+// Offer one candidate per lane (valid=false for idle lanes). Wave-uniform control flow.
+__device__ __forceinline__ void wave_topk_offer(WaveTopK& t, bool valid, uint64_t key, uint32_t doc) {
+  bool surv = valid && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
+  uint64_t mask = __ballot(surv);
+  if (mask == 0) return;
+  uint32_t ns = __popcll(mask);
+  if (t.pend + ns > t.cap) {
+    wave_topk_truncate(t);
+    surv = surv && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
+    mask = __ballot(surv);
+    if (mask == 0) return;
+    ns = __popcll(mask);
+  }
+  if (surv) {
+    uint32_t slot = t.cap + t.pend + __popcll(mask & ((1ull << lane_id()) - 1ull));
+    t.keys[slot] = key;
+    t.docs[slot] = doc;
+  }
+  t.pend += ns;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LdsOffsets lo_ = carve(plan, MODE == kModeScore);
+  uint64_t* const bm64 = reinterpret_cast<uint64_t*>(smem + lo_.bm);
+  uint64_t* const stack = reinterpret_cast<uint64_t*>(smem + lo_.stack);
+  uint64_t* const seg_lo = reinterpret_cast<uint64_t*>(smem + lo_.seg_lo);
+  uint64_t* const seg_hi = reinterpret_cast<uint64_t*>(smem + lo_.seg_hi);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + lo_.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + lo_.prog);
+  uint32_t* const scan_tot = reinterpret_cast<uint32_t*>(smem + lo_.scan_tot);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + lo_.misc);
+  uint16_t* const pref = reinterpret_cast<uint16_t*>(smem + lo_.pref);
+  uint16_t* const matchbuf = reinterpret_cast<uint16_t*>(smem + lo_.match);
+
+  const uint32_t tid = threadIdx.x;
+  const uint32_t qi = blockIdx.x % bt.n_queries;   // item-major: neighbouring workgroups walk the same doc range
+  const uint32_t item = blockIdx.x / bt.n_queries; // for different queries, so shared lists/doc_len hit in L2
+  const DevQuery q = bt.queries[qi];
+  if (q.mode != MODE) return;
+
+  const uint32_t n_leaves = q.n_leaves;
+  for (uint32_t i = tid; i < n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
+
+  WaveTopK tk;
+  if (MODE == kModeScore) {
+    tk.cap = q.cap;
+    tk.needed = q.needed;
+    tk.keys = reinterpret_cast<uint64_t*>(smem + lo_.tk_keys) + static_cast<size_t>(wave_id()) * 2 * q.cap;
+    tk.docs = reinterpret_cast<uint32_t*>(smem + lo_.tk_docs) + static_cast<size_t>(wave_id()) * 2 * q.cap;
+    tk.have = 0;
+    tk.pend = 0;
+    tk.bound_key = 0;
+    tk.bound_doc = 0;
+    for (uint32_t i = lane_id(); i < 2 * q.cap; i += 64) {
+      tk.keys[i] = 0;
+      tk.docs[i] = 0;
+    }
+  }
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+
+  const uint32_t tile_begin = item * kTilesPerItem;
+  const uint32_t tile_end = min(tile_begin + kTilesPerItem, ix.n_tiles);
+  __syncthreads();
+
+  for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
+    const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
+
+    // ---- A. operand setup: segment bounds, and bitmaps that need no scatter -----------------------------------
+    if (tid < n_leaves) {
+      const DevLeaf lf = leaf[tid];
+      uint64_t a = 0, b = 0;
+      if (lf.kind == kLeafList) {
+        const uint64_t l0 = ix.offsets[lf.a], l1 = ix.offsets[lf.a + 1];
+        const uint32_t row = ix.skip_row[lf.a];
+        if (row != kNoRow) {
+          const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+          a = l0 + r[tile];
+          b = l0 + r[tile + 1];
+        } else {
+          a = lower_bound_u32(ix.docids, l0, l1, tile_first);
+          b = lower_bound_u32(ix.docids, a, l1, tile_first + kTileDocs);
+        }
+      } else if (lf.kind == kLeafExplicit) {
+        a = lower_bound_u32(bt.explicit_pool, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
+        b = lower_bound_u32(bt.explicit_pool, a, static_cast<uint64_t>(lf.a) + lf.b, tile_first + kTileDocs);
+      } else if (lf.kind == kLeafGramBitmap) {
+        // rank base for tf lookups: postings of the gram before this tile
+        const uint32_t row = ix.skip_row[lf.a];
+        a = ix.offsets[lf.a] + ix.tile_off[static_cast<uint64_t>(row) * (ix.n_tiles + 1) + tile];
+      }
+      seg_lo[tid] = a;
+      seg_hi[tid] = b;
+    }
+    for (uint32_t l = 0; l < n_leaves; ++l) {
+      const DevLeaf lf = leaf[l];
+      uint64_t w = 0;
+      if (lf.kind == kLeafGramBitmap) {
+        w = ix.gram_bitmaps[(static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + tid];
+      } else if (lf.kind == kLeafFilterBitmap) {
+        w = ix.filter_bitmaps[(static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + tid];
+      } else if (lf.kind == kLeafRange) {
+        // slots [a, b) of the shard; this thread's word covers slots [s0, s0+64)
+        const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + static_cast<uint64_t>(tid) * 64;
+        const uint64_t ra = lf.a > s0 ? lf.a - s0 : 0;
+        const uint64_t rb = lf.b > s0 ? lf.b - s0 : 0;
+        const uint64_t hi_mask = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
+        const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
+        w = hi_mask & ~lo_mask;
+      }
+      bm64[l * kBlock + tid] = w;
+    }
+    __syncthreads();
+
+    // ---- B. scatter sorted segments into their bitmaps ---------------------------------------------------------
+    for (uint32_t l = 0; l < n_leaves; ++l) {
+      const uint32_t kind = leaf[l].kind;
+      if (kind == kLeafList) {
+        scatter_segment(ix.docids, seg_lo[l], seg_hi[l], static_cast<uint32_t>(tile_first),
+                        reinterpret_cast<uint32_t*>(bm64 + l * kBlock));
+      } else if (kind == kLeafExplicit) {
+        scatter_segment(bt.explicit_pool, seg_lo[l], seg_hi[l], static_cast<uint32_t>(tile_first),
+                        reinterpret_cast<uint32_t*>(bm64 + l * kBlock));
+      }
+    }
+    __syncthreads();
+
+    // ---- C. evaluate the query's program on this thread's 64-bit word ------------------------------------------
+    uint64_t acc = 0;
+    {
+      uint32_t sp = 0;
+      uint64_t cs[7] = {0, 0, 0, 0, 0, 0, 0};  // bit-sliced per-doc counters (one bit lane per doc slot)
+      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+        const uint32_t ins = prog[pc];
+        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+        switch (op) {
+          case kOpLoad: acc = bm64[arg * kBlock + tid]; break;
+          case kOpAnd: acc &= bm64[arg * kBlock + tid]; break;
+          case kOpOr: acc |= bm64[arg * kBlock + tid]; break;
+          case kOpAndNot: acc &= ~bm64[arg * kBlock + tid]; break;
+          case kOpPush: stack[sp * kBlock + tid] = acc; ++sp; break;
+          case kOpPopAnd: --sp; acc = stack[sp * kBlock + tid] & acc; break;
+          case kOpPopOr: --sp; acc = stack[sp * kBlock + tid] | acc; break;
+          case kOpPopAndNot: --sp; acc = stack[sp * kBlock + tid] & ~acc; break;
+          case kOpCount: {
+            const uint32_t pcnt = __popcll(acc);
+            cnt0 += arg == 0 ? pcnt : 0;
+            cnt1 += arg == 1 ? pcnt : 0;
+            cnt2 += arg == 2 ? pcnt : 0;
+            cnt3 += arg == 3 ? pcnt : 0;
+            break;
+          }
+          case kOpThreshBegin:
+#pragma unroll
+            for (int b = 0; b < 7; ++b) cs[b] = 0;
+            break;
+          case kOpThreshAdd: {
+            uint64_t carry = bm64[arg * kBlock + tid];
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+              const uint64_t t = cs[b] & carry;
+              cs[b] ^= carry;
+              carry = t;
+            }
+            break;
+          }
+          case kOpThreshEnd: {
+            // per-bit-lane compare of the 7-bit counters with the constant arg: ge = (count >= arg)
+            uint64_t gt = 0, eq = ~0ull;
+#pragma unroll
+            for (int b = 6; b >= 0; --b) {
+              const uint64_t tb = ((arg >> b) & 1u) ? ~0ull : 0ull;
+              gt |= eq & cs[b] & ~tb;
+              eq &= ~(cs[b] ^ tb);
+            }
+            acc = gt | eq;
+            break;
+          }
+          default: break;
+        }
+      }
+    }
+    const uint32_t my_cnt = __popcll(acc);
+    cnt_res += my_cnt;
+
+    if (MODE == kModeBitmap) {
+      const uint64_t obase = (static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile) * kWordsPerTile;
+      bt.rbits[obase + tid] = acc;
+      // per-tile count
+      uint32_t s = wave_incl_scan(my_cnt);
+      if (lane_id() == 63) scan_tot[wave_id()] = s;
+      __syncthreads();
+      if (tid == 0) {
+        bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile] =
+            scan_tot[0] + scan_tot[1] + scan_tot[2] + scan_tot[3];
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // ---- D. (score mode) ranks: exclusive prefix popcounts of the result and of every scored operand ----------
+    // quantities are packed two per u32 (a tile holds at most 16384 set bits, so 16 bits each)
+    const uint32_t n_q = 1 + q.n_score;
+    const uint32_t n_packed = (n_q + 1) >> 1;
+    uint32_t excl_res = 0;
+    for (uint32_t pk = 0; pk < n_packed; ++pk) {
+      const uint32_t qa = 2 * pk, qb = 2 * pk + 1;
+      const uint32_t va = qa == 0 ? my_cnt
+                                  : __popcll(bm64[bt.score_terms[q.score_begin + qa - 1].leaf * kBlock + tid]);
+      const uint32_t vb =
+          qb < n_q ? __popcll(bm64[bt.score_terms[q.score_begin + qb - 1].leaf * kBlock + tid]) : 0u;
+      const uint32_t v = va | (vb << 16);
+      const uint32_t inc = wave_incl_scan(v);
+      if (lane_id() == 63) scan_tot[wave_id() * 16 + pk] = inc;
+      // stash the wave-local exclusive value; the cross-wave offset is added after the barrier
+      const uint32_t ex = inc - v;
+      pref[qa * kBlock + tid] = static_cast<uint16_t>(ex & 0xFFFFu);
+      if (qb < n_q) pref[qb * kBlock + tid] = static_cast<uint16_t>(ex >> 16);
+    }
+    __syncthreads();
+    uint32_t total_matches = 0;
+    for (uint32_t pk = 0; pk < n_packed; ++pk) {
+      uint32_t off = 0, tot = 0;
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t t = scan_tot[w * 16 + pk];
+        if (w < wave_id()) off += t;
+        tot += t;
+      }
+      const uint32_t qa = 2 * pk, qb = 2 * pk + 1;
+      pref[qa * kBlock + tid] = static_cast<uint16_t>(pref[qa * kBlock + tid] + (off & 0xFFFFu));
+      if (qb < n_q) pref[qb * kBlock + tid] = static_cast<uint16_t>(pref[qb * kBlock + tid] + (off >> 16));
+      if (pk == 0) {
+        total_matches = tot & 0xFFFFu;
+        excl_res = pref[tid];
+      }
+    }
+    // (pref rows are read by other threads only after the barrier that follows the first enumeration)
+
+    // ---- E. enumerate matches into LDS in rank order, then score them one per lane -----------------------------
+    for (uint32_t rb = 0; rb < total_matches; rb += kMatchBuf) {
+      {
+        uint64_t bits = acc;
+        uint32_t r = excl_res;
+        while (bits) {
+          const uint32_t bpos = __builtin_ctzll(bits);
+          bits &= bits - 1;
+          if (r >= rb && r < rb + kMatchBuf) matchbuf[r - rb] = static_cast<uint16_t>(tid * 64 + bpos);
+          ++r;
+        }
+      }
+      __syncthreads();
+      const uint32_t nm = min(kMatchBuf, total_matches - rb);
+      for (uint32_t j0 = 0; j0 < nm; j0 += kBlock) {
+        const uint32_t j = j0 + tid;
+        const bool valid = j < nm;
+        double score = 0.0;
+        uint32_t doc = 0;
+        if (valid) {
+          const uint32_t d = matchbuf[j];
+          const uint32_t word = d >> 6, bit = d & 63;
+          const uint64_t below = (1ull << bit) - 1ull;
+          const uint32_t slot = tile * kTileDocs + d;
+          doc = ix.first_doc_id + slot;
+          const double dl = static_cast<double>(ix.doc_len[slot]);
+          // bm25_scorer.cpp:80-84, same operation order
+          const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+          for (uint32_t i = 0; i < q.n_score; ++i) {
+            const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+            const uint64_t wbits = bm64[st.leaf * kBlock + word];
+            if ((wbits >> bit) & 1ull) {
+              const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
+              const double tf = static_cast<double>(ix.tf[seg_lo[st.leaf] + rank]);
+              const double numerator = tf * q.k1_plus_1;
+              const double denominator = tf + q.k1 * length_norm;
+              score += st.idf * numerator / denominator;
+            }
+          }
+        }
+        const uint64_t key = score_key(score, q.descending != 0);
+        wave_topk_offer(tk, valid, key, q.descending ? doc : ~doc);
+      }
+      __syncthreads();
+    }
+    __syncthreads();  // bitmaps / pref / matchbuf are rewritten by the next tile
+  }
+
+  // ---- funnel counters: one atomic per wave per slot -----------------------------------------------------------
+  {
+    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t x = v[s];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if (lane_id() == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
+    }
+  }
+  if (MODE != kModeScore) return;
+
+  // ---- F. merge the four waves' lists into this workgroup's best `needed`, best first, to HBM ------------------
+  wave_topk_truncate(tk);
+  if (lane_id() == 0) misc[wave_id()] = tk.have;
+  __syncthreads();
+  {
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + lo_.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + lo_.tk_docs);
+    const uint32_t cap = q.cap;
+    uint32_t have[4];
+    uint32_t total = 0;
+    for (int w = 0; w < 4; ++w) {
+      have[w] = min(misc[w], q.needed);
+      total += have[w];
+    }
+    const uint64_t obase = (static_cast<uint64_t>(q.out_slot) * ix.n_items + item) * bt.cand_stride;
+    for (uint32_t e = tid; e < 4 * cap; e += kBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= have[w]) continue;
+      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+      // rank = entries of the other waves' (sorted) lists that beat this one, plus its own position
+      uint32_t rank = i;
+      for (uint32_t w2 = 0; w2 < 4; ++w2) {
+        if (w2 == w) continue;
+        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+        uint32_t lo = 0, hi = have[w2];
+        while (lo < hi) {  // first index whose entry does NOT beat (k,d)
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < q.needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = d;
+      }
+    }
+    if (tid == 0) bt.cand_n[static_cast<uint64_t>(q.out_slot) * ix.n_items + item] = min(total, q.needed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// merge of sorted candidate lists (per-workgroup lists of one shard, or per-shard lists of one query)
+// ---------------------------------------------------------------------------------------------------------------
+
+// lists: n_lists lists per query; list j of query slot qq is list L = qq*q_mul + j*j_mul: keys[L*stride ...],
+// cnt[L] valid entries, each sorted best-first (per-workgroup lists: q_mul = n_lists, j_mul = 1; per-shard lists
+// gathered as [shard][query]: q_mul = 1, j_mul = n_queries). Writes the merged best `needed` (best first) to top_keys/top_docs[qq*top_stride..]
+// and the page [offset, offset+limit) to page_docs/page_scores[qq*page_stride ..].
+__global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __restrict__ queries, uint32_t n_lists,
+                                                            const uint64_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ docs,
+                                                            const uint32_t* __restrict__ cnt, uint32_t stride,
+                                                            uint32_t q_mul, uint32_t j_mul,
+                                                            uint64_t* __restrict__ top_keys,
+                                                            uint32_t* __restrict__ top_docs,
+                                                            uint32_t* __restrict__ top_n, uint32_t top_stride,
+                                                            uint32_t* __restrict__ page_docs,
+                                                            double* __restrict__ page_scores,
+                                                            uint32_t* __restrict__ page_n, uint32_t page_stride,
+                                                            const uint32_t* __restrict__ query_ids) {
+  const uint32_t slot = blockIdx.x;
+  const DevQuery q = queries[query_ids[slot]];
+  const uint64_t lbase = static_cast<uint64_t>(slot) * q_mul;
+#define MGX_L(j) (lbase + static_cast<uint64_t>(j) * j_mul)
+  __shared__ uint32_t s_total;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  uint32_t local_total = 0;
+  for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) local_total += min(cnt[MGX_L(j)], q.needed);
+  if (local_total) atomicAdd(&s_total, local_total);
+  __syncthreads();
+  const uint32_t total = s_total;
+  const uint32_t merged = min(total, q.needed);
+  const uint32_t page_lo = min(q.offset, merged);
+  const uint32_t page_hi = q.limit == 0 ? merged : min(q.offset + q.limit, merged);
+
+  const uint64_t total_slots = static_cast<uint64_t>(n_lists) * q.needed;
+  for (uint64_t e = threadIdx.x; e < total_slots; e += kBlock) {
+    const uint32_t j = static_cast<uint32_t>(e / q.needed), i = static_cast<uint32_t>(e % q.needed);
+    if (i >= cnt[MGX_L(j)]) continue;
+    const uint64_t k = keys[MGX_L(j) * stride + i];
+    const uint32_t d = docs[MGX_L(j) * stride + i];
+    uint32_t rank = i;
+    for (uint32_t j2 = 0; j2 < n_lists && rank < q.needed; ++j2) {
+      if (j2 == j) continue;
+      const uint64_t* kk = keys + MGX_L(j2) * stride;
+      const uint32_t* dd = docs + MGX_L(j2) * stride;
+      uint32_t lo = 0, hi = min(cnt[MGX_L(j2)], q.needed);
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < q.needed) {
+      if (top_keys) {
+        top_keys[static_cast<uint64_t>(slot) * top_stride + rank] = k;
+        top_docs[static_cast<uint64_t>(slot) * top_stride + rank] = d;
+      }
+      if (page_docs && rank >= page_lo && rank < page_hi) {
+        page_docs[static_cast<uint64_t>(slot) * page_stride + rank - page_lo] = q.descending ? d : ~d;
+        page_scores[static_cast<uint64_t>(slot) * page_stride + rank - page_lo] = key_score(k, q.descending != 0);
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (top_n) top_n[slot] = merged;
+    if (page_n) page_n[slot] = page_hi - page_lo;
+  }
+#undef MGX_L
+}
+
+// out[q] = sum over shards of totals[shard][q]
+__global__ void sum_totals_kernel(const uint64_t* __restrict__ totals, uint32_t n_shards, uint32_t n_queries,
+                                  uint64_t* __restrict__ out) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_queries) return;
+  uint64_t s = 0;
+  for (uint32_t r = 0; r < n_shards; ++r) s += totals[static_cast<uint64_t>(r) * n_queries + q];
+  out[q] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// result bitmaps -> docid pages
+// ---------------------------------------------------------------------------------------------------------------
+
+// Exclusive scan of tile_cnt per bitmap-mode query (one workgroup each): tile_start[slot][t], total[slot].
+__global__ __launch_bounds__(kBlock) void scan_tiles_kernel(const uint32_t* __restrict__ tile_cnt, uint32_t n_tiles,
+                                                            uint64_t* __restrict__ tile_start,
+                                                            uint64_t* __restrict__ totals) {
+  __shared__ uint64_t s_carry;
+  __shared__ uint32_t s_w[4];
+  const uint32_t slot = blockIdx.x;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_tiles; base += kBlock) {
+    const uint32_t t = base + threadIdx.x;
+    const uint32_t v = t < n_tiles ? tile_cnt[static_cast<uint64_t>(slot) * n_tiles + t] : 0;
+    const uint32_t inc = wave_incl_scan(v);
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave_id(); ++w) off += s_w[w];
+    if (t < n_tiles) tile_start[static_cast<uint64_t>(slot) * n_tiles + t] = s_carry + off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kBlock - 1) s_carry += off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[slot] = s_carry;
+}
+
+// One workgroup per (tile, query): writes the tile's matches that fall inside the requested page.
+// Page = the first `take[slot]` ids in ascending order, or (reverse) the last `take[slot]` ids, descending.
+__global__ __launch_bounds__(kBlock) void expand_kernel(const uint64_t* __restrict__ rbits,
+                                                        const uint64_t* __restrict__ tile_start,
+                                                        const uint64_t* __restrict__ totals,
+                                                        const uint64_t* __restrict__ take,
+                                                        const uint64_t* __restrict__ out_off,
+                                                        const uint32_t* __restrict__ reverse, uint32_t n_tiles,
+                                                        uint32_t first_doc_id, uint32_t* __restrict__ out) {
+  const uint32_t tile = blockIdx.x, slot = blockIdx.y;
+  const uint64_t total = totals[slot], want = take[slot];
+  const uint64_t start = tile_start[static_cast<uint64_t>(slot) * n_tiles + tile];
+  const uint64_t end = tile + 1 < n_tiles ? tile_start[static_cast<uint64_t>(slot) * n_tiles + tile + 1] : total;
+  if (start == end) return;
+  const bool rev = reverse[slot] != 0;
+  // ranks wanted: ascending [0, want) ; reverse [total-want, total)
+  const uint64_t want_lo = rev ? total - want : 0, want_hi = rev ? total : want;
+  if (end <= want_lo || start >= want_hi) return;
+  __shared__ uint32_t s_w[4];
+  const uint64_t w = rbits[(static_cast<uint64_t>(slot) * n_tiles + tile) * kWordsPerTile + threadIdx.x];
+  const uint32_t c = __popcll(w);
+  const uint32_t inc = wave_incl_scan(c);
+  if (lane_id() == 63) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int i = 0; i < wave_id(); ++i) off += s_w[i];
+  uint64_t r = start + off + inc - c;
+  uint64_t bits = w;
+  while (bits) {
+    const uint32_t b = __builtin_ctzll(bits);
+    bits &= bits - 1;
+    if (r >= want_lo && r < want_hi) {
+      const uint32_t doc = first_doc_id + tile * kTileDocs + threadIdx.x * 64 + b;
+      const uint64_t pos = rev ? (total - 1 - r) : r;
+      out[out_off[slot] + pos] = doc;
+    }
+    ++r;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small-candidate operators
+// ---------------------------------------------------------------------------------------------------------------
+
+// Index::FilterByNgrams: keep[i] = candidate i is present in every list.
+__global__ void retain_kernel(DevIndex ix, const uint32_t* __restrict__ cand, uint64_t n_cand,
+                              const uint32_t* __restrict__ grams, uint32_t n_grams, uint8_t* __restrict__ keep) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_cand) return;
+  const uint32_t d = cand[i];
+  bool ok = d >= ix.first_doc_id && static_cast<uint64_t>(d) - ix.first_doc_id < ix.n_docs;
+  for (uint32_t t = 0; ok && t < n_grams; ++t) {
+    const uint32_t g = grams[t];
+    uint64_t lo = ix.offsets[g], hi = ix.offsets[g + 1];
+    const uint32_t row = ix.skip_row[g];
+    if (row != kNoRow) {
+      const uint32_t tile = (d - ix.first_doc_id) >> kTileShift;
+      const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+      hi = lo + r[tile + 1];
+      lo = lo + r[tile];
+    }
+    const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
+    ok = p < hi && ix.docids[p] == d;
+  }
+  keep[i] = ok ? 1 : 0;
+}
+
+// BM25Scorer::ScoreDocuments for single-gram terms over explicit candidates (bm25_scorer.cpp:71-91).
+__global__ void score_candidates_kernel(DevIndex ix, const uint32_t* __restrict__ cand, uint64_t n_cand,
+                                        const uint32_t* __restrict__ grams, const double* __restrict__ idfs,
+                                        uint32_t n_terms, double k1, double b, double one_minus_b, double k1_plus_1,
+                                        double avgdl_clamped, double* __restrict__ scores) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_cand) return;
+  const uint32_t d = cand[i];
+  double score = 0.0;
+  if (d >= ix.first_doc_id && static_cast<uint64_t>(d) - ix.first_doc_id < ix.n_docs) {
+    const uint32_t slot = d - ix.first_doc_id;
+    const uint32_t dli = ix.doc_len[slot];
+    if (dli > 0) {  // empty / missing text => 0.0
+      const double dl = static_cast<double>(dli);
+      const double length_norm = one_minus_b + b * dl / avgdl_clamped;
+      for (uint32_t t = 0; t < n_terms; ++t) {
+        const uint32_t g = grams[t];
+        if (g == kNoRow) continue;  // term unknown to the index: tf = 0 everywhere
+        uint64_t lo = ix.offsets[g], hi = ix.offsets[g + 1];
+        const uint32_t row = ix.skip_row[g];
+        if (row != kNoRow) {
+          const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+          hi = lo + r[(slot >> kTileShift) + 1];
+          lo = lo + r[slot >> kTileShift];
+        }
+        const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
+        if (p < hi && ix.docids[p] == d) {
+          const double tf = static_cast<double>(ix.tf[p]);
+          const double numerator = tf * k1_plus_1;
+          const double denominator = tf + k1 * length_norm;
+          score += idfs[t] * numerator / denominator;
+        }
+      }
+    }
+  }
+  scores[i] = score;
+}
+
+// (key, docid') pairs for ResultSorter::SortByScore on arbitrary inputs, and the trivial one-list "merge" input.
+__global__ void make_sort_keys_kernel(const uint32_t* __restrict__ docs, const double* __restrict__ scores,
+                                      uint64_t n, int descending, uint64_t* __restrict__ keys,
+                                      uint32_t* __restrict__ dprime) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double s = scores[i] + 0.0;  // -0.0 ties with +0.0 in the reference comparator
+  keys[i] = score_key(s, descending != 0);
+  dprime[i] = descending ? docs[i] : ~docs[i];
+}
+
+// rank-by-counting sort for SortByScore on device-resident (key, docid') pairs: rank[i] = entries that beat i.
+// O(n^2 / threads); used for result sets up to a few tens of thousands (larger ones are sorted on the host side of
+// the shim after scoring on the device).
+__global__ void rank_count_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ dprime, uint64_t n,
+                                  uint32_t lo, uint32_t hi, int descending, uint32_t* __restrict__ out) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = keys[i];
+  const uint32_t d = dprime[i];
+  uint32_t rank = 0;
+  for (uint64_t j = 0; j < n; ++j) rank += better(keys[j], dprime[j], k, d) ? 1u : 0u;
+  if (rank >= lo && rank < hi) out[rank - lo] = descending ? d : ~d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+
+#define MGX_KCHECK()                                   \
+  do {                                                 \
+    hipError_t e_ = hipGetLastError();                 \
+    if (e_ != hipSuccess) return static_cast<int>(e_); \
+  } while (0)
+
+int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const uint32_t* rows_gram, uint32_t n_rows,
+                       uint32_t n_tiles, uint32_t first_doc_id, uint32_t* tile_off, hipStream_t s) {
+  const uint64_t total = static_cast<uint64_t>(n_rows) * (n_tiles + 1);
+  if (total == 0) return 0;
+  const uint32_t blocks = static_cast<uint32_t>((total + 255) / 256);
+  hipLaunchKernelGGL(build_tile_off_kernel, dim3(blocks), dim3(256), 0, s, offsets, docids, rows_gram, n_rows,
+                     n_tiles, first_doc_id, tile_off);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
+                       uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s) {
+  if (n_rows == 0) return 0;
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
+    const uint32_t nr = n_rows - r0 < 32768 ? n_rows - r0 : 32768;
+    hipLaunchKernelGGL(build_bitmap_kernel, dim3(64, nr), dim3(256), 0, s, docids, row_lo + r0, row_hi + r0,
+                       first_doc_id, words_per_row,
+                       reinterpret_cast<unsigned long long*>(bitmaps + static_cast<uint64_t>(r0) * words_per_row));
+    MGX_KCHECK();
+  }
+  return 0;
+}
+
+int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s) {
+  const uint64_t grid = static_cast<uint64_t>(ix.n_items) * bt.n_queries;
+  if (grid == 0) return 0;
+  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  if (mode == kModeScore) {
+    if (plan.bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_eval_kernel<kModeScore>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(tile_eval_kernel<kModeScore>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s,
+                       ix, bt, plan);
+  } else {
+    if (plan.bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_eval_kernel<kModeBitmap>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+      if (e != hipSuccess) return static_cast<int>(e);
+    }
+    hipLaunchKernelGGL(tile_eval_kernel<kModeBitmap>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes,
+                       s, ix, bt, plan);
+  }
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
+                    const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint32_t stride, uint32_t q_mul,
+                    uint32_t j_mul, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n, uint32_t top_stride,
+                    uint32_t* page_docs, double* page_scores, uint32_t* page_n, uint32_t page_stride, hipStream_t s) {
+  if (n_slots == 0) return 0;
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, stride,
+                     q_mul, j_mul, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
+                     query_ids);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t* out, hipStream_t s) {
+  if (n_queries == 0) return 0;
+  hipLaunchKernelGGL(sum_totals_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, totals, n_shards, n_queries,
+                     out);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
+                    uint64_t* totals, hipStream_t s) {
+  if (n_slots == 0) return 0;
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_slots), dim3(kBlock), 0, s, tile_cnt, n_tiles, tile_start, totals);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchExpand(const uint64_t* rbits, const uint64_t* tile_start, const uint64_t* totals, const uint64_t* take,
+                 const uint64_t* out_off, const uint32_t* reverse, uint32_t n_slots, uint32_t n_tiles,
+                 uint32_t first_doc_id, uint32_t* out, hipStream_t s) {
+  if (n_slots == 0 || n_tiles == 0) return 0;
+  for (uint32_t s0 = 0; s0 < n_slots; s0 += 32768) {
+    const uint32_t ns = n_slots - s0 < 32768 ? n_slots - s0 : 32768;
+    hipLaunchKernelGGL(expand_kernel, dim3(n_tiles, ns), dim3(kBlock), 0, s,
+                       rbits + static_cast<uint64_t>(s0) * n_tiles * kWordsPerTile,
+                       tile_start + static_cast<uint64_t>(s0) * n_tiles, totals + s0, take + s0, out_off + s0,
+                       reverse + s0, n_tiles, first_doc_id, out);
+    MGX_KCHECK();
+  }
+  return 0;
+}
+
+int LaunchRetain(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint32_t* grams, uint32_t n_grams,
+                 uint8_t* keep, hipStream_t s) {
+  if (n_cand == 0) return 0;
+  hipLaunchKernelGGL(retain_kernel, dim3(static_cast<uint32_t>((n_cand + 255) / 256)), dim3(256), 0, s, ix, cand,
+                     n_cand, grams, n_grams, keep);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchScoreCandidates(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint32_t* grams,
+                          const double* idfs, uint32_t n_terms, double k1, double b, double avgdl, double* scores,
+                          hipStream_t s) {
+  if (n_cand == 0) return 0;
+  const double avg = avgdl > 1.0 ? avgdl : 1.0;
+  hipLaunchKernelGGL(score_candidates_kernel, dim3(static_cast<uint32_t>((n_cand + 255) / 256)), dim3(256), 0, s, ix,
+                     cand, n_cand, grams, idfs, n_terms, k1, b, 1.0 - b, k1 + 1.0, avg, scores);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchSortByScore(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint32_t lo,
+                      uint32_t hi, uint64_t* keys_tmp, uint32_t* dprime_tmp, uint32_t* out, hipStream_t s) {
+  if (n == 0) return 0;
+  const uint32_t blocks = static_cast<uint32_t>((n + 255) / 256);
+  hipLaunchKernelGGL(make_sort_keys_kernel, dim3(blocks), dim3(256), 0, s, docs, scores, n, descending, keys_tmp,
+                     dprime_tmp);
+  MGX_KCHECK();
+  hipLaunchKernelGGL(rank_count_kernel, dim3(blocks), dim3(256), 0, s, keys_tmp, dprime_tmp, n, lo, hi, descending,
+                     out);
+  MGX_KCHECK();
+  return 0;
+}
+
+}  // namespace mgx

@@ -1,0 +1,32 @@
+// mgx_launch.hpp — host-callable launchers of the kernels in mgx_kernels.hip. Return 0 or a hipError_t value.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include "mgx_internal.hpp"
+
+namespace mgx {
+
+int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const uint32_t* rows_gram, uint32_t n_rows,
+                       uint32_t n_tiles, uint32_t first_doc_id, uint32_t* tile_off, hipStream_t s);
+int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
+                       uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s);
+int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
+int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
+                    const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint32_t stride, uint32_t q_mul,
+                    uint32_t j_mul, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n, uint32_t top_stride,
+                    uint32_t* page_docs, double* page_scores, uint32_t* page_n, uint32_t page_stride, hipStream_t s);
+int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t* out, hipStream_t s);
+int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
+                    uint64_t* totals, hipStream_t s);
+int LaunchExpand(const uint64_t* rbits, const uint64_t* tile_start, const uint64_t* totals, const uint64_t* take,
+                 const uint64_t* out_off, const uint32_t* reverse, uint32_t n_slots, uint32_t n_tiles,
+                 uint32_t first_doc_id, uint32_t* out, hipStream_t s);
+int LaunchRetain(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint32_t* grams, uint32_t n_grams,
+                 uint8_t* keep, hipStream_t s);
+int LaunchScoreCandidates(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint32_t* grams,
+                          const double* idfs, uint32_t n_terms, double k1, double b, double avgdl, double* scores,
+                          hipStream_t s);
+int LaunchSortByScore(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint32_t lo,
+                      uint32_t hi, uint64_t* keys_tmp, uint32_t* dprime_tmp, uint32_t* out, hipStream_t s);
+
+}  // namespace mgx

@@ -1,0 +1,537 @@
+"""Host-side mirror of the reference's operator interface over the C ABI of libmygram_gpu.so.
+
+Names follow the reference (src/index/index.h, src/index/bm25_scorer.h, src/query/result_sorter.h,
+src/server/search_pipeline.h) so the parity tests read like the reference's own tests. Everything that computes on
+postings goes through the C ABI to the HIP kernels; what stays on the host is what the reference also does per query
+on the host before touching posting lists: normalisation, n-gram generation, dictionary lookup, term ordering and
+the empty/unknown-term rules.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, load
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# host-side string rules (src/utils/string_utils.cpp)
+# --------------------------------------------------------------------------------------------------------------------
+
+def _is_cjk_ideograph(cp):  # string_utils.cpp:441-448 — kana is NOT an ideograph here
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or
+            0x2A700 <= cp <= 0x2B73F or 0x2B740 <= cp <= 0x2B81F or 0xF900 <= cp <= 0xFAFF)
+
+
+def _generate_ngrams(text, n):  # string_utils.cpp:382-423
+    if n <= 0 or len(text) < n:
+        return []
+    return [text[i:i + n] for i in range(len(text) - n + 1)]
+
+
+def _generate_hybrid_ngrams(text, ascii_n, kanji_n, cross_boundary):  # string_utils.cpp:452-509
+    out = []
+    if ascii_n <= 0 or kanji_n <= 0:
+        return out
+    for i, ch in enumerate(text):
+        cjk = _is_cjk_ideograph(ord(ch))
+        n = kanji_n if cjk else ascii_n
+        if i + n > len(text):
+            continue
+        if not cross_boundary and any(_is_cjk_ideograph(ord(c)) != cjk for c in text[i + 1:i + n]):
+            continue
+        out.append(text[i:i + n])
+    return out
+
+
+def generate_query_ngrams(normalized, ngram_size, kanji_ngram_size, cross_boundary=True):
+    """GenerateQueryNgrams, string_utils.cpp:639-653 (returns str grams, in text order)."""
+    if kanji_ngram_size > 0:
+        return _generate_hybrid_ngrams(normalized, ngram_size if ngram_size > 0 else 2, kanji_ngram_size,
+                                       cross_boundary)
+    if ngram_size == 0:
+        return _generate_hybrid_ngrams(normalized, 2, 1, True)
+    return _generate_ngrams(normalized, ngram_size)
+
+
+def normalize_text(text):
+    """Index::NormalizeText restricted to what this build restates: ASCII lower-casing (non-ICU branch,
+    string_utils.cpp:371-377). NFKC / width folding (ICU) is not rebuilt: callers pass NFKC-normal text."""
+    return "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in text)
+
+
+def compute_idf(total_docs, doc_freq):
+    """BM25Scorer::ComputeIDF, src/index/bm25_scorer.cpp:14-25 (host side: once per term per query)."""
+    if total_docs == 0:
+        return 0.0
+    df = min(doc_freq, total_docs)
+    return math.log((float(total_docs) - float(df) + 0.5) / (float(df) + 0.5) + 1.0)
+
+
+def _np_view(ptr, count, dtype):
+    if not ptr or count == 0:
+        return np.zeros(0, dtype=dtype)
+    nbytes = int(count) * np.dtype(dtype).itemsize
+    buf = (C.c_uint8 * nbytes).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=int(count))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# corpus / columns / device index
+# --------------------------------------------------------------------------------------------------------------------
+
+class Corpus:
+    """Normalized document texts as (text_bytes u8, text_off u64[n+1])."""
+
+    def __init__(self, text_bytes, text_off, _owner=None):
+        self.text_bytes, self.text_off, self._owner = text_bytes, text_off, _owner
+        self.n_docs = len(text_off) - 1
+
+    @classmethod
+    def from_texts(cls, texts):
+        bs = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in texts]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        if bs:
+            off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        data = np.frombuffer(b"".join(bs) + b"\0" * 16, dtype=np.uint8).copy()
+        return cls(data, off)
+
+    @classmethod
+    def synthetic(cls, n_docs, seed=42, global_first=0, n_threads=0):
+        """The deterministic ASCII corpus of include/mygram_tools.h."""
+        L = load()
+        h = C.c_void_p()
+        rc = L.mgxt_corpus_generate(seed, global_first, n_docs, n_threads, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("mgxt_corpus_generate rc=%d" % rc)
+        tb, to, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        L.mgxt_corpus_view(h, C.byref(tb), C.byref(to), C.byref(n))
+        off = _np_view(to.value, n.value + 1, np.uint64)
+        data = _np_view(tb.value, int(off[-1]) + 16, np.uint8)
+
+        class _Owner:
+            def __init__(self, handle):
+                self.handle = handle
+
+            def __del__(self):
+                load().mgxt_corpus_destroy(self.handle)
+
+        return cls(data, off, _Owner(h))
+
+    def text(self, i):
+        return bytes(self.text_bytes[int(self.text_off[i]):int(self.text_off[i + 1])])
+
+
+class Columns:
+    """mgx_columns: gram dictionary + CSR postings + tf + doc_len, built on the host by libmygram_gpu."""
+
+    def __init__(self, corpus, first_doc_id=1, ngram_size=2, kanji_ngram_size=0, cross_boundary=True, n_threads=0):
+        L = load()
+        self.ngram_size, self.kanji_ngram_size, self.cross_boundary = ngram_size, kanji_ngram_size, cross_boundary
+        bp = _capi.BuildParams(C.sizeof(_capi.BuildParams), _capi.ABI_VERSION, ngram_size, kanji_ngram_size,
+                               int(cross_boundary), n_threads)
+        h = C.c_void_p()
+        check(L.mgx_columns_build(C.byref(bp), corpus.text_bytes.ctypes.data, corpus.text_off.ctypes.data,
+                                  first_doc_id, corpus.n_docs, C.byref(h)))
+        self._h = h
+        v = _capi.ColumnsView()
+        check(L.mgx_columns_view_get(h, C.byref(v)))
+        self.view = v
+        self.n_grams = int(v.n_grams)
+        self.n_postings = int(v.n_postings)
+        self.first_doc_id = int(v.first_doc_id)
+        self.n_docs = int(v.n_docs)
+        self.bm25_doc_count = int(v.bm25_doc_count)
+        self.bm25_total_len = int(v.bm25_total_len)
+        self.key_off = _np_view(v.key_off, self.n_grams + 1, np.uint32)
+        self.key_bytes = _np_view(v.key_bytes, int(self.key_off[-1]) if self.n_grams else 0, np.uint8)
+        self.offsets = _np_view(v.offsets, self.n_grams + 1, np.uint64)
+        self.docids = _np_view(v.docids, self.n_postings, np.uint32)
+        self.tf = _np_view(v.tf, self.n_postings, np.uint8)
+        self.doc_len = _np_view(v.doc_len, self.n_docs, np.uint32)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgx_columns_destroy(self._h)
+            self._h = None
+
+    def lookup(self, gram):
+        """gram (str/bytes) -> gram id, or None when the gram is not in the index."""
+        g = gram.encode("utf-8") if isinstance(gram, str) else bytes(gram)
+        gid, found = C.c_uint32(), C.c_int()
+        check(load().mgx_columns_lookup(self._h, g, len(g), C.byref(gid), C.byref(found)))
+        return int(gid.value) if found.value else None
+
+    def gram(self, gid):
+        return bytes(self.key_bytes[int(self.key_off[gid]):int(self.key_off[gid + 1])])
+
+    def avg_doc_length(self):  # BM25Stats::avg_doc_length, server_types.h:182-187
+        return self.bm25_total_len / self.bm25_doc_count if self.bm25_doc_count else 0.0
+
+
+class DeviceIndex:
+    """mgx_index: one doc-range shard resident in HBM."""
+
+    def __init__(self, columns, device=0, dense_threshold=0.0, with_scoring=True):
+        L = load()
+        v = columns.view
+        d = _capi.IndexDesc(C.sizeof(_capi.IndexDesc), _capi.ABI_VERSION, device, 0, v.first_doc_id, v.n_docs,
+                            v.n_grams, v.offsets, v.docids, v.tf if with_scoring else None,
+                            v.doc_len if with_scoring else None, dense_threshold)
+        h = C.c_void_p()
+        check(L.mgx_index_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgx_index_destroy(self._h)
+            self._h = None
+
+    def memory_bytes(self):
+        n = C.c_uint64()
+        check(load().mgx_index_memory_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def add_filter_bitmap(self, docids):
+        a = np.ascontiguousarray(docids, dtype=np.uint32)
+        out = C.c_uint32()
+        check(load().mgx_index_add_filter_bitmap(self._h, a.ctypes.data, len(a), C.byref(out)))
+        return int(out.value)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# queries
+# --------------------------------------------------------------------------------------------------------------------
+
+class Query:
+    """The parts of query::Query (src/query/query_parser.h:207-243) the hot path consumes."""
+
+    def __init__(self, terms, not_terms=(), filters=(), sort_score=False, limit=100, offset=0, descending=True,
+                 k1=1.2, b=0.75, fuzzy=0):
+        self.terms, self.not_terms, self.filters = list(terms), list(not_terms), list(filters)
+        self.sort_score, self.limit, self.offset, self.descending = sort_score, limit, offset, descending
+        self.k1, self.b, self.fuzzy = k1, b, fuzzy
+
+
+class TermInfo:
+    """search_pipeline::SearchTermInfo (src/server/search_pipeline.h:44-55)."""
+    __slots__ = ("term", "normalized", "grams", "gram_ids", "estimated_size", "df", "threshold")
+
+
+class SearchResult:
+    __slots__ = ("total", "docs", "scores", "total_candidates", "after_intersection", "after_not", "after_filters",
+                 "empty_term_detected", "term_order")
+
+    def __init__(self):
+        self.total = 0
+        self.docs = np.zeros(0, np.uint32)
+        self.scores = np.zeros(0, np.float64)
+        self.total_candidates = self.after_intersection = self.after_not = self.after_filters = 0
+        self.empty_term_detected = False
+        self.term_order = []
+
+
+def _take_u32(ptr, n):
+    out = np.ctypeslib.as_array(ptr, shape=(max(int(n), 1),))[: int(n)].copy() if n else np.zeros(0, np.uint32)
+    load().mgx_free(ptr)
+    return out.astype(np.uint32)
+
+
+class PreparedBatch:
+    """mgx_batch: a compiled, device-resident batch of queries that can be executed repeatedly."""
+
+    def __init__(self, index, cqueries, keep, shells, orders):
+        self.index, self._keep, self._shells, self._orders = index, keep, shells, orders
+        self.n = len(cqueries)
+        self._h = None
+        if self.n:
+            h = C.c_void_p()
+            arr = (_capi.Query * self.n)(*cqueries)
+            check(load().mgx_batch_prepare(index.device_index._h, arr, self.n, C.byref(h)))
+            self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgx_batch_destroy(self._h)
+            self._h = None
+
+    def execute(self, stream=None):
+        if self._h:
+            check(load().mgx_batch_execute(self._h, stream))
+
+    def fetch(self):
+        """-> list[SearchResult] in the order the queries were given (host-resolved queries included)."""
+        v = _capi.ResultView()
+        if self._h:
+            check(load().mgx_batch_fetch(self._h, C.byref(v)))
+        out = []
+        k = 0
+        for qi, shell in enumerate(self._shells):
+            if shell is not None:  # resolved on the host (empty / unknown term): never reached the device
+                out.append(shell)
+                continue
+            r = v.queries[k]
+            k += 1
+            s = SearchResult()
+            s.term_order = self._orders[qi]
+            s.total = int(r.total)
+            s.total_candidates, s.after_intersection = int(r.total_candidates), int(r.after_intersection)
+            s.after_not, s.after_filters = int(r.after_not), int(r.after_filters)
+            if r.n_docs:
+                s.docs = np.ctypeslib.as_array(v.docs, shape=(r.docs_begin + r.n_docs,))[r.docs_begin:].copy()
+                s.scores = np.ctypeslib.as_array(v.scores, shape=(r.docs_begin + r.n_docs,))[r.docs_begin:].copy()
+            out.append(s)
+        return out
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(), C.c_uint32()
+        check(load().mgx_batch_kernel_time_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def algorithmic_bytes(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(load().mgx_batch_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
+    def topk_stride(self):
+        s = C.c_uint32()
+        check(load().mgx_batch_export_topk(self._h, None, None, None, None, C.byref(s), None))
+        return int(s.value)
+
+    def export_topk(self, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream=None):
+        s = C.c_uint32()
+        check(load().mgx_batch_export_topk(self._h, keys_ptr, docs_ptr, counts_ptr, totals_ptr, C.byref(s), stream))
+        return int(s.value)
+
+    def merge_shards(self, n_shards, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream=None):
+        check(load().mgx_batch_merge_shards(self._h, n_shards, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream))
+
+
+class Index:
+    """Read side of mygramdb::index::Index (src/index/index.h:46-300) over one device shard.
+
+    `total_docs` / `avg_doc_length` are the table's BM25Stats (global over all shards when sharded)."""
+
+    def __init__(self, corpus=None, texts=None, first_doc_id=1, ngram_size=2, kanji_ngram_size=0, cross_boundary=True,
+                 device=0, dense_threshold=0.0, total_docs=None, avg_doc_length=None, global_posting_sizes=None,
+                 n_threads=0):
+        if corpus is None:
+            corpus = Corpus.from_texts(texts if texts is not None else [])
+        self.ngram_size = ngram_size
+        # the Index object keeps kanji = ngram when 0 (index.cpp:31); query n-grams use the table config value
+        self.kanji_ngram_size = kanji_ngram_size
+        self.cross_boundary = cross_boundary
+        self.columns = Columns(corpus, first_doc_id, ngram_size, kanji_ngram_size, cross_boundary, n_threads)
+        self.device_index = DeviceIndex(self.columns, device, dense_threshold)
+        self.total_docs = self.columns.bm25_doc_count if total_docs is None else total_docs
+        self.avg_doc_length = self.columns.avg_doc_length() if avg_doc_length is None else avg_doc_length
+        # df source: posting sizes of the WHOLE table (a shard passes the global sizes so idf is identical everywhere)
+        self._global_sizes = global_posting_sizes
+
+    # ---- dictionary -------------------------------------------------------------------------------------------
+    def posting_size(self, gram):
+        gid = self.columns.lookup(gram)
+        if gid is None:
+            return 0
+        if self._global_sizes is not None:
+            return int(self._global_sizes[gid])
+        return int(self.columns.offsets[gid + 1] - self.columns.offsets[gid])
+
+    estimate_posting_size = posting_size  # index.cpp:756-759
+
+    def _ids(self, terms):
+        """gram strings -> (ids of known grams, saw_unknown)."""
+        ids, unknown = [], False
+        for t in terms:
+            gid = self.columns.lookup(t)
+            if gid is None:
+                unknown = True
+            else:
+                ids.append(gid)
+        return ids, unknown
+
+    # ---- Index::Search* ---------------------------------------------------------------------------------------
+    def search_and(self, terms, limit=0, reverse=False):
+        """Index::SearchAnd, index.cpp:199-368."""
+        if len(terms) == 0:
+            return np.zeros(0, np.uint32)  # :203
+        ids, unknown = self._ids(terms)
+        if unknown:
+            return np.zeros(0, np.uint32)  # :211-215
+        a = np.asarray(ids, dtype=np.uint32)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_and(self.device_index._h, a.ctypes.data, len(a), limit, int(reverse), C.byref(p),
+                             C.byref(n)))
+        return _take_u32(p, n.value)
+
+    def search_or(self, terms):
+        """Index::SearchOr, index.cpp:418-448 (unknown terms skipped)."""
+        ids, _ = self._ids(terms)
+        if not ids:
+            return np.zeros(0, np.uint32)
+        a = np.asarray(sorted(set(ids)), dtype=np.uint32)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_or(self.device_index._h, a.ctypes.data, len(a), C.byref(p), C.byref(n)))
+        return _take_u32(p, n.value)
+
+    def search_not(self, all_docs, terms):
+        """Index::SearchNot, index.cpp:450-486."""
+        docs = np.ascontiguousarray(all_docs, dtype=np.uint32)
+        ids, _ = self._ids(terms)
+        if len(terms) == 0 or not ids:
+            return docs.copy()  # :451-453 / nothing to exclude
+        a = np.asarray(sorted(set(ids)), dtype=np.uint32)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_not(self.device_index._h, docs.ctypes.data, len(docs), a.ctypes.data, len(a), C.byref(p),
+                             C.byref(n)))
+        return _take_u32(p, n.value)
+
+    def search_by_threshold(self, terms, threshold):
+        """Index::SearchByThreshold, index.cpp:488-578."""
+        if len(terms) == 0 or threshold == 0:
+            return np.zeros(0, np.uint32)
+        uniq = sorted(set(t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in terms))  # :496-497
+        if threshold > len(uniq):
+            return np.zeros(0, np.uint32)
+        if threshold == len(uniq):
+            return self.search_and(uniq)  # :504-506
+        ids, _ = self._ids(uniq)  # missing grams do not count (:512-518)
+        if len(ids) < threshold:
+            return np.zeros(0, np.uint32)
+        a = np.asarray(ids, dtype=np.uint32)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_threshold(self.device_index._h, a.ctypes.data, len(a), threshold, C.byref(p), C.byref(n)))
+        return _take_u32(p, n.value)
+
+    def filter_by_ngrams(self, candidates, terms):
+        """Index::FilterByNgrams, index.cpp:370-416 (caller order and duplicates kept)."""
+        cand = np.ascontiguousarray(candidates, dtype=np.uint32)
+        if len(cand) == 0:
+            return np.zeros(0, np.uint32)
+        if len(terms) == 0:
+            return cand.copy()
+        ids, unknown = self._ids(terms)
+        if unknown:
+            return np.zeros(0, np.uint32)
+        a = np.asarray(ids, dtype=np.uint32)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_retain(self.device_index._h, cand.ctypes.data, len(cand), a.ctypes.data, len(a),
+                                C.byref(p), C.byref(n)))
+        return _take_u32(p, n.value)
+
+    # ---- BM25Scorer / ResultSorter ----------------------------------------------------------------------------
+    def score_documents(self, candidates, terms, dfs, total_docs, avg_doc_length, k1=1.2, b=0.75):
+        """BM25Scorer::ScoreDocuments (bm25_scorer.cpp:47-99) for terms that are exactly one n-gram long."""
+        if len(terms) != len(dfs):
+            raise _capi.MgxError(2, "BM25 search_terms and term_doc_freqs must have identical lengths")
+        cand = np.ascontiguousarray(candidates, dtype=np.uint32)
+        gids = []
+        for t in terms:
+            gid = self.columns.lookup(t)
+            gids.append(0xFFFFFFFF if gid is None else gid)
+        g = np.asarray(gids, dtype=np.uint32)
+        idfs = np.asarray([compute_idf(total_docs, d) for d in dfs], dtype=np.float64)
+        out = np.zeros(max(len(cand), 1), dtype=np.float64)
+        check(load().mgx_score_documents(self.device_index._h, cand.ctypes.data, len(cand), g.ctypes.data,
+                                         idfs.ctypes.data, len(g), float(avg_doc_length), float(k1), float(b),
+                                         out.ctypes.data))
+        return out[: len(cand)]
+
+    def sort_by_score(self, results, scores, descending=True, limit=0, offset=0):
+        """ResultSorter::SortByScore, result_sorter.cpp:661-716."""
+        r = np.ascontiguousarray(results, dtype=np.uint32)
+        s = np.ascontiguousarray(scores, dtype=np.float64)
+        p, n = C.POINTER(C.c_uint32)(), C.c_uint64()
+        check(load().mgx_sort_by_score(self.device_index._h, r.ctypes.data, s.ctypes.data, len(r), int(descending),
+                                       limit, offset, C.byref(p), C.byref(n)))
+        return _take_u32(p, n.value)
+
+    # ---- search_pipeline ---------------------------------------------------------------------------------------
+    def term_info(self, term, fuzzy=0):
+        """GenerateTermInfos for one term (search_pipeline.cpp:569-603); df from posting sizes (single-gram terms)."""
+        ti = TermInfo()
+        ti.term = term
+        ti.normalized = normalize_text(term)
+        grams = generate_query_ngrams(ti.normalized, self.ngram_size, self.kanji_ngram_size, self.cross_boundary)
+        ti.grams = sorted(set(g.encode("utf-8") for g in grams))  # DeduplicateSorted: bytewise
+        ti.gram_ids = []
+        size = None  # SIZE_MAX
+        for g in ti.grams:
+            ps = self.posting_size(g)
+            if ps > 0:
+                size = ps if size is None else min(size, ps)
+                ti.gram_ids.append(self.columns.lookup(g))
+            else:
+                size = 0
+                break
+        ti.estimated_size = size
+        ti.df = size if (len(ti.grams) == 1 and size) else None
+        ti.threshold = 0
+        if fuzzy and ti.grams:
+            # ExecuteWithFuzzy, search_pipeline.cpp:1697-1700
+            short = sum(1 for g in ti.grams if len(g) <= 3)
+            n_eff = (self.kanji_ngram_size or self.ngram_size) if short * 2 > len(ti.grams) else self.ngram_size
+            ti.threshold = max(1, len(ti.grams) - fuzzy * n_eff)
+        return ti
+
+    def prepare(self, queries):
+        """Compiles queries the way ExecuteFullPipeline's regular branch plans them (search_pipeline.cpp:2002-2030,
+        Execute :795-869) and uploads them as one batch."""
+        cqueries, keep, shells, orders = [], [], [], []
+        for q in queries:
+            tis = [self.term_info(t, q.fuzzy) for t in q.terms]
+            order = sorted(range(len(tis)), key=lambda i: (float("inf") if tis[i].estimated_size is None
+                                                           else tis[i].estimated_size))  # stable, :2012-2014
+            tis = [tis[i] for i in order]
+            shell = SearchResult()
+            shell.term_order = order
+            orders.append(order)
+            if any(t.estimated_size in (0, None) and (t.grams or not t.normalized) for t in tis):
+                shell.empty_term_detected = True  # Execute :804-810
+                shells.append(shell)
+                continue
+            if any(not t.grams for t in tis):
+                raise _capi.MgxError(4, "a term shorter than one n-gram needs the substring fallback "
+                                        "(SearchNormalizedSubstring), which is not on the device path")
+            cterms = (_capi.Term * len(tis))()
+            for j, t in enumerate(tis):
+                ids = np.asarray(t.gram_ids, dtype=np.uint32)
+                keep.append(ids)
+                thr = t.threshold if (q.fuzzy and t.threshold < len(ids)) else 0
+                idf = 0.0
+                if q.sort_score:
+                    if t.df is None:
+                        raise _capi.MgxError(4, "SORT _score on the device needs single-n-gram terms")
+                    idf = compute_idf(self.total_docs, t.df)
+                cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, idf)
+            nts = []
+            for nt in q.not_terms:
+                ti = self.term_info(nt)
+                if not ti.grams:
+                    raise _capi.MgxError(4, "NOT term shorter than one n-gram is not on the device path")
+                if ti.estimated_size == 0:
+                    continue  # an unknown gram: the NOT term matches nothing
+                nts.append(ti)
+            cnots = (_capi.Term * max(len(nts), 1))()
+            for j, t in enumerate(nts):
+                ids = np.asarray(t.gram_ids, dtype=np.uint32)
+                keep.append(ids)
+                cnots[j] = _capi.Term(ids.ctypes.data, len(ids), 0, 0.0)
+            cf = (_capi.Filter * max(len(q.filters), 1))()
+            for j, (bid, negate) in enumerate(q.filters):
+                cf[j] = _capi.Filter(bid, int(negate))
+            keep.extend([cterms, cnots, cf])
+            cq = _capi.Query(C.cast(cterms, C.c_void_p), len(tis), C.cast(cnots, C.c_void_p), len(nts),
+                             C.cast(cf, C.c_void_p), len(q.filters),
+                             _capi.SORT_SCORE if q.sort_score else _capi.SORT_DOCID, q.limit, q.offset,
+                             int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
+            cqueries.append(cq)
+            shells.append(None)
+        return PreparedBatch(self, cqueries, keep, shells, orders)
+
+    def search_batch(self, queries):
+        b = self.prepare(queries)
+        b.execute()
+        return b.fetch()

@@ -1,0 +1,85 @@
+"""Shared helpers of the -m gpu parity tests: build the same corpus on the device (through the C ABI) and in the
+oracle, and run one query through both."""
+import numpy as np
+
+import golden_util as G
+from oracle import oracle as O
+from pkg import mg
+
+
+def densify(docs):
+    """[(doc_id, text)] with arbitrary ids -> (first_doc_id, texts over the dense id range; gaps = empty text,
+    which produces no n-grams and no BM25 weight, i.e. the doc does not exist for the hot path)."""
+    ids = [d for d, _ in docs]
+    first, last = min(ids), max(ids)
+    texts = [""] * (last - first + 1)
+    for d, t in docs:
+        texts[d - first] = t if t is not None else ""
+    return first, texts
+
+
+class Pair:
+    """The same index on the device (mg.Index) and in the oracle."""
+
+    def __init__(self, docs=None, corpus=None, first_doc_id=1, ngram=2, kanji=0, cross=True, dense_threshold=0.0):
+        if corpus is None:
+            first_doc_id, texts = densify(docs)
+            corpus = mg.Corpus.from_texts(texts)
+        self.corpus = corpus
+        self.dev = mg.Index(corpus=corpus, first_doc_id=first_doc_id, ngram_size=ngram, kanji_ngram_size=kanji,
+                            cross_boundary=cross, dense_threshold=dense_threshold)
+        c = self.dev.columns
+        # the oracle adopts the CSR arrays; tests/test_host_cpu.py pins those arrays to the oracle's own text-level build
+        self.oidx = O.Index.from_csr(ngram, kanji, cross, c.key_bytes, c.key_off, c.offsets, c.docids)
+        if first_doc_id == 1:
+            self.ostore = O.DocumentStore.from_arrays(corpus.text_bytes, corpus.text_off)
+        else:
+            self.ostore = O.DocumentStore()
+            for i in range(corpus.n_docs):
+                t = corpus.text(i)
+                if t:
+                    self.ostore.add(first_doc_id + i, t)
+        self.N, self.total_len = c.bm25_doc_count, c.bm25_total_len
+        self.avgdl = c.avg_doc_length()
+        self.filters = {}  # bitmap id -> sorted docids
+
+    def add_filter(self, docids):
+        docids = np.asarray(sorted(docids), dtype=np.uint32)
+        bid = self.dev.device_index.add_filter_bitmap(docids)
+        self.filters[bid] = docids
+        return bid
+
+    def oracle_query(self, q):
+        """(total, page docids, page scores or None, funnel dict) the reference would produce."""
+        filters = [(self.filters[bid], neg) for bid, neg in q.filters]
+        r = O.execute(self.oidx, self.ostore, q.terms, q.not_terms, filters, compute_df=q.sort_score,
+                      ngram_size=self.dev.ngram_size, kanji_ngram_size=self.dev.kanji_ngram_size,
+                      cross_boundary=self.dev.cross_boundary)
+        res = r["results"]
+        if q.sort_score:
+            terms = [mg.engine.normalize_text(q.terms[i]) for i in r["term_order"]]
+            sc = O.score_documents(self.ostore, res, terms, r["term_df"], self.N, self.avgdl, q.k1, q.b)
+            page = O.sort_by_score(res, sc, q.descending, q.limit, q.offset)
+            lookup = dict(zip(res.tolist(), sc.tolist()))
+            return len(res), page, np.asarray([lookup[d] for d in page.tolist()]), r
+        page = res[::-1] if q.descending else res
+        if q.limit:
+            page = page[: q.limit]
+        return len(res), page, None, r
+
+    def check(self, queries):
+        got = self.dev.search_batch(queries)
+        for q, g in zip(queries, got):
+            total, page, scores, r = self.oracle_query(q)
+            ctx = (q.terms, q.not_terms, q.filters, q.limit, q.offset, q.descending)
+            assert g.total == total, ctx
+            assert g.docs.tolist() == page.tolist(), ctx
+            if scores is not None:
+                # fp64 arithmetic in the reference's operation order: bit-exact, far inside the 1e-5 relative bar
+                assert np.array_equal(g.scores, scores), (ctx, g.scores, scores)
+            if not r["empty_term_detected"]:
+                for k in ("total_candidates", "after_intersection", "after_not", "after_filters"):
+                    assert getattr(g, k) == r[k], (ctx, k)
+            else:
+                assert g.empty_term_detected
+        return got

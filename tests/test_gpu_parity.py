@@ -1,0 +1,188 @@
+"""-m gpu parity tests: the HIP path (through the C ABI of libmygram_gpu.so) against the CPU oracle and the
+reference's own known-answer vectors. Integer results are compared bit-exactly; BM25 scores bit-exactly too
+(the required bar is 1e-5 relative)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+from gpu_util import Pair, densify
+from oracle import oracle as O
+from pkg import mg
+
+pytestmark = pytest.mark.gpu
+Query = mg.engine.Query
+
+DENSE = [pytest.param(0.0, id="dense-bitmaps"), pytest.param(4.0, id="lists-only")]
+
+
+def _run_call(idx, call):
+    op = call["op"]
+    if op == "search_and":
+        return idx.search_and(call["terms"], call.get("limit", 0), call.get("reverse", False))
+    if op == "search_or":
+        return idx.search_or(call["terms"])
+    if op == "search_not":
+        return idx.search_not(G.expand_ids(call["all_docs"]), call["terms"])
+    if op == "search_by_threshold":
+        return idx.search_by_threshold(call["terms"], call["threshold"])
+    if op == "filter_by_ngrams":
+        return idx.filter_by_ngrams(G.expand_ids(call["candidates"]), call["terms"])
+    raise ValueError(op)
+
+
+@pytest.mark.parametrize("dense", DENSE)
+@pytest.mark.parametrize("case", G.index_cases(), ids=lambda c: c["id"])
+def test_reference_known_answers(case, dense):
+    """tests/index/{index_search,search_by_threshold,index_gettopn}_test.cpp vectors through Index::Search*."""
+    first, texts = densify(G.expand_docs(case["docs"]))
+    ic = case["index"]
+    idx = mg.Index(texts=texts, first_doc_id=first, ngram_size=ic["ngram"], kanji_ngram_size=ic.get("kanji", 0),
+                   dense_threshold=dense)
+    for call in case["calls"]:
+        got = _run_call(idx, call)
+        assert got.tolist() == G.expand_ids(call["expect"]), (case["source"], call)
+
+
+@pytest.fixture(scope="module", params=DENSE)
+def pair60k(request):
+    return Pair(corpus=mg.Corpus.synthetic(60_000, seed=42), dense_threshold=request.param)
+
+
+def _letter_grams(pair):
+    c = pair.dev.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    g = [i for i in range(c.n_grams) if b" " not in c.gram(i)]
+    return c, sizes, sorted(g, key=lambda i: -sizes[i])
+
+
+def test_set_algebra_random_vs_oracle(pair60k):
+    c, sizes, grams = _letter_grams(pair60k)
+    rng = np.random.default_rng(1)
+    pool = grams[:200]
+    all_docs = np.arange(1, c.n_docs + 1, dtype=np.uint32)
+    for it in range(30):
+        k = int(rng.integers(1, 6))
+        terms = [c.gram(int(g)).decode() for g in rng.choice(pool, size=k, replace=False)]
+        if it % 5 == 0:
+            terms.append("zq")  # maybe unknown / very rare
+        for limit, reverse in [(0, False), (7, False), (7, True), (0, True)]:
+            assert pair60k.dev.search_and(terms, limit, reverse).tolist() == \
+                pair60k.oidx.search_and(terms, limit, reverse).tolist(), (terms, limit, reverse)
+        assert pair60k.dev.search_or(terms).tolist() == pair60k.oidx.search_or(terms).tolist(), terms
+        sub = all_docs[:: int(rng.integers(1, 5))]
+        assert pair60k.dev.search_not(sub, terms).tolist() == pair60k.oidx.search_not(sub, terms).tolist(), terms
+        for th in range(0, len(terms) + 2):
+            assert pair60k.dev.search_by_threshold(terms + terms[:1], th).tolist() == \
+                pair60k.oidx.search_by_threshold(terms + terms[:1], th).tolist(), (terms, th)
+        cand = rng.integers(0, c.n_docs + 50, size=int(rng.integers(1, 1500))).astype(np.uint32)
+        assert pair60k.dev.filter_by_ngrams(cand, terms[:2]).tolist() == \
+            pair60k.oidx.filter_by_ngrams(cand, terms[:2]).tolist(), terms
+
+
+def test_scored_batch_bit_exact(pair60k):
+    c, sizes, grams = _letter_grams(pair60k)
+    rng = np.random.default_rng(2)
+    queries = []
+    for it in range(48):
+        k = int(rng.integers(1, 5))
+        pool = grams[:60] if it % 3 else grams[:400]
+        terms = [c.gram(int(g)).decode() for g in rng.choice(pool, size=k, replace=False)]
+        queries.append(Query(terms, sort_score=True, limit=int(rng.choice([1, 10, 37, 100])),
+                             offset=int(rng.choice([0, 0, 3, 50])), descending=bool(it % 4 != 3)))
+    queries.append(Query(["th", "zz"], sort_score=True, limit=10))       # unknown gram -> empty before the device
+    queries.append(Query(["TH", "He", "IN"], sort_score=True, limit=10))  # normalisation: ASCII lower
+    pair60k.check(queries)
+
+
+def test_not_terms_filters_and_funnel(pair60k):
+    c, sizes, grams = _letter_grams(pair60k)
+    rng = np.random.default_rng(3)
+    f_even = pair60k.add_filter(range(2, c.n_docs + 1, 2))
+    f_mod5 = pair60k.add_filter(range(5, c.n_docs + 1, 5))
+    f_none = pair60k.add_filter([])
+    queries = []
+    for it in range(40):
+        terms = [c.gram(int(g)).decode() for g in rng.choice(grams[:80], size=int(rng.integers(1, 4)), replace=False)]
+        nots = [c.gram(int(g)).decode() for g in rng.choice(grams[:300], size=int(rng.integers(0, 3)), replace=False)]
+        if it % 7 == 0:
+            nots.append("qj")  # unknown gram in a NOT term: dropped
+        if it % 6 == 0:
+            nots.append(terms[0] + "e")  # multi-gram NOT term
+        filters = [[], [(f_even, False)], [(f_mod5, True)], [(f_even, False), (f_mod5, False)], [(f_none, True)],
+                   [(f_none, False)]][it % 6]
+        queries.append(Query(terms, nots, filters, sort_score=bool(it % 2), limit=int(rng.choice([5, 20, 0]) or 5)
+                             if it % 2 else int(rng.choice([0, 5, 20])), descending=bool(it % 3)))
+    pair60k.check(queries)
+
+
+def test_multi_gram_terms_docid_order(pair60k):
+    # config-3 style: terms longer than one n-gram are the AND of their grams (verify_text off), no scoring
+    c = pair60k.dev.columns
+    words = sorted({w for i in range(300) for w in pair60k.corpus.text(i).decode().split(" ") if len(w) >= 3})
+    rng = np.random.default_rng(4)
+    queries = [Query([str(w) for w in rng.choice(words, size=int(rng.integers(1, 4)), replace=False)],
+                     limit=int(rng.choice([0, 10])), descending=bool(i % 2)) for i in range(30)]
+    pair60k.check(queries)
+
+
+def test_fuzzy_threshold_terms(pair60k):
+    # ExecuteWithFuzzy: per term "at least theta of its grams", AND across terms; checked against the oracle's
+    # SearchByThreshold composition
+    words = sorted({w for i in range(200) for w in pair60k.corpus.text(i).decode().split(" ") if len(w) >= 5})[:20]
+    for w in words:
+        q = Query([w], limit=0, descending=False, fuzzy=1)
+        got = pair60k.dev.search_batch([q])[0]
+        ti = pair60k.dev.term_info(w, 1)
+        want = pair60k.oidx.search_by_threshold(ti.grams, ti.threshold)
+        assert got.docs.tolist() == want.tolist(), w
+
+
+def test_bm25_golden_vectors_on_device():
+    bm = G.load("bm25.json")
+    for v in bm["score_properties"]:
+        first, texts = densify([(d, t) for d, t in v["docs"]])
+        idx = mg.Index(texts=texts, first_doc_id=first, ngram_size=5)  # "hello"/"alpha": one 5-gram per term
+        if v["assert"] == "raises":
+            with pytest.raises(mg._capi.MgxError):
+                idx.score_documents(v["candidates"], v["terms"], v["dfs"], v["N"], v["avgdl"], v["k1"], v["b"])
+            continue
+        score = idx.score_documents(v["candidates"], v["terms"], v["dfs"], v["N"], v["avgdl"], v["k1"], v["b"])
+        assert eval(v["assert"], {"score": score, "abs": abs, "idf": O.compute_idf}), (v["id"], score)
+    idx = mg.Index(texts=["x"], ngram_size=1)
+    for v in bm["sort_by_score"]:
+        got = idx.sort_by_score(v["results"], v["scores"], v["desc"], v["limit"], v["offset"])
+        assert got.tolist() == v["expect"], v
+
+
+def test_score_documents_unknown_and_textless_candidates():
+    # bm25_scorer_test.cpp:194-230: unknown candidates and docs without the term score 0.0 and are kept, in order
+    texts = ["alpha beta" if i % 3 == 0 else "gamma delta" for i in range(2051)]
+    idx = mg.Index(texts=texts, ngram_size=5)
+    cands = list(range(1, 2052)) + [9_000_000]
+    score = idx.score_documents(cands, ["alpha"], [684], 2051, 2.0)
+    assert len(score) == len(cands)
+    assert all(score[i] > 0.0 for i in range(0, 2051, 3))
+    assert score[1] == 0.0 and score[-1] == 0.0
+
+
+def test_ties_break_on_docid_both_directions():
+    # every doc identical => all scores tie; DESC keeps larger docids first, ASC smaller first (result_sorter.cpp:681-686)
+    p = Pair(docs=[(i, "abab cd") for i in range(1, 40_001)])
+    got = p.check([Query(["ab", "cd"], sort_score=True, limit=10, descending=True),
+                   Query(["ab", "cd"], sort_score=True, limit=10, descending=False),
+                   Query(["ab"], sort_score=True, limit=1000, offset=24, descending=True)])
+    assert got[0].docs.tolist() == list(range(40_000, 39_990, -1))
+    assert got[1].docs.tolist() == list(range(1, 11))
+
+
+def test_spans_many_tiles_and_workgroups():
+    # 600k docs = 37 tiles of 16384 = 2 workgroup items per query; first_doc_id far from 1
+    corpus = mg.Corpus.synthetic(600_000, seed=5)
+    p = Pair(corpus=corpus)
+    c, sizes, grams = _letter_grams(p)
+    rng = np.random.default_rng(6)
+    qs = [Query([c.gram(int(g)).decode() for g in rng.choice(grams[:40], size=3, replace=False)], sort_score=True,
+                limit=10) for _ in range(6)]
+    qs += [Query([c.gram(int(g)).decode() for g in rng.choice(grams[100:300], size=2, replace=False)],
+                 limit=25, descending=True) for _ in range(4)]
+    p.check(qs)
