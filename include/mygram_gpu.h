@@ -202,17 +202,17 @@ int mgx_batch_execute(mgx_batch* batch, void* hip_stream);
 /* Waits for the last execute and copies the (small) results to host memory owned by the batch. */
 int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);
 /* Multi-GPU exchange (one rank per doc-range shard; only for batches whose queries are all MGX_SORT_SCORE).
- * Copies the per-query top-(offset+limit) of the last execute into CALLER-owned DEVICE buffers on `hip_stream`:
- * keys_out[n_queries*stride] (order-preserving u64 of the fp64 score, best first), docs_out[n_queries*stride],
- * counts_out[n_queries], totals_out[n_queries] (match count of this shard). Call with keys_out == NULL to only
- * learn *stride. */
-int mgx_batch_export_topk(mgx_batch* batch, uint64_t* keys_out, uint32_t* docs_out, uint32_t* counts_out,
-                          uint64_t* totals_out, uint32_t* stride, void* hip_stream);
-/* Merges the exported lists of `n_shards` ranks, gathered as [shard][query][stride] / [shard][query] DEVICE arrays
- * (e.g. by one RCCL all-gather per array), into the final page and total of every query, on `hip_stream`; read the
- * result with mgx_batch_fetch. */
-int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* keys, const uint32_t* docs,
-                           const uint32_t* counts, const uint64_t* totals, void* hip_stream);
+ * Copies this shard's per-query top-(offset+limit) of the last execute into two CALLER-owned DEVICE blobs on
+ * `hip_stream`, laid out so that ONE all-gather per blob moves everything:
+ *   blob64[n_queries*stride + n_queries] : keys (order-preserving u64 of the fp64 score, best first, `stride` per
+ *                                           query), then this shard's match count per query;
+ *   blob32[n_queries*stride + n_queries] : doc ids parallel to the keys, then the number of valid entries per query.
+ * Call with both blobs NULL to only learn *stride. */
+int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride, void* hip_stream);
+/* Merges the blobs of `n_shards` ranks, gathered rank after rank (the layout an RCCL all-gather produces), into the
+ * final page and total of every query, on `hip_stream`; read the result with mgx_batch_fetch. */
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, const uint32_t* blob32,
+                           void* hip_stream);
 /* Algorithmic bytes of one execute (4*sum|L_i| + R*(T+4) + 12*min(k,R), summed over queries); R is
  * taken from the last fetched execute. */
 int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes, uint64_t* topk_bytes);

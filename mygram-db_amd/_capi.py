@@ -106,8 +106,8 @@ def load():
     L.mgx_batch_prepare.argtypes = [vp, C.POINTER(Query), u32, C.POINTER(vp)]
     L.mgx_batch_execute.argtypes = [vp, vp]
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
-    L.mgx_batch_export_topk.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u32), vp]
-    L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
+    L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, vp, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]
     L.mgx_batch_destroy.argtypes = [vp]

@@ -696,8 +696,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     }
     const uint32_t n = static_cast<uint32_t>(g.qids.size());
     MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, idx->dev.n_items, g.dev.cand_keys,
-                               g.dev.cand_docs, g.dev.cand_n, g.dev.cand_stride, /*q_mul=*/idx->dev.n_items,
-                               /*j_mul=*/1, b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
+                               g.dev.cand_docs, g.dev.cand_n,
+                               /*kq=*/static_cast<uint64_t>(idx->dev.n_items) * g.dev.cand_stride,
+                               /*kj=*/g.dev.cand_stride, /*cq=*/idx->dev.n_items, /*cj=*/1,
+                               b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
                                b->d_top_n.as<uint32_t>(), b->top_stride, b->d_page_docs.as<uint32_t>(),
                                b->d_page_scores.as<double>(), b->d_page_n.as<uint32_t>(), b->page_stride, s));
   }
@@ -866,40 +868,45 @@ int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out) {
   }
 }
 
-int mgx_batch_export_topk(mgx_batch* batch, uint64_t* keys_out, uint32_t* docs_out, uint32_t* counts_out,
-                          uint64_t* totals_out, uint32_t* stride, void* hip_stream) {
+int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride,
+                          void* hip_stream) {
   if (!batch || !stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null argument");
   if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: every query must be MGX_SORT_SCORE");
   *stride = batch->top_stride;
-  if (!keys_out) return MGX_OK;  // size query
+  if (!blob64 && !blob32) return MGX_OK;  // size query
+  if (!blob64 || !blob32) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null blob");
   if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: not executed");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const size_t n = batch->score.qids.size();
+  const size_t ks = n * batch->top_stride;
   MGX_HIP(hipSetDevice(batch->idx->device));
-  MGX_HIP(hipMemcpyAsync(keys_out, batch->d_top_keys.p, n * batch->top_stride * 8, hipMemcpyDeviceToDevice, s));
-  MGX_HIP(hipMemcpyAsync(docs_out, batch->d_top_docs.p, n * batch->top_stride * 4, hipMemcpyDeviceToDevice, s));
-  MGX_HIP(hipMemcpyAsync(counts_out, batch->d_top_n.p, n * 4, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(blob64, batch->d_top_keys.p, ks * 8, hipMemcpyDeviceToDevice, s));
   // totals: counter slot 4 of every query
-  MGX_HIP(hipMemcpy2DAsync(totals_out, 8, static_cast<char*>(batch->score.d_counters.p) + 4 * 8, 64, 8, n,
+  MGX_HIP(hipMemcpy2DAsync(blob64 + ks, 8, static_cast<char*>(batch->score.d_counters.p) + 4 * 8, 64, 8, n,
                            hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(blob32, batch->d_top_docs.p, ks * 4, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(blob32 + ks, batch->d_top_n.p, n * 4, hipMemcpyDeviceToDevice, s));
   return MGX_OK;
 }
 
-int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* keys, const uint32_t* docs,
-                           const uint32_t* counts, const uint64_t* totals, void* hip_stream) {
-  if (!batch || !keys || !docs || !counts || !totals || n_shards == 0)
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, const uint32_t* blob32,
+                           void* hip_stream) {
+  if (!batch || !blob64 || !blob32 || n_shards == 0)
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: null argument");
   if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: every query must be MGX_SORT_SCORE");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
+  const uint64_t pitch = static_cast<uint64_t>(n) * batch->top_stride + n;  // elements per rank blob
   MGX_HIP(hipSetDevice(batch->idx->device));
-  MGX_LAUNCH(mgx::LaunchMergeTopK(batch->score.dev.queries, batch->score.d_ident.as<uint32_t>(), n, n_shards, keys,
-                                  docs, counts, batch->top_stride, /*q_mul=*/1, /*j_mul=*/n, nullptr, nullptr, nullptr,
-                                  0, batch->d_page_docs.as<uint32_t>(), batch->d_page_scores.as<double>(),
+  MGX_LAUNCH(mgx::LaunchMergeTopK(batch->score.dev.queries, batch->score.d_ident.as<uint32_t>(), n, n_shards, blob64,
+                                  blob32, blob32 + static_cast<uint64_t>(n) * batch->top_stride,
+                                  /*kq=*/batch->top_stride, /*kj=*/pitch, /*cq=*/1, /*cj=*/pitch, nullptr, nullptr,
+                                  nullptr, 0, batch->d_page_docs.as<uint32_t>(), batch->d_page_scores.as<double>(),
                                   batch->d_page_n.as<uint32_t>(), batch->page_stride, s));
-  MGX_LAUNCH(mgx::LaunchSumTotals(totals, n_shards, n, batch->d_total_override.as<uint64_t>(), s));
+  MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch,
+                                  batch->d_total_override.as<uint64_t>(), s));
   batch->merged_shards = true;
   batch->last_stream = s;
   return MGX_OK;

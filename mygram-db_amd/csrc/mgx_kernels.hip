@@ -567,15 +567,16 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 // merge of sorted candidate lists (per-workgroup lists of one shard, or per-shard lists of one query)
 // ---------------------------------------------------------------------------------------------------------------
 
-// lists: n_lists lists per query; list j of query slot qq is list L = qq*q_mul + j*j_mul: keys[L*stride ...],
-// cnt[L] valid entries, each sorted best-first (per-workgroup lists: q_mul = n_lists, j_mul = 1; per-shard lists
-// gathered as [shard][query]: q_mul = 1, j_mul = n_queries). Writes the merged best `needed` (best first) to top_keys/top_docs[qq*top_stride..]
+// lists: n_lists sorted (best-first) lists per query; list j of query slot qq starts at keys[qq*kq + j*kj] (same for
+// docs) and holds cnt[qq*cq + j*cj] valid entries. Per-workgroup lists of one shard: kq = n_lists*stride, kj = stride,
+// cq = n_lists, cj = 1. Per-shard lists gathered rank by rank: kq = stride, kj = elements per rank blob, cq = 1,
+// cj = elements per rank blob. Writes the merged best `needed` (best first) to top_keys/top_docs[qq*top_stride..]
 // and the page [offset, offset+limit) to page_docs/page_scores[qq*page_stride ..].
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __restrict__ queries, uint32_t n_lists,
                                                             const uint64_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ docs,
-                                                            const uint32_t* __restrict__ cnt, uint32_t stride,
-                                                            uint32_t q_mul, uint32_t j_mul,
+                                                            const uint32_t* __restrict__ cnt, uint64_t kq,
+                                                            uint64_t kj, uint64_t cq, uint64_t cj,
                                                             uint64_t* __restrict__ top_keys,
                                                             uint32_t* __restrict__ top_docs,
                                                             uint32_t* __restrict__ top_n, uint32_t top_stride,
@@ -585,13 +586,13 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
                                                             const uint32_t* __restrict__ query_ids) {
   const uint32_t slot = blockIdx.x;
   const DevQuery q = queries[query_ids[slot]];
-  const uint64_t lbase = static_cast<uint64_t>(slot) * q_mul;
-#define MGX_L(j) (lbase + static_cast<uint64_t>(j) * j_mul)
+#define MGX_K(j) (static_cast<uint64_t>(slot) * kq + static_cast<uint64_t>(j) * kj)
+#define MGX_C(j) (static_cast<uint64_t>(slot) * cq + static_cast<uint64_t>(j) * cj)
   __shared__ uint32_t s_total;
   if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
   uint32_t local_total = 0;
-  for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) local_total += min(cnt[MGX_L(j)], q.needed);
+  for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) local_total += min(cnt[MGX_C(j)], q.needed);
   if (local_total) atomicAdd(&s_total, local_total);
   __syncthreads();
   const uint32_t total = s_total;
@@ -602,15 +603,15 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   const uint64_t total_slots = static_cast<uint64_t>(n_lists) * q.needed;
   for (uint64_t e = threadIdx.x; e < total_slots; e += kBlock) {
     const uint32_t j = static_cast<uint32_t>(e / q.needed), i = static_cast<uint32_t>(e % q.needed);
-    if (i >= cnt[MGX_L(j)]) continue;
-    const uint64_t k = keys[MGX_L(j) * stride + i];
-    const uint32_t d = docs[MGX_L(j) * stride + i];
+    if (i >= cnt[MGX_C(j)]) continue;
+    const uint64_t k = keys[MGX_K(j) + i];
+    const uint32_t d = docs[MGX_K(j) + i];
     uint32_t rank = i;
     for (uint32_t j2 = 0; j2 < n_lists && rank < q.needed; ++j2) {
       if (j2 == j) continue;
-      const uint64_t* kk = keys + MGX_L(j2) * stride;
-      const uint32_t* dd = docs + MGX_L(j2) * stride;
-      uint32_t lo = 0, hi = min(cnt[MGX_L(j2)], q.needed);
+      const uint64_t* kk = keys + MGX_K(j2);
+      const uint32_t* dd = docs + MGX_K(j2);
+      uint32_t lo = 0, hi = min(cnt[MGX_C(j2)], q.needed);
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
         if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
@@ -632,16 +633,17 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
     if (top_n) top_n[slot] = merged;
     if (page_n) page_n[slot] = page_hi - page_lo;
   }
-#undef MGX_L
+#undef MGX_K
+#undef MGX_C
 }
 
-// out[q] = sum over shards of totals[shard][q]
+// out[q] = sum over shards of totals[shard*pitch + q]
 __global__ void sum_totals_kernel(const uint64_t* __restrict__ totals, uint32_t n_shards, uint32_t n_queries,
-                                  uint64_t* __restrict__ out) {
+                                  uint64_t pitch, uint64_t* __restrict__ out) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n_queries) return;
   uint64_t s = 0;
-  for (uint32_t r = 0; r < n_shards; ++r) s += totals[static_cast<uint64_t>(r) * n_queries + q];
+  for (uint32_t r = 0; r < n_shards; ++r) s += totals[static_cast<uint64_t>(r) * pitch + q];
   out[q] = s;
 }
 
@@ -864,21 +866,23 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
 }
 
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
-                    const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint32_t stride, uint32_t q_mul,
-                    uint32_t j_mul, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n, uint32_t top_stride,
-                    uint32_t* page_docs, double* page_scores, uint32_t* page_n, uint32_t page_stride, hipStream_t s) {
+                    const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
+                    uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
+                    uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
+                    uint32_t page_stride, hipStream_t s) {
   if (n_slots == 0) return 0;
-  hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, stride,
-                     q_mul, j_mul, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
+  hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, kq, kj,
+                     cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
                      query_ids);
   MGX_KCHECK();
   return 0;
 }
 
-int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t* out, hipStream_t s) {
+int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t pitch, uint64_t* out,
+                    hipStream_t s) {
   if (n_queries == 0) return 0;
   hipLaunchKernelGGL(sum_totals_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, s, totals, n_shards, n_queries,
-                     out);
+                     pitch, out);
   MGX_KCHECK();
   return 0;
 }

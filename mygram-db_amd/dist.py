@@ -1,0 +1,112 @@
+"""Doc-range sharding of one table across ranks (one process per GPU) and the per-batch top-k exchange.
+
+Every rank owns a contiguous doc-id range as a complete small index: postings never cross shards, so
+set algebra needs no communication. What must be global is what BM25 reads: N, avgdl and each gram's document
+frequency (so idf — and therefore every score — is identical on all ranks); they are summed once at load time. Per
+batch the ranks exchange only their per-query top-(offset+limit): two all-gathers (one 64-bit blob, one 32-bit blob,
+see mgx_batch_export_topk) followed by a device-side merge with the ResultSorter::SortByScore comparator. RCCL has no
+custom reduction operator, so the north star's "all-reduce of top-k" is realised as all-gather + local merge.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+
+def shard_range(n_docs_total, rank, world):
+    """Contiguous doc range of `rank`: (number of docs before it, its doc count). Doc ids are 1-based."""
+    per = (n_docs_total + world - 1) // world
+    first = min(rank * per, n_docs_total)
+    return first, min(per, n_docs_total - first)
+
+
+def _device_for_backend():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def allreduce_sum_i64(values):
+    """Sum of an int64 vector over all ranks (identity when not distributed)."""
+    a = np.ascontiguousarray(values, dtype=np.int64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return a
+    t = torch.from_numpy(a.copy()).to(_device_for_backend())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def global_table_stats(local_keys, local_sizes, local_doc_count, local_total_len):
+    """-> (global posting size per LOCAL gram id, global BM25 doc_count, global total_len).
+
+    Shards may hold different gram dictionaries; sizes are aligned by gram bytes."""
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return np.asarray(local_sizes, dtype=np.int64), int(local_doc_count), int(local_total_len)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, list(local_keys))
+    union = sorted(set(k for ks in gathered for k in ks))
+    pos = {k: i for i, k in enumerate(union)}
+    vec = np.zeros(len(union) + 2, dtype=np.int64)
+    for k, s in zip(local_keys, local_sizes):
+        vec[pos[k]] = s
+    vec[-2], vec[-1] = local_doc_count, local_total_len
+    tot = allreduce_sum_i64(vec)
+    sizes = np.asarray([tot[pos[k]] for k in local_keys], dtype=np.int64)
+    return sizes, int(tot[-2]), int(tot[-1])
+
+
+class ShardedTable:
+    """One rank's shard of a table plus the global statistics every rank agrees on."""
+
+    def __init__(self, corpus, first_doc_id, device=0, ngram_size=2, kanji_ngram_size=0, cross_boundary=True,
+                 dense_threshold=0.0, n_threads=0):
+        self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.index = engine.Index(corpus=corpus, first_doc_id=first_doc_id, ngram_size=ngram_size,
+                                  kanji_ngram_size=kanji_ngram_size, cross_boundary=cross_boundary, device=device,
+                                  dense_threshold=dense_threshold, n_threads=n_threads)
+        c = self.index.columns
+        keys = [c.gram(g) for g in range(c.n_grams)]
+        sizes = np.diff(c.offsets.astype(np.int64))
+        gsizes, n, total_len = global_table_stats(keys, sizes, c.bm25_doc_count, c.bm25_total_len)
+        self.index._global_sizes = gsizes
+        self.index.total_docs = n
+        self.index.avg_doc_length = (total_len / n) if n else 0.0
+        self.keys, self.global_sizes = keys, gsizes
+        self._blobs = {}
+
+    def prepare(self, queries):
+        return self.index.prepare(queries)
+
+    def _buffers(self, batch):
+        key = id(batch)
+        if key not in self._blobs:
+            stride = batch.topk_stride()
+            n = batch.n * stride + batch.n
+            dev = torch.device("cuda", self.index.device_index.device)
+            self._blobs[key] = (torch.empty(n, dtype=torch.int64, device=dev),
+                                torch.empty(n, dtype=torch.int32, device=dev),
+                                torch.empty(n * self.world, dtype=torch.int64, device=dev),
+                                torch.empty(n * self.world, dtype=torch.int32, device=dev))
+        return self._blobs[key]
+
+    def run(self, batch):
+        """Executes `batch` on this shard, exchanges per-shard top-k and merges: afterwards batch.fetch*() returns
+        the table-wide page and total on every rank."""
+        stream = torch.cuda.current_stream().cuda_stream
+        batch.execute(stream)
+        if self.world == 1:
+            return
+        b64, b32, g64, g32 = self._buffers(batch)
+        batch.export_topk(b64.data_ptr(), b32.data_ptr(), stream)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(g64, b64)
+            dist.all_gather_into_tensor(g32, b32)
+        else:  # gloo: stage through host memory (CPU rehearsal of the exchange; RCCL is the production path)
+            h64 = [torch.empty(b64.numel(), dtype=torch.int64) for _ in range(self.world)]
+            h32 = [torch.empty(b32.numel(), dtype=torch.int32) for _ in range(self.world)]
+            dist.all_gather(h64, b64.cpu())
+            dist.all_gather(h32, b32.cpu())
+            g64.copy_(torch.cat(h64))
+            g32.copy_(torch.cat(h32))
+        batch.merge_shards(self.world, g64.data_ptr(), g32.data_ptr(), stream)

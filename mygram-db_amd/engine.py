@@ -295,18 +295,24 @@ class PreparedBatch:
         check(load().mgx_batch_algorithmic_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def fetch_raw(self):
+        """mgx_batch_fetch without building Python objects (the timed path of bench.py)."""
+        v = _capi.ResultView()
+        check(load().mgx_batch_fetch(self._h, C.byref(v)))
+        return v
+
     def topk_stride(self):
         s = C.c_uint32()
-        check(load().mgx_batch_export_topk(self._h, None, None, None, None, C.byref(s), None))
+        check(load().mgx_batch_export_topk(self._h, None, None, C.byref(s), None))
         return int(s.value)
 
-    def export_topk(self, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream=None):
+    def export_topk(self, blob64_ptr, blob32_ptr, stream=None):
         s = C.c_uint32()
-        check(load().mgx_batch_export_topk(self._h, keys_ptr, docs_ptr, counts_ptr, totals_ptr, C.byref(s), stream))
+        check(load().mgx_batch_export_topk(self._h, blob64_ptr, blob32_ptr, C.byref(s), stream))
         return int(s.value)
 
-    def merge_shards(self, n_shards, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream=None):
-        check(load().mgx_batch_merge_shards(self._h, n_shards, keys_ptr, docs_ptr, counts_ptr, totals_ptr, stream))
+    def merge_shards(self, n_shards, blob64_ptr, blob32_ptr, stream=None):
+        check(load().mgx_batch_merge_shards(self._h, n_shards, blob64_ptr, blob32_ptr, stream))
 
 
 class Index:
