@@ -199,9 +199,11 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
 
   MGX_HIP(mgx::Upload(idx->d_offsets, d->offsets, G + 1));
   MGX_HIP(mgx::Upload(idx->d_docids, d->docids, P, 4));
+  uint32_t max_doc_len = 0;
   if (idx->can_score) {
     MGX_HIP(mgx::Upload(idx->d_tf, d->tf, P, 4));
     MGX_HIP(mgx::Upload(idx->d_doc_len, d->doc_len, n_docs));
+    for (uint64_t i = 0; i < n_docs; ++i) max_doc_len = std::max(max_doc_len, d->doc_len[i]);
   }
 
   // which grams get a skip row / a dense bitmap
@@ -260,7 +262,7 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.first_doc_id = d->first_doc_id;
   v.n_docs = static_cast<uint32_t>(n_docs);
   v.n_tiles = n_tiles;
-  v.n_items = (n_tiles + mgx::kTilesPerItem - 1) / mgx::kTilesPerItem;
+  v.max_doc_len = max_doc_len;
   *out = idx.release();
   return MGX_OK;
 }
@@ -365,6 +367,8 @@ struct QuerySpec {
   uint32_t stack_depth = 0;
   double k1 = 1.2, b = 0.75, avgdl = 0.0;
   uint64_t list_postings = 0;  // sum of |L| over gram operands (algorithmic bytes = 4x)
+  bool wave_ok = true;         // flat program + every scored term in its own register slot
+  double est_density = 0.0;    // estimated fraction of docs that match (work per tile grows with it)
 };
 
 struct Compiler {
@@ -377,7 +381,9 @@ struct Compiler {
     auto it = gram_leaf.find(g);
     if (it != gram_leaf.end()) return it->second;
     DevLeaf lf{};
+    lf.score_slot = kNoSlot;
     lf.a = g;
+    lf.row = idx->h_skip_row[g];
     if (idx->h_bm_row[g] != kNoRow) {
       lf.kind = kLeafGramBitmap;
       lf.b = idx->h_bm_row[g];
@@ -391,7 +397,15 @@ struct Compiler {
     return id;
   }
   void Emit(Op op, uint32_t arg = 0) {
+    if (op == kOpCount) {
+      arg = 1u << arg;  // slot -> mask; consecutive counts of the same accumulator share one instruction
+      if (!q->prog.empty() && (q->prog.back() >> 24) == kOpCount) {
+        q->prog.back() |= arg;
+        return;
+      }
+    }
     q->prog.push_back(MakeInstr(op, arg));
+    if (op != kOpLoad && op != kOpAnd && op != kOpOr && op != kOpAndNot && op != kOpCount) q->wave_ok = false;
     if (op == kOpPush) {
       ++sp;
       q->stack_depth = std::max(q->stack_depth, sp);
@@ -436,6 +450,18 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     int rc = ValidateTerm(idx, in.not_terms[i], "NOT term");
     if (rc) return rc;
   }
+  {
+    double dens = 1.0;
+    for (uint32_t i = 0; i < in.n_terms; ++i) {
+      uint64_t mn = ~0ull;
+      for (uint32_t g = 0; g < in.terms[i].n_grams; ++g) {
+        const uint32_t id = in.terms[i].gram_ids[g];
+        mn = std::min<uint64_t>(mn, idx->h_offsets[id + 1] - idx->h_offsets[id]);
+      }
+      dens *= static_cast<double>(mn) / static_cast<double>(idx->dev.n_docs);
+    }
+    out->est_density = dens;
+  }
   c.LoadTerm(in.terms[0]);
   c.Emit(kOpCount, 0);
   for (uint32_t i = 1; i < in.n_terms; ++i) {
@@ -463,6 +489,8 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   for (uint32_t i = 0; i < in.n_filters; ++i) {
     if (in.filters[i].bitmap_id >= idx->n_filter_rows) return Fail(MGX_ERR_OUT_OF_RANGE, "unknown filter bitmap id");
     DevLeaf lf{};
+    lf.score_slot = kNoSlot;
+    lf.row = kNoRow;
     lf.kind = kLeafFilterBitmap;
     lf.b = in.filters[i].bitmap_id;
     const uint32_t id = static_cast<uint32_t>(out->leaves.size());
@@ -494,6 +522,11 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       DevScoreTerm st{};
       st.leaf = c.GramLeaf(t.gram_ids[0]);
       st.idf = t.idf;
+      // the same gram scored twice (a repeated term) keeps the first slot; the block kernel handles that shape
+      if (out->leaves[st.leaf].score_slot == kNoSlot && i < static_cast<uint32_t>(kWaveScoreSlots))
+        out->leaves[st.leaf].score_slot = i;
+      else
+        out->wave_ok = false;
       out->score.push_back(st);
     }
   } else if (in.sort == MGX_SORT_DOCID) {
@@ -521,7 +554,10 @@ struct mgx_batch {
     std::vector<uint32_t> qids;  // batch index of each member
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
-    DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident;
+    mgx::WavePlan wplan{};
+    bool use_wave = false;
+    DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident, d_items, d_list_begin;
+    uint32_t n_items = 0;
     std::vector<unsigned long long> h_counters;
   };
   Group score, bitmap;
@@ -597,18 +633,61 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     b->list_bytes += 4 * s.list_postings;
   }
   g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode);
-  if (g.plan.bytes > 160 * 1024) return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
+  if (score_mode) {
+    bool wave_ok = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr, has_list = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      const QuerySpec& s = b->specs[g.qids[i]];
+      wave_ok = wave_ok && s.wave_ok;
+      for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;
+    }
+    g.wplan = PlanWave(max_leaves, max_score, max_instr, max_cap, b->idx->dev.max_doc_len, has_list);
+    g.use_wave = wave_ok && g.wplan.bytes <= 160 * 1024;
+  }
+  if (!g.use_wave && g.plan.bytes > 160 * 1024)
+    return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
   MGX_HIP(Upload(g.d_queries, dq.data(), dq.size()));
   MGX_HIP(Upload(g.d_leaves, leaves.data(), leaves.size()));
   MGX_HIP(Upload(g.d_prog, prog.data(), prog.size()));
   MGX_HIP(Upload(g.d_score, score.data(), score.size()));
   MGX_HIP(Upload(g.d_explicit, expl.data(), expl.size(), 4));
-  MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 8 * sizeof(unsigned long long)));
+  // [n][8] counters followed by [n] pruning bounds: one memset clears both before every execute
+  MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 9 * sizeof(unsigned long long)));
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
   MGX_HIP(Upload(g.d_ident, ident.data(), n));
+  // ---- work items: cut every query into runs of tiles of about equal estimated cost ------------------------------
+  // cost of one tile ~ 1 (operand fetch, program) + matches/128 (enumeration + scoring); a workgroup gets ~48 units.
+  std::vector<DevItem> items;
+  std::vector<uint32_t> list_begin(n + 1, 0);
+  {
+    const uint32_t n_tiles = b->idx->dev.n_tiles;
+    for (uint32_t i = 0; i < n; ++i) {
+      const QuerySpec& s = b->specs[g.qids[i]];
+      static const double kMatchesPerUnit = std::getenv("MGX_ITEM_MATCHES") ? atof(std::getenv("MGX_ITEM_MATCHES")) : 256.0;
+      static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 96.0;
+      const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
+      uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
+      tiles = std::max<uint32_t>(4, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~3u;  // whole rounds of 4 waves
+      list_begin[i] = static_cast<uint32_t>(items.size());
+      for (uint32_t t = 0; t < n_tiles; t += tiles) {
+        DevItem it{i, t, std::min(tiles, n_tiles - t), 0};
+        items.push_back(it);
+      }
+    }
+    list_begin[n] = static_cast<uint32_t>(items.size());
+    for (uint32_t k = 0; k < items.size(); ++k) items[k].list = k;  // candidate lists stay grouped by query
+    // launch order: by doc range (coarsely), then by query, so concurrent workgroups share operand tiles in L2
+    std::stable_sort(items.begin(), items.end(), [](const DevItem& a, const DevItem& c) {
+      return a.tile_begin / kMaxTilesPerItem < c.tile_begin / kMaxTilesPerItem;
+    });
+  }
+  g.n_items = static_cast<uint32_t>(items.size());
+  MGX_HIP(Upload(g.d_items, items.data(), items.size()));
+  MGX_HIP(Upload(g.d_list_begin, list_begin.data(), list_begin.size()));
   g.h_counters.assign(static_cast<size_t>(n) * 8, 0);
   DevBatch& d = g.dev;
+  d.items = g.d_items.as<DevItem>();
+  d.n_items = g.n_items;
   d.queries = g.d_queries.as<DevQuery>();
   d.leaves = g.d_leaves.as<DevLeaf>();
   d.prog = g.d_prog.as<uint32_t>();
@@ -616,19 +695,21 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   d.explicit_pool = g.d_explicit.as<uint32_t>();
   d.n_queries = n;
   d.counters = g.d_counters.as<unsigned long long>();
+  d.bounds = score_mode ? d.counters + static_cast<size_t>(n) * 8 : nullptr;
+  d.debug_skip = std::getenv("MGX_DEBUG_SKIP") ? static_cast<uint32_t>(atoi(std::getenv("MGX_DEBUG_SKIP"))) : 0u;
   if (score_mode) {
     uint32_t max_needed = 1, max_limit = 1;
     for (const DevQuery& q : dq) {
       max_needed = std::max(max_needed, q.needed);
       max_limit = std::max(max_limit, q.limit);
     }
-    const size_t items = b->idx->dev.n_items;
+    const size_t n_lists_total = g.n_items;
     d.cand_stride = max_needed;
     b->top_stride = max_needed;
     b->page_stride = max_limit;
-    MGX_HIP(b->d_cand_keys.Alloc(static_cast<size_t>(n) * items * max_needed * 8));
-    MGX_HIP(b->d_cand_docs.Alloc(static_cast<size_t>(n) * items * max_needed * 4));
-    MGX_HIP(b->d_cand_n.Alloc(static_cast<size_t>(n) * items * 4));
+    MGX_HIP(b->d_cand_keys.Alloc(n_lists_total * max_needed * 8));
+    MGX_HIP(b->d_cand_docs.Alloc(n_lists_total * max_needed * 4));
+    MGX_HIP(b->d_cand_n.Alloc(n_lists_total * 4));
     MGX_HIP(b->d_top_keys.Alloc(static_cast<size_t>(n) * max_needed * 8));
     MGX_HIP(b->d_top_docs.Alloc(static_cast<size_t>(n) * max_needed * 4));
     MGX_HIP(b->d_top_n.Alloc(static_cast<size_t>(n) * 4));
@@ -689,19 +770,22 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
+    if (g.use_wave) {
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev, g.wplan, s));
+    } else {
+      MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
+    }
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev1, s));
       timed = true;
     }
     const uint32_t n = static_cast<uint32_t>(g.qids.size());
-    MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, idx->dev.n_items, g.dev.cand_keys,
-                               g.dev.cand_docs, g.dev.cand_n,
-                               /*kq=*/static_cast<uint64_t>(idx->dev.n_items) * g.dev.cand_stride,
-                               /*kj=*/g.dev.cand_stride, /*cq=*/idx->dev.n_items, /*cj=*/1,
+    MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, 0, g.dev.cand_keys, g.dev.cand_docs,
+                               g.dev.cand_n, /*kq=*/0, /*kj=*/g.dev.cand_stride, /*cq=*/0, /*cj=*/1,
                                b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
                                b->d_top_n.as<uint32_t>(), b->top_stride, b->d_page_docs.as<uint32_t>(),
-                               b->d_page_scores.as<double>(), b->d_page_n.as<uint32_t>(), b->page_stride, s));
+                               b->d_page_scores.as<double>(), b->d_page_n.as<uint32_t>(), b->page_stride,
+                               g.d_list_begin.as<uint32_t>(), s));
   }
   if (!b->bitmap.qids.empty()) {
     mgx_batch::Group& g = b->bitmap;
@@ -747,7 +831,7 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     page_n.resize(n);
     page_docs.resize(n * b->page_stride);
     page_scores.resize(n * b->page_stride);
-    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, g.d_counters.bytes, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     MGX_HIP(hipMemcpy(page_n.data(), b->d_page_n.p, n * 4, hipMemcpyDeviceToHost));
     MGX_HIP(hipMemcpy(page_docs.data(), b->d_page_docs.p, page_docs.size() * 4, hipMemcpyDeviceToHost));
     MGX_HIP(hipMemcpy(page_scores.data(), b->d_page_scores.p, page_scores.size() * 8, hipMemcpyDeviceToHost));
@@ -765,7 +849,7 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     totals.resize(n);
     take.resize(n);
     out_off.resize(n);
-    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, g.d_counters.bytes, hipMemcpyDeviceToHost));
+    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     MGX_HIP(hipMemcpy(totals.data(), b->d_totals.p, n * 8, hipMemcpyDeviceToHost));
     uint64_t at = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -904,7 +988,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                                   blob32, blob32 + static_cast<uint64_t>(n) * batch->top_stride,
                                   /*kq=*/batch->top_stride, /*kj=*/pitch, /*cq=*/1, /*cj=*/pitch, nullptr, nullptr,
                                   nullptr, 0, batch->d_page_docs.as<uint32_t>(), batch->d_page_scores.as<double>(),
-                                  batch->d_page_n.as<uint32_t>(), batch->page_stride, s));
+                                  batch->d_page_n.as<uint32_t>(), batch->page_stride, nullptr, s));
   MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch,
                                   batch->d_total_override.as<uint64_t>(), s));
   batch->merged_shards = true;
@@ -1063,6 +1147,8 @@ int mgx_not(mgx_index* idx, const uint32_t* all_docs, uint64_t n_all, const uint
       else q.explicit_ids.push_back(all_docs[i]);
     }
     mgx::DevLeaf lf{};
+    lf.score_slot = mgx::kNoSlot;
+    lf.row = mgx::kNoRow;
     lf.kind = mgx::kLeafExplicit;
     lf.a = 0;
     lf.b = static_cast<uint32_t>(q.explicit_ids.size());

@@ -18,7 +18,7 @@ constexpr int kBlock = 256;                       // threads per workgroup (4 wa
 constexpr int kTileShift = 14;                    // 16384 doc slots per tile
 constexpr uint32_t kTileDocs = 1u << kTileShift;  // = kBlock * 64 bits: one u64 bitmap word per thread
 constexpr int kWordsPerTile = kTileDocs / 64;     // 256
-constexpr int kTilesPerItem = 32;                 // tiles walked by one workgroup (a "supertile")
+constexpr int kMaxTilesPerItem = 64;              // most tiles one workgroup walks (cheap queries)
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLeaves = 40;               // operand bitmaps resident in LDS at once
 constexpr uint32_t kMaxScoreTerms = 16;
@@ -35,8 +35,14 @@ enum LeafKind : uint32_t {
 };
 
 struct DevLeaf {
-  uint32_t kind, a, b, pad;
+  uint32_t kind, a, b;
+  uint32_t score_slot;  // index of the scored term whose tf column this operand carries, or kNoSlot
+  uint32_t row;         // the gram's skip row (tile_off), or kNoRow; filled by the host so kernels need not chase it
 };
+constexpr uint32_t kNoSlot = 0xFFu;
+constexpr int kWaveScoreSlots = 4;   // scored terms the wave kernel keeps in registers
+constexpr uint32_t kTableTf = 8;     // BM25 contribution tables cover tf 1..8 ...
+constexpr uint32_t kTableDlMax = 256;  // ... and doc lengths below min(max_doc_len+1, 256)
 
 // ---- tile program: an accumulator machine over 64-bit bitmap words -------------------------------------------
 enum Op : uint32_t {
@@ -48,7 +54,7 @@ enum Op : uint32_t {
   kOpPopAnd,        // acc = stack[--sp] & acc
   kOpPopOr,         // acc = stack[--sp] | acc
   kOpPopAndNot,     // acc = stack[--sp] & ~acc
-  kOpCount,         // counter[arg] += popcount(acc)   (funnel counters)
+  kOpCount,         // counter[s] += popcount(acc) for every slot s whose bit is set in arg (funnel counters)
   kOpThreshBegin,   // bit-sliced counters = 0
   kOpThreshAdd,     // counters += W(leaf)
   kOpThreshEnd,     // acc = (counters >= arg)
@@ -92,10 +98,19 @@ struct DevIndex {
   uint32_t first_doc_id;
   uint32_t n_docs;
   uint32_t n_tiles;
-  uint32_t n_items;           // ceil(n_tiles / kTilesPerItem)
+  uint32_t max_doc_len;
+};
+
+// One workgroup's share of a query: tiles [tile_begin, tile_begin + n_tiles). The host cuts every query into items
+// of about equal estimated cost (expensive queries — many matches per tile — get more, shorter items), so no
+// workgroup is a long tail. `list` is the item's index in the launch-wide candidate arrays.
+struct DevItem {
+  uint32_t query, tile_begin, n_tiles, list;
 };
 
 struct DevBatch {
+  const DevItem* items;
+  uint32_t n_items;
   const DevQuery* queries;
   const DevLeaf* leaves;
   const uint32_t* prog;
@@ -104,11 +119,13 @@ struct DevBatch {
   uint32_t n_queries;
   // outputs
   unsigned long long* counters;  // [n_queries][8]: funnel slots 0..3, slot 4 = final result count
-  // score mode: per (query, item) candidates, best first
-  uint64_t* cand_keys;   // [n_score_queries][n_items][cand_stride]
+  unsigned long long* bounds;    // [n_queries] query-wide top-k pruning bound (score mode; zeroed per execute)
+  // score mode: per item candidates, best first
+  uint64_t* cand_keys;   // [n_items][cand_stride]
   uint32_t* cand_docs;
-  uint32_t* cand_n;      // [n_score_queries][n_items]
+  uint32_t* cand_n;      // [n_items]
   uint32_t cand_stride;
+  uint32_t debug_skip;   // timing ablations only (MGX_DEBUG_SKIP): 1 = no scoring, 2 = no enumeration+scoring, 4 = no parking
   // bitmap mode
   uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]
   uint32_t* tile_cnt;    // [n_bitmap_queries][n_tiles]
@@ -121,6 +138,16 @@ struct LdsPlan {
 };
 LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr, uint32_t max_cap,
                 bool score_mode);
+
+// LDS plan of the wave-autonomous scoring kernel (flat programs, <= kWaveScoreSlots scored terms).
+struct WavePlan {
+  uint32_t max_leaves, max_score, max_instr, max_cap;
+  uint32_t table_dl;      // doc-length extent of the BM25 tables (0 => no tables)
+  uint32_t has_list;      // some operand needs the per-wave scatter bitmap
+  uint32_t bytes;
+};
+WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
+                  bool has_list);
 
 // Order-preserving key of a BM25 score for "larger is better" comparisons (scores are >= 0, so the IEEE bit pattern
 // orders like the value); ASC sorts flip both key and docid.

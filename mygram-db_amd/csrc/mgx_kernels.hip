@@ -29,12 +29,16 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // of other lanes' data across it (and drains the wave's own outstanding LDS traffic).
 __device__ __forceinline__ void wave_lds_sync() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (no LDS traffic): Hillis-Steele inside each row of
+// 16 lanes (row_shr 1,2,4,8; out-of-row sources read as 0), then lane 15 of each row is added to the next row
+// (row_bcast:15, rows 1 and 3) and lane 31 to the upper half (row_bcast:31, rows 2 and 3).
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t n = __shfl_up(v, d, 64);
-    if (lane_id() >= d) v += n;
-  }
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2,3
   return v;
 }
 
@@ -81,7 +85,7 @@ __host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
   o.stack = at;     at += p.max_stack * kBlock * 8;
   o.seg_lo = at;    at += align8(p.max_leaves * 8);
   o.seg_hi = at;    at += align8(p.max_leaves * 8);
-  o.leaf = at;      at += p.max_leaves * 16;
+  o.leaf = at;      at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
   o.prog = at;      at += align8(p.max_instr * 4);
   o.scan_tot = at;  at += 4 * 16 * 4;  // 4 waves x up to 16 packed scan lanes
   o.misc = at;      at += 64;
@@ -181,12 +185,18 @@ struct WaveTopK {
   uint32_t have, pend;   // wave-uniform
   uint64_t bound_key;    // valid when have >= needed
   uint32_t bound_doc;
+  // Query-wide pruning bound shared by every wave working on the query: the best `needed`-th key any of them has
+  // published so far. At least `needed` docs with a key >= it exist, so a candidate with a strictly smaller key can
+  // never reach the page; equal keys are kept (docid decides). Stale reads only prune less.
+  unsigned long long* gbound_ptr;
+  uint64_t gbound;
 };
 
 // In-LDS bitonic sort (best first) of all 2*cap entries by the 64 lanes of one wave, then keep the first cap.
 __device__ void wave_topk_truncate(WaveTopK& t) {
   const uint32_t n = 2 * t.cap;
   const int lane = lane_id();
+  if (t.pend == 0) return;  // the kept region is already sorted (or empty)
   wave_lds_sync();
   for (uint32_t k = 2; k <= n; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -217,18 +227,29 @@ __device__ void wave_topk_truncate(WaveTopK& t) {
   if (t.have >= t.needed) {
     t.bound_key = t.keys[t.needed - 1];
     t.bound_doc = t.docs[t.needed - 1];
+    if (t.gbound_ptr && t.bound_key > t.gbound) {
+      if (lane == 0) atomicMax(t.gbound_ptr, static_cast<unsigned long long>(t.bound_key));
+      t.gbound = t.bound_key;
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_topk_refresh_gbound(WaveTopK& t) {
+  if (t.gbound_ptr) {
+    const uint64_t g = __hip_atomic_load(t.gbound_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g > t.gbound) t.gbound = g;
   }
 }
 
 // Offer one candidate per lane (valid=false for idle lanes). Wave-uniform control flow.
 __device__ __forceinline__ void wave_topk_offer(WaveTopK& t, bool valid, uint64_t key, uint32_t doc) {
-  bool surv = valid && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
+  bool surv = valid && key >= t.gbound && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
   uint64_t mask = __ballot(surv);
   if (mask == 0) return;
   uint32_t ns = __popcll(mask);
   if (t.pend + ns > t.cap) {
     wave_topk_truncate(t);
-    surv = surv && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
+    surv = surv && key >= t.gbound && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
     mask = __ballot(surv);
     if (mask == 0) return;
     ns = __popcll(mask);
@@ -257,8 +278,10 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   uint16_t* const matchbuf = reinterpret_cast<uint16_t*>(smem + lo_.match);
 
   const uint32_t tid = threadIdx.x;
-  const uint32_t qi = blockIdx.x % bt.n_queries;   // item-major: neighbouring workgroups walk the same doc range
-  const uint32_t item = blockIdx.x / bt.n_queries; // for different queries, so shared lists/doc_len hit in L2
+  // items are ordered by doc range first: neighbouring workgroups walk the same tiles for different queries, so
+  // shared lists / doc_len hit in L2
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query;
   const DevQuery q = bt.queries[qi];
   if (q.mode != MODE) return;
 
@@ -276,6 +299,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     tk.pend = 0;
     tk.bound_key = 0;
     tk.bound_doc = 0;
+    tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
+    tk.gbound = 0;
     for (uint32_t i = lane_id(); i < 2 * q.cap; i += 64) {
       tk.keys[i] = 0;
       tk.docs[i] = 0;
@@ -283,12 +308,13 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   }
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
 
-  const uint32_t tile_begin = item * kTilesPerItem;
-  const uint32_t tile_end = min(tile_begin + kTilesPerItem, ix.n_tiles);
+  const uint32_t tile_begin = it.tile_begin;
+  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   __syncthreads();
 
   for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
+    if (MODE == kModeScore) wave_topk_refresh_gbound(tk);
 
     // ---- A. operand setup: segment bounds, and bitmaps that need no scatter -----------------------------------
     if (tid < n_leaves) {
@@ -368,10 +394,10 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
           case kOpPopAndNot: --sp; acc = stack[sp * kBlock + tid] & ~acc; break;
           case kOpCount: {
             const uint32_t pcnt = __popcll(acc);
-            cnt0 += arg == 0 ? pcnt : 0;
-            cnt1 += arg == 1 ? pcnt : 0;
-            cnt2 += arg == 2 ? pcnt : 0;
-            cnt3 += arg == 3 ? pcnt : 0;
+            cnt0 += (arg & 1u) ? pcnt : 0;
+            cnt1 += (arg & 2u) ? pcnt : 0;
+            cnt2 += (arg & 4u) ? pcnt : 0;
+            cnt3 += (arg & 8u) ? pcnt : 0;
             break;
           }
           case kOpThreshBegin:
@@ -535,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       have[w] = min(misc[w], q.needed);
       total += have[w];
     }
-    const uint64_t obase = (static_cast<uint64_t>(q.out_slot) * ix.n_items + item) * bt.cand_stride;
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
     for (uint32_t e = tid; e < 4 * cap; e += kBlock) {
       const uint32_t w = e / cap, i = e % cap;
       if (i >= have[w]) continue;
@@ -559,7 +585,447 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
         bt.cand_docs[obase + rank] = d;
       }
     }
-    if (tid == 0) bt.cand_n[static_cast<uint64_t>(q.out_slot) * ix.n_items + item] = min(total, q.needed);
+    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-autonomous scoring kernel (the fast path of SORT _score batches)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// Same work as tile_eval_kernel<kModeScore> for "flat" programs (LOAD/AND/OR/ANDNOT/COUNT only, at most
+// kWaveScoreSlots scored terms), restructured so that nothing inside the tile loop needs a workgroup barrier:
+//   * each WAVE owns whole 16384-doc tiles (tile = tile_begin + wave, +4, ...); a lane owns 4 consecutive 64-bit
+//     words (256 doc slots) of every operand bitmap (two 16-byte loads per operand for bitmap-form operands; sorted
+//     lists go through a 2 KiB per-wave LDS bitmap);
+//   * phase A evaluates the program in registers; scored operands are also parked in per-wave LDS together with a
+//     per-word prefix popcount, so that the posting index of any doc (for the tf column) is
+//     tile_off + prefix[word] + popcount(word & below) — no rank directory, no block scan;
+//   * phase B: every lane appends its matches (14-bit slots) to the wave's LDS match buffer — nothing else;
+//   * phase C: matches are scored one per lane, up to kScoreUnroll per lane per iteration with every gather (doc_len,
+//     tf per term) issued before the first is consumed, so a tile costs about one memory round trip;
+//   * BM25 term contributions idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) are tabulated once per workgroup in LDS for
+//     tf <= 8 and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84), so a match costs
+//     one LDS read per term instead of an fp64 division; anything outside the table is computed directly;
+//   * every wave keeps its own running top-k (WaveTopK); the four lists are merged once at the end.
+
+constexpr uint32_t kWaveMatchBuf = 512;  // matches buffered per wave between enumeration and scoring
+constexpr int kScoreUnroll = 8;          // matches in flight per lane in phase C
+constexpr int kPrefetchOps = 6;          // bitmap operands whose next tile is touched ahead of time
+
+struct WaveOffsets {
+  uint32_t prog, leaf, table, scratch, opw, opp, mbuf, tk_keys, tk_docs, misc, total;
+};
+
+__host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
+  WaveOffsets o;
+  uint32_t at = 0;
+  o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
+  o.prog = at;     at += align8(p.max_instr * 4);
+  o.misc = at;     at += 128;  // [0..3] per-wave list sizes; [8..8+2*kPrefetchOps) row bases of prefetchable operands
+  o.table = at;    at += p.max_score * kTableTf * p.table_dl * 8;
+  o.scratch = at;  at += p.has_list ? 4 * kWordsPerTile * 8 : 0;
+  o.opw = at;      at += 4 * p.max_score * kWordsPerTile * 8;
+  o.opp = at;      at += 4 * p.max_score * 2 * kWordsPerTile * 2;  // one u16 per 32-bit half-word
+  o.mbuf = at;     at += 4 * kWaveMatchBuf * 2;
+  o.tk_keys = at;  at += 4 * 2 * p.max_cap * 8;
+  o.tk_docs = at;  at += 4 * 2 * p.max_cap * 4;
+  o.total = at;
+  return o;
+}
+
+WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
+                  bool has_list) {
+  WavePlan p{max_leaves ? max_leaves : 1, max_score, max_instr ? max_instr : 1, max_cap, 0, has_list ? 1u : 0u, 0};
+  p.table_dl = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
+  p.bytes = carve_wave(p).total;
+  return p;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan_total(uint32_t v, uint32_t* total) {
+  const uint32_t inc = wave_incl_scan(v);
+  *total = __builtin_amdgcn_readlane(inc, 63);
+  return inc - v;
+}
+
+// scatter one sorted segment into a per-wave 16384-bit LDS bitmap, 64 lanes
+__device__ __forceinline__ void wave_scatter_segment(const uint32_t* __restrict__ ids, uint64_t lo, uint64_t hi,
+                                                     uint32_t tile_first_doc, uint32_t* __restrict__ bm32) {
+  const uint64_t p0 = lo & ~3ull;
+  for (uint64_t p = p0 + 4ull * lane_id(); p < hi; p += 4ull * 64) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ids + p);
+    const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+    uint32_t curw = 0xFFFFFFFFu, curm = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t q = p + j;
+      if (q >= lo && q < hi) {
+        const uint32_t bit = e[j] - tile_first_doc;
+        const uint32_t w = bit >> 5, m = 1u << (bit & 31);
+        if (w == curw) {
+          curm |= m;
+        } else {
+          if (curm) atomicOr(&bm32[curw], curm);
+          curw = w;
+          curm = m;
+        }
+      }
+    }
+    if (curm) atomicOr(&bm32[curw], curm);
+  }
+}
+
+// This lane's four 64-bit words (256 doc slots) of one operand for `tile`; *seg_rel = list-relative index of the
+// tile's first posting (the rank base of the tf column) for posting-list operands.
+__device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
+                                                   uint32_t tile, uint64_t tile_first, uint64_t* scratch,
+                                                   uint64_t (&w)[4], uint32_t* seg_rel) {
+  const uint32_t lane = lane_id();
+  *seg_rel = 0;
+  if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap) {
+    const uint64_t* rowp = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
+                           (static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + lane * 4;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(rowp);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + 2);
+    w[0] = (static_cast<uint64_t>(v0.y) << 32) | v0.x;
+    w[1] = (static_cast<uint64_t>(v0.w) << 32) | v0.z;
+    w[2] = (static_cast<uint64_t>(v1.y) << 32) | v1.x;
+    w[3] = (static_cast<uint64_t>(v1.w) << 32) | v1.z;
+    if (lf.kind == kLeafGramBitmap && lf.score_slot != kNoSlot)
+      *seg_rel = ix.tile_off[static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1) + tile];
+  } else if (lf.kind == kLeafRange) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + (static_cast<uint64_t>(lane) * 4 + k) * 64;
+      const uint64_t ra = lf.a > s0 ? lf.a - s0 : 0, rb = lf.b > s0 ? lf.b - s0 : 0;
+      const uint64_t hi_mask = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
+      const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
+      w[k] = hi_mask & ~lo_mask;
+    }
+  } else {  // sorted list (posting list or explicit ids): scatter into this wave's LDS bitmap
+    uint64_t a, b;
+    const uint32_t* ids;
+    if (lf.kind == kLeafList) {
+      ids = ix.docids;
+      const uint64_t l0 = ix.offsets[lf.a], l1 = ix.offsets[lf.a + 1];
+      if (lf.row != kNoRow) {
+        const uint32_t* r = ix.tile_off + static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1);
+        a = l0 + r[tile];
+        b = l0 + r[tile + 1];
+      } else {
+        a = lower_bound_u32(ids, l0, l1, tile_first);
+        b = lower_bound_u32(ids, a, l1, tile_first + kTileDocs);
+      }
+      *seg_rel = static_cast<uint32_t>(a - l0);
+    } else {
+      ids = bt.explicit_pool;
+      a = lower_bound_u32(ids, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
+      b = lower_bound_u32(ids, a, static_cast<uint64_t>(lf.a) + lf.b, tile_first + kTileDocs);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) scratch[lane * 4 + k] = 0;
+    wave_lds_sync();
+    wave_scatter_segment(ids, a, b, static_cast<uint32_t>(tile_first), reinterpret_cast<uint32_t*>(scratch));
+    wave_lds_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = scratch[lane * 4 + k];
+    wave_lds_sync();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const WaveOffsets wo = carve_wave(plan);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + wo.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + wo.prog);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + wo.misc);
+  double* const table = reinterpret_cast<double*>(smem + wo.table);
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  const uint32_t ns_alloc = plan.max_score;
+  uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
+  uint64_t* const opw = reinterpret_cast<uint64_t*>(smem + wo.opw) + static_cast<size_t>(wave) * ns_alloc * kWordsPerTile;
+  const uint32_t* const opw32 = reinterpret_cast<const uint32_t*>(opw);
+  uint16_t* const opp = reinterpret_cast<uint16_t*>(smem + wo.opp) + static_cast<size_t>(wave) * ns_alloc * 2 * kWordsPerTile;
+  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
+
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query;
+  const DevQuery q = bt.queries[qi];
+  const uint32_t n_leaves = q.n_leaves;
+  const uint32_t tdl = plan.table_dl;
+  for (uint32_t i = tid; i < n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
+  // BM25 contribution tables: table[(i*kTableTf + tf-1)*tdl + dl]
+  for (uint32_t e = tid; e < q.n_score * kTableTf * tdl; e += kBlock) {
+    const uint32_t dli = e % tdl, tfi = (e / tdl) % kTableTf + 1, i = e / (tdl * kTableTf);
+    const double idf = bt.score_terms[q.score_begin + i].idf;
+    const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
+    const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+    const double numerator = tf * q.k1_plus_1;
+    const double denominator = tf + q.k1 * length_norm;
+    table[e] = idf * numerator / denominator;
+  }
+
+  // bitmap-form operands, in program order: their next tile is touched (loaded and discarded) while the current
+  // tile is being scored, so that the real loads of the next tile hit in L2/L1 instead of paying HBM latency
+  const uint64_t** const pf_base = reinterpret_cast<const uint64_t**>(misc + 8);
+  if (tid == 0) {
+    uint32_t n_pf = 0;
+    for (uint32_t pc = 0; pc < q.n_instr && n_pf < kPrefetchOps; ++pc) {
+      const uint32_t ins = bt.prog[q.prog_begin + pc];
+      if ((ins >> 24) == kOpCount) continue;
+      const DevLeaf lf = bt.leaves[q.leaf_begin + (ins & 0xFFFFFFu)];
+      if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap)
+        pf_base[n_pf++] = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
+                          static_cast<uint64_t>(lf.b) * ix.n_tiles * kWordsPerTile;
+    }
+    misc[4] = n_pf;
+  }
+
+  WaveTopK tk;
+  tk.cap = q.cap;
+  tk.needed = q.needed;
+  tk.keys = reinterpret_cast<uint64_t*>(smem + wo.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + wo.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.have = 0;
+  tk.pend = 0;
+  tk.bound_key = 0;
+  tk.bound_doc = 0;
+  tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
+  tk.gbound = 0;
+  for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
+    tk.keys[i] = 0;
+    tk.docs[i] = 0;
+  }
+  __syncthreads();
+
+  // per scored term: where its tf column starts, and its idf (for contributions outside the table)
+  uint64_t tf_base[kWaveScoreSlots];
+  double idf_s[kWaveScoreSlots];
+#pragma unroll
+  for (int i = 0; i < kWaveScoreSlots; ++i) {
+    tf_base[i] = 0;
+    idf_s[i] = 0.0;
+    if (static_cast<uint32_t>(i) < q.n_score) {
+      const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+      tf_base[i] = ix.offsets[leaf[st.leaf].a];
+      idf_s[i] = st.idf;
+    }
+  }
+
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  const uint32_t tile_begin = it.tile_begin;
+  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
+  const bool desc = q.descending != 0;
+
+  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += 4) {
+    const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
+    wave_topk_refresh_gbound(tk);
+    uint64_t acc[4] = {0, 0, 0, 0};
+
+    // ---- phase A: program; scored operands are also parked in LDS with, per 32-bit half-word, the number of their
+    // postings that precede it inside the tile --------------------------------------------------------------------
+    uint32_t sseg[kWaveScoreSlots] = {0, 0, 0, 0};  // tile's first posting of each scored operand, list-relative
+    for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+      const uint32_t ins = prog[pc];
+      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+      if (op == kOpCount) {
+        const uint32_t pcnt = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+        cnt0 += (arg & 1u) ? pcnt : 0;
+        cnt1 += (arg & 2u) ? pcnt : 0;
+        cnt2 += (arg & 4u) ? pcnt : 0;
+        cnt3 += (arg & 8u) ? pcnt : 0;
+        continue;
+      }
+      const DevLeaf lf = leaf[arg];
+      uint64_t w[4];
+      uint32_t seg_rel;
+      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (op == kOpLoad) acc[k] = w[k];
+        else if (op == kOpAnd) acc[k] &= w[k];
+        else if (op == kOpOr) acc[k] |= w[k];
+        else if (op == kOpAndNot) acc[k] &= ~w[k];
+      }
+      if (lf.score_slot != kNoSlot && !(bt.debug_skip & 4u)) {
+        const uint32_t c = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+        uint32_t tot;
+        uint32_t run = wave_excl_scan_total(c, &tot);
+        uint64_t* ow = opw + lf.score_slot * kWordsPerTile + lane * 4;
+        uint16_t* op16 = opp + lf.score_slot * (2 * kWordsPerTile) + lane * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ow[k] = w[k];
+          op16[2 * k] = static_cast<uint16_t>(run);
+          run += __popc(static_cast<uint32_t>(w[k]));
+          op16[2 * k + 1] = static_cast<uint16_t>(run);
+          run += __popc(static_cast<uint32_t>(w[k] >> 32));
+        }
+#pragma unroll
+        for (int i = 0; i < kWaveScoreSlots; ++i)
+          if (lf.score_slot == static_cast<uint32_t>(i)) sseg[i] = seg_rel;
+      }
+    }
+    cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+
+    // Touch this wave's next tile now that this tile's own operand loads have returned (vector memory returns in
+    // issue order, so issuing the touch earlier would only delay them); the touch is waited for at the end of the
+    // iteration, i.e. it overlaps enumeration and scoring.
+    uint4 pfa[kPrefetchOps], pfb[kPrefetchOps];
+    {
+      const uint32_t n_pf = misc[4];
+      const uint32_t nt = tile + 4 < tile_end ? tile + 4 : tile;
+#pragma unroll
+      for (int j = 0; j < kPrefetchOps; ++j) {
+        pfa[j] = make_uint4(0, 0, 0, 0);
+        pfb[j] = make_uint4(0, 0, 0, 0);
+        if (static_cast<uint32_t>(j) < n_pf) {
+          const uint64_t* p = pf_base[j] + static_cast<uint64_t>(nt) * kWordsPerTile + lane * 4;
+          pfa[j] = *reinterpret_cast<const uint4*>(p);
+          pfb[j] = *reinterpret_cast<const uint4*>(p + 2);
+        }
+      }
+    }
+
+    // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc (every lane resumes where it stopped), C scores.
+    for (;;) {
+      const uint32_t left = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+      uint32_t n_left;
+      const uint32_t my_first = wave_excl_scan_total(left, &n_left);
+      if (n_left == 0 || (bt.debug_skip & 2u)) break;  // wave-uniform
+      // ---- phase B: this lane's next matches, in doc order, into the wave's match buffer ----------------------------
+      {
+        uint32_t r = my_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t base = lane * 256 + k * 64;
+          while (acc[k] != 0 && r < kWaveMatchBuf) {
+            const uint32_t bit = __builtin_ctzll(acc[k]);
+            acc[k] &= acc[k] - 1;
+            mbuf[r] = static_cast<uint16_t>(base + bit);
+            ++r;
+          }
+        }
+      }
+      wave_lds_sync();
+      const uint32_t nm = min(kWaveMatchBuf, n_left);
+      // ---- phase C: score them, one match per lane, kScoreUnroll in flight --------------------------------------------
+      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
+        bool valid[kScoreUnroll];
+        uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
+        uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+          valid[m] = false;
+          slot[m] = 0;
+          dli[m] = 0;
+#pragma unroll
+          for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
+          if (j0 + m * 64 < nm) {  // wave-uniform
+            const uint32_t j = j0 + m * 64 + lane;
+            valid[m] = j < nm;
+            if (valid[m]) {
+              const uint32_t d = mbuf[j];
+              const uint32_t half = d >> 5, mask = 1u << (d & 31);  // 32-bit halves: cheaper than 64-bit VALU ops
+              slot[m] = tile * kTileDocs + d;
+              dli[m] = ix.doc_len[slot[m]];
+#pragma unroll
+              for (int i = 0; i < kWaveScoreSlots; ++i) {
+                if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
+                  const uint32_t wbits = opw32[i * (2 * kWordsPerTile) + half];
+                  if (wbits & mask) {
+                    const uint32_t rank = opp[i * (2 * kWordsPerTile) + half] + __popc(wbits & (mask - 1u));
+                    tfv[m][i] = ix.tf[tf_base[i] + sseg[i] + rank];
+                  }
+                }
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+          if (j0 + m * 64 < nm) {  // wave-uniform
+            double score = 0.0;
+#pragma unroll
+            for (int i = 0; i < kWaveScoreSlots; ++i) {
+              if (tfv[m][i] != 0) {
+                if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
+                  score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
+                } else {  // bm25_scorer.cpp:80-84, same operation order as the table
+                  const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
+                  const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+                  const double numerator = tf * q.k1_plus_1;
+                  const double denominator = tf + q.k1 * length_norm;
+                  score += idf_s[i] * numerator / denominator;
+                }
+              }
+            }
+            const uint32_t doc = ix.first_doc_id + slot[m];
+            wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    {
+      uint32_t sink = 0;
+#pragma unroll
+      for (int j = 0; j < kPrefetchOps; ++j)
+        sink ^= pfa[j].x ^ pfa[j].y ^ pfa[j].z ^ pfa[j].w ^ pfb[j].x ^ pfb[j].y ^ pfb[j].z ^ pfb[j].w;
+      __asm__ volatile("" ::"v"(sink));
+    }
+  }
+
+  {
+    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t x = v[s];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
+    }
+  }
+
+  // ---- merge the four waves' lists into this workgroup's best `needed` (as tile_eval_kernel does) ------------------
+  wave_topk_truncate(tk);
+  if (lane == 0) misc[wave] = tk.have;
+  __syncthreads();
+  {
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + wo.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + wo.tk_docs);
+    const uint32_t cap = q.cap;
+    uint32_t have[4];
+    uint32_t total = 0;
+    for (int w = 0; w < 4; ++w) {
+      have[w] = min(misc[w], q.needed);
+      total += have[w];
+    }
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
+    for (uint32_t e = tid; e < 4 * cap; e += kBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= have[w]) continue;
+      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+      uint32_t rank = i;
+      for (uint32_t w2 = 0; w2 < 4; ++w2) {
+        if (w2 == w) continue;
+        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+        uint32_t lo = 0, hi = have[w2];
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < q.needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = d;
+      }
+    }
+    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
   }
 }
 
@@ -583,11 +1049,16 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
                                                             uint32_t* __restrict__ page_docs,
                                                             double* __restrict__ page_scores,
                                                             uint32_t* __restrict__ page_n, uint32_t page_stride,
-                                                            const uint32_t* __restrict__ query_ids) {
+                                                            const uint32_t* __restrict__ query_ids,
+                                                            const uint32_t* __restrict__ list_begin) {
   const uint32_t slot = blockIdx.x;
   const DevQuery q = queries[query_ids[slot]];
-#define MGX_K(j) (static_cast<uint64_t>(slot) * kq + static_cast<uint64_t>(j) * kj)
-#define MGX_C(j) (static_cast<uint64_t>(slot) * cq + static_cast<uint64_t>(j) * cj)
+  // with list_begin (CSR over query slots) the lists of slot qq are lists list_begin[qq] .. list_begin[qq+1]-1 of
+  // one launch-wide array: list L at keys[L*kj], cnt[L*cj]
+  const uint64_t l0 = list_begin ? list_begin[slot] : 0;
+  if (list_begin) n_lists = list_begin[slot + 1] - list_begin[slot];
+#define MGX_K(j) (list_begin ? (l0 + (j)) * kj : static_cast<uint64_t>(slot) * kq + static_cast<uint64_t>(j) * kj)
+#define MGX_C(j) (list_begin ? (l0 + (j)) * cj : static_cast<uint64_t>(slot) * cq + static_cast<uint64_t>(j) * cj)
   __shared__ uint32_t s_total;
   if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
@@ -841,7 +1312,7 @@ int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uin
 }
 
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s) {
-  const uint64_t grid = static_cast<uint64_t>(ix.n_items) * bt.n_queries;
+  const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
   if (mode == kModeScore) {
@@ -865,15 +1336,29 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
   return 0;
 }
 
+int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
+  const uint64_t grid = bt.n_items;
+  if (grid == 0) return 0;
+  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  if (plan.bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_score_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(wave_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan);
+  MGX_KCHECK();
+  return 0;
+}
+
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
                     uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
-                    uint32_t page_stride, hipStream_t s) {
+                    uint32_t page_stride, const uint32_t* list_begin, hipStream_t s) {
   if (n_slots == 0) return 0;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, kq, kj,
                      cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
-                     query_ids);
+                     query_ids, list_begin);
   MGX_KCHECK();
   return 0;
 }

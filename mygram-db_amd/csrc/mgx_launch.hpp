@@ -11,11 +11,12 @@ int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const ui
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
                        uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
+int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
                     uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
-                    uint32_t page_stride, hipStream_t s);
+                    uint32_t page_stride, const uint32_t* list_begin, hipStream_t s);
 int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t pitch, uint64_t* out,
                     hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,

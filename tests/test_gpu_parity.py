@@ -79,7 +79,16 @@ def test_set_algebra_random_vs_oracle(pair60k):
             pair60k.oidx.filter_by_ngrams(cand, terms[:2]).tolist(), terms
 
 
-def test_scored_batch_bit_exact(pair60k):
+@pytest.fixture(params=["wave-kernel", "block-kernel"])
+def score_kernel(request, monkeypatch):
+    """SORT _score batches run on the wave-autonomous kernel when every query is flat; the general workgroup
+    kernel is kept covered by forcing it."""
+    if request.param == "block-kernel":
+        monkeypatch.setenv("MGX_FORCE_BLOCK_KERNEL", "1")
+    return request.param
+
+
+def test_scored_batch_bit_exact(pair60k, score_kernel):
     c, sizes, grams = _letter_grams(pair60k)
     rng = np.random.default_rng(2)
     queries = []
@@ -94,7 +103,7 @@ def test_scored_batch_bit_exact(pair60k):
     pair60k.check(queries)
 
 
-def test_not_terms_filters_and_funnel(pair60k):
+def test_not_terms_filters_and_funnel(pair60k, score_kernel):
     c, sizes, grams = _letter_grams(pair60k)
     rng = np.random.default_rng(3)
     f_even = pair60k.add_filter(range(2, c.n_docs + 1, 2))
@@ -165,7 +174,7 @@ def test_score_documents_unknown_and_textless_candidates():
     assert score[1] == 0.0 and score[-1] == 0.0
 
 
-def test_ties_break_on_docid_both_directions():
+def test_ties_break_on_docid_both_directions(score_kernel):
     # every doc identical => all scores tie; DESC keeps larger docids first, ASC smaller first (result_sorter.cpp:681-686)
     p = Pair(docs=[(i, "abab cd") for i in range(1, 40_001)])
     got = p.check([Query(["ab", "cd"], sort_score=True, limit=10, descending=True),
@@ -175,9 +184,9 @@ def test_ties_break_on_docid_both_directions():
     assert got[1].docs.tolist() == list(range(1, 11))
 
 
-def test_spans_many_tiles_and_workgroups():
-    # 600k docs = 37 tiles of 16384 = 2 workgroup items per query; first_doc_id far from 1
-    corpus = mg.Corpus.synthetic(600_000, seed=5)
+def test_spans_many_tiles_and_workgroups(score_kernel):
+    # 1.2M docs = 74 tiles of 16384 = 2 workgroup items (64 tiles each) per query
+    corpus = mg.Corpus.synthetic(1_200_000, seed=5)
     p = Pair(corpus=corpus)
     c, sizes, grams = _letter_grams(p)
     rng = np.random.default_rng(6)
