@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -103,7 +104,7 @@ struct mgx_index {
   hipStream_t stream = nullptr;
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
-  DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
+  DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_gram_rank, d_filter_bitmaps;
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -247,6 +248,9 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
     MGX_LAUNCH(mgx::LaunchBuildBitmaps(idx->d_docids.as<uint32_t>(), d_lo.as<uint64_t>(), d_hi.as<uint64_t>(),
                                        static_cast<uint32_t>(bm_grams.size()), d->first_doc_id, idx->words_per_row,
                                        idx->d_gram_bitmaps.as<uint64_t>(), idx->stream));
+    MGX_HIP(idx->d_gram_rank.Alloc(bm_grams.size() * idx->words_per_row * 2 * sizeof(uint16_t)));
+    MGX_LAUNCH(mgx::LaunchBuildRankDir(idx->d_gram_bitmaps.as<uint64_t>(), static_cast<uint32_t>(bm_grams.size()),
+                                       n_tiles, idx->d_gram_rank.as<uint16_t>(), idx->stream));
     MGX_HIP(hipStreamSynchronize(idx->stream));
   }
 
@@ -258,6 +262,7 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.skip_row = idx->d_skip_row.as<uint32_t>();
   v.tile_off = idx->d_tile_off.as<uint32_t>();
   v.gram_bitmaps = idx->d_gram_bitmaps.as<uint64_t>();
+  v.gram_rank = idx->d_gram_rank.as<uint16_t>();
   v.filter_bitmaps = nullptr;
   v.first_doc_id = d->first_doc_id;
   v.n_docs = static_cast<uint32_t>(n_docs);
@@ -302,7 +307,8 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (out) *out = 0;
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
-         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes;
+         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_gram_rank.bytes +
+         idx->d_filter_bitmaps.bytes;
   return MGX_OK;
 }
 
@@ -555,7 +561,11 @@ struct mgx_batch {
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
     mgx::WavePlan wplan{};
-    bool use_wave = false;
+    // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
+    // separately, over disjoint item lists, into the same candidate arrays
+    mgx::DevBatch dev_wave{};
+    DevBuf d_items_wave;
+    uint32_t n_items_wave = 0;
     DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident, d_items, d_list_begin;
     uint32_t n_items = 0;
     std::vector<unsigned long long> h_counters;
@@ -633,17 +643,28 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     b->list_bytes += 4 * s.list_postings;
   }
   g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode);
+  std::vector<uint8_t> on_wave(n, 0);
   if (score_mode) {
-    bool wave_ok = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr, has_list = false;
+    const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
+    uint32_t wl = 0, wsc = 0, wi = 0, wc = 64;
+    bool has_list = false;
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = b->specs[g.qids[i]];
-      wave_ok = wave_ok && s.wave_ok;
+      bool ok = allow && s.wave_ok;
+      // the wave kernel reads a scored term's tf position through the dense form (bitmap + rank directory)
+      for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
+      if (!ok) continue;
+      on_wave[i] = 1;
       for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;
+      wl = std::max<uint32_t>(wl, dq[i].n_leaves);
+      wsc = std::max<uint32_t>(wsc, dq[i].n_score);
+      wi = std::max<uint32_t>(wi, dq[i].n_instr);
+      wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    g.wplan = PlanWave(max_leaves, max_score, max_instr, max_cap, b->idx->dev.max_doc_len, has_list);
-    g.use_wave = wave_ok && g.wplan.bytes <= 160 * 1024;
+    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
+    if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
-  if (!g.use_wave && g.plan.bytes > 160 * 1024)
+  if (g.plan.bytes > 160 * 1024)
     return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
   MGX_HIP(Upload(g.d_queries, dq.data(), dq.size()));
   MGX_HIP(Upload(g.d_leaves, leaves.data(), leaves.size()));
@@ -652,6 +673,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   MGX_HIP(Upload(g.d_explicit, expl.data(), expl.size(), 4));
   // [n][8] counters followed by [n] pruning bounds: one memset clears both before every execute
   MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 9 * sizeof(unsigned long long)));
+  g.h_counters.assign(static_cast<size_t>(n) * 8, 0);
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
   MGX_HIP(Upload(g.d_ident, ident.data(), n));
@@ -667,7 +689,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 96.0;
       const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
-      tiles = std::max<uint32_t>(4, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~3u;  // whole rounds of 4 waves
+      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of 8 waves
       list_begin[i] = static_cast<uint32_t>(items.size());
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), 0};
@@ -681,10 +703,17 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       return a.tile_begin / kMaxTilesPerItem < c.tile_begin / kMaxTilesPerItem;
     });
   }
-  g.n_items = static_cast<uint32_t>(items.size());
-  MGX_HIP(Upload(g.d_items, items.data(), items.size()));
+  const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
+  std::vector<DevItem> items_wave, items_block;
+  for (const DevItem& it : items) (on_wave[it.query] ? items_wave : items_block).push_back(it);
+  g.n_items = static_cast<uint32_t>(items_block.size());
+  g.n_items_wave = static_cast<uint32_t>(items_wave.size());
+  MGX_HIP(Upload(g.d_items, items_block.data(), items_block.size()));
+  MGX_HIP(Upload(g.d_items_wave, items_wave.data(), items_wave.size()));
   MGX_HIP(Upload(g.d_list_begin, list_begin.data(), list_begin.size()));
-  g.h_counters.assign(static_cast<size_t>(n) * 8, 0);
+  if (std::getenv("MGX_VERBOSE"))
+    fprintf(stderr, "[mgx] %s group: %u queries; wave kernel %u items (lds %u B), block kernel %u items (lds %u B)\n",
+            score_mode ? "score" : "bitmap", n, g.n_items_wave, g.wplan.bytes, g.n_items, g.plan.bytes);
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
   d.n_items = g.n_items;
@@ -703,7 +732,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       max_needed = std::max(max_needed, q.needed);
       max_limit = std::max(max_limit, q.limit);
     }
-    const size_t n_lists_total = g.n_items;
+    const size_t n_lists_total = n_lists_all;
     d.cand_stride = max_needed;
     b->top_stride = max_needed;
     b->page_stride = max_limit;
@@ -734,6 +763,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
   }
+  g.dev_wave = d;
+  g.dev_wave.items = g.d_items_wave.as<DevItem>();
+  g.dev_wave.n_items = g.n_items_wave;
   return MGX_OK;
 }
 
@@ -770,11 +802,8 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    if (g.use_wave) {
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev, g.wplan, s));
-    } else {
-      MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
-    }
+    MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev1, s));
       timed = true;

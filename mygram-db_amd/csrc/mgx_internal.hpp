@@ -40,7 +40,9 @@ struct DevLeaf {
   uint32_t row;         // the gram's skip row (tile_off), or kNoRow; filled by the host so kernels need not chase it
 };
 constexpr uint32_t kNoSlot = 0xFFu;
-constexpr int kWaveScoreSlots = 4;   // scored terms the wave kernel keeps in registers
+constexpr int kWaveScoreSlots = 4;   // scored terms the wave kernel handles
+constexpr int kWaveBlock = 512;      // threads per workgroup of the wave kernel (8 autonomous waves share one BM25 table)
+constexpr int kWavesPerBlock = kWaveBlock / 64;
 constexpr uint32_t kTableTf = 8;     // BM25 contribution tables cover tf 1..8 ...
 constexpr uint32_t kTableDlMax = 256;  // ... and doc lengths below min(max_doc_len+1, 256)
 
@@ -94,6 +96,7 @@ struct DevIndex {
   const uint32_t* skip_row;   // [G] row in tile_off, or kNoRow
   const uint32_t* tile_off;   // [rows][n_tiles+1]
   const uint64_t* gram_bitmaps;
+  const uint16_t* gram_rank;  // [bitmap rows][n_tiles*512]: postings of the row inside the tile before each 32-bit half-word
   const uint64_t* filter_bitmaps;
   uint32_t first_doc_id;
   uint32_t n_docs;

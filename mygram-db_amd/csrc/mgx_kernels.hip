@@ -143,6 +143,26 @@ __global__ void build_bitmap_kernel(const uint32_t* __restrict__ docids, const u
   }
 }
 
+// gram_rank[row][tile*512 + h] = set bits of the row's bitmap inside `tile` before 32-bit half-word h.
+// One 256-thread workgroup per (tile, row); thread t owns 64-bit word t.
+__global__ __launch_bounds__(kBlock) void build_rank_dir_kernel(const uint64_t* __restrict__ bitmaps, uint32_t n_tiles,
+                                                                uint16_t* __restrict__ rank) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t tile = blockIdx.x, row = blockIdx.y;
+  const uint64_t base = (static_cast<uint64_t>(row) * n_tiles + tile) * kWordsPerTile;
+  const uint64_t w = bitmaps[base + threadIdx.x];
+  const uint32_t lo = __popc(static_cast<uint32_t>(w)), hi = __popc(static_cast<uint32_t>(w >> 32));
+  const uint32_t inc = wave_incl_scan(lo + hi);
+  if (lane_id() == 63) s_w[wave_id()] = inc;
+  __syncthreads();
+  uint32_t off = 0;
+  for (int i = 0; i < wave_id(); ++i) off += s_w[i];
+  const uint32_t ex = off + inc - (lo + hi);
+  uint16_t* o = rank + base * 2 + threadIdx.x * 2;
+  o[0] = static_cast<uint16_t>(ex);
+  o[1] = static_cast<uint16_t>(ex + lo);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------------------------
@@ -593,28 +613,28 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 // wave-autonomous scoring kernel (the fast path of SORT _score batches)
 // ---------------------------------------------------------------------------------------------------------------
 //
-// Same work as tile_eval_kernel<kModeScore> for "flat" programs (LOAD/AND/OR/ANDNOT/COUNT only, at most
-// kWaveScoreSlots scored terms), restructured so that nothing inside the tile loop needs a workgroup barrier:
-//   * each WAVE owns whole 16384-doc tiles (tile = tile_begin + wave, +4, ...); a lane owns 4 consecutive 64-bit
-//     words (256 doc slots) of every operand bitmap (two 16-byte loads per operand for bitmap-form operands; sorted
-//     lists go through a 2 KiB per-wave LDS bitmap);
-//   * phase A evaluates the program in registers; scored operands are also parked in per-wave LDS together with a
-//     per-word prefix popcount, so that the posting index of any doc (for the tf column) is
-//     tile_off + prefix[word] + popcount(word & below) — no rank directory, no block scan;
-//   * phase B: every lane appends its matches (14-bit slots) to the wave's LDS match buffer — nothing else;
-//   * phase C: matches are scored one per lane, up to kScoreUnroll per lane per iteration with every gather (doc_len,
-//     tf per term) issued before the first is consumed, so a tile costs about one memory round trip;
+// Same work as tile_eval_kernel<kModeScore> for "flat" programs (LOAD/AND/OR/ANDNOT/COUNT only) whose scored terms
+// (at most kWaveScoreSlots) all have the precomputed dense-bitmap form. Built for occupancy: the kernel is bound by
+// memory latency, not bandwidth, so what counts is how many tiles a CU has in flight.
+//   * a workgroup is 8 waves that share nothing but the query's BM25 table; each WAVE owns whole 16384-doc tiles
+//     (tile = tile_begin + wave, +8, ...) and never meets a workgroup barrier inside the tile loop;
+//   * phase A: a lane owns 4 consecutive 64-bit words (256 doc slots) of every operand (two 16-byte loads per
+//     bitmap-form operand; sorted lists go through a 2 KiB per-wave LDS bitmap) and evaluates the program in registers;
+//   * phase B: every lane appends its matches (14-bit slots) to the wave's small LDS match buffer;
+//   * phase C: matches are scored one per lane, kScoreUnroll per lane in flight. The posting index of a match in a
+//     scored term's tf column is tile_off[tile] + gram_rank[half-word] + popcount(bits below) — the bitmap half-word
+//     and the rank directory entry are re-read from L1/L2 (the wave has just streamed them), so no operand copy
+//     lives in LDS; then tf and doc_len gathers, then one LDS table read per term;
 //   * BM25 term contributions idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) are tabulated once per workgroup in LDS for
-//     tf <= 8 and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84), so a match costs
-//     one LDS read per term instead of an fp64 division; anything outside the table is computed directly;
-//   * every wave keeps its own running top-k (WaveTopK); the four lists are merged once at the end.
+//     tf <= 8 and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84); anything outside
+//     the table is computed directly;
+//   * every wave keeps its own running top-k (WaveTopK) pruned by the query-wide bound; the lists are merged at the end.
 
-constexpr uint32_t kWaveMatchBuf = 512;  // matches buffered per wave between enumeration and scoring
-constexpr int kScoreUnroll = 8;          // matches in flight per lane in phase C
-constexpr int kPrefetchOps = 6;          // bitmap operands whose next tile is touched ahead of time
+constexpr uint32_t kWaveMatchBuf = 256;  // matches buffered per wave between enumeration and scoring
+constexpr int kScoreUnroll = 2;          // matches in flight per lane in phase C
 
 struct WaveOffsets {
-  uint32_t prog, leaf, table, scratch, opw, opp, mbuf, tk_keys, tk_docs, misc, total;
+  uint32_t prog, leaf, table, scratch, mbuf, tk_keys, tk_docs, misc, total;
 };
 
 __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
@@ -622,14 +642,12 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
   uint32_t at = 0;
   o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
   o.prog = at;     at += align8(p.max_instr * 4);
-  o.misc = at;     at += 128;  // [0..3] per-wave list sizes; [8..8+2*kPrefetchOps) row bases of prefetchable operands
+  o.misc = at;     at += 64;
   o.table = at;    at += p.max_score * kTableTf * p.table_dl * 8;
-  o.scratch = at;  at += p.has_list ? 4 * kWordsPerTile * 8 : 0;
-  o.opw = at;      at += 4 * p.max_score * kWordsPerTile * 8;
-  o.opp = at;      at += 4 * p.max_score * 2 * kWordsPerTile * 2;  // one u16 per 32-bit half-word
-  o.mbuf = at;     at += 4 * kWaveMatchBuf * 2;
-  o.tk_keys = at;  at += 4 * 2 * p.max_cap * 8;
-  o.tk_docs = at;  at += 4 * 2 * p.max_cap * 4;
+  o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
+  o.mbuf = at;     at += kWavesPerBlock * kWaveMatchBuf * 2;
+  o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
+  o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
   o.total = at;
   return o;
 }
@@ -675,13 +693,11 @@ __device__ __forceinline__ void wave_scatter_segment(const uint32_t* __restrict_
   }
 }
 
-// This lane's four 64-bit words (256 doc slots) of one operand for `tile`; *seg_rel = list-relative index of the
-// tile's first posting (the rank base of the tf column) for posting-list operands.
+// This lane's four 64-bit words (256 doc slots) of one operand for `tile`.
 __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
                                                    uint32_t tile, uint64_t tile_first, uint64_t* scratch,
-                                                   uint64_t (&w)[4], uint32_t* seg_rel) {
+                                                   uint64_t (&w)[4]) {
   const uint32_t lane = lane_id();
-  *seg_rel = 0;
   if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap) {
     const uint64_t* rowp = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
                            (static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + lane * 4;
@@ -691,8 +707,6 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
     w[1] = (static_cast<uint64_t>(v0.w) << 32) | v0.z;
     w[2] = (static_cast<uint64_t>(v1.y) << 32) | v1.x;
     w[3] = (static_cast<uint64_t>(v1.w) << 32) | v1.z;
-    if (lf.kind == kLeafGramBitmap && lf.score_slot != kNoSlot)
-      *seg_rel = ix.tile_off[static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1) + tile];
   } else if (lf.kind == kLeafRange) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -716,7 +730,6 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
         a = lower_bound_u32(ids, l0, l1, tile_first);
         b = lower_bound_u32(ids, a, l1, tile_first + kTileDocs);
       }
-      *seg_rel = static_cast<uint32_t>(a - l0);
     } else {
       ids = bt.explicit_pool;
       a = lower_bound_u32(ids, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
@@ -733,7 +746,7 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
   }
 }
 
-__global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+__global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WaveOffsets wo = carve_wave(plan);
   DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + wo.leaf);
@@ -741,11 +754,7 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + wo.misc);
   double* const table = reinterpret_cast<double*>(smem + wo.table);
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  const uint32_t ns_alloc = plan.max_score;
   uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
-  uint64_t* const opw = reinterpret_cast<uint64_t*>(smem + wo.opw) + static_cast<size_t>(wave) * ns_alloc * kWordsPerTile;
-  const uint32_t* const opw32 = reinterpret_cast<const uint32_t*>(opw);
-  uint16_t* const opp = reinterpret_cast<uint16_t*>(smem + wo.opp) + static_cast<size_t>(wave) * ns_alloc * 2 * kWordsPerTile;
   uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
 
   const DevItem it = bt.items[blockIdx.x];
@@ -753,33 +762,20 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
   const DevQuery q = bt.queries[qi];
   const uint32_t n_leaves = q.n_leaves;
   const uint32_t tdl = plan.table_dl;
-  for (uint32_t i = tid; i < n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
-  for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
+  for (uint32_t i = tid; i < n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
   // BM25 contribution tables: table[(i*kTableTf + tf-1)*tdl + dl]
-  for (uint32_t e = tid; e < q.n_score * kTableTf * tdl; e += kBlock) {
-    const uint32_t dli = e % tdl, tfi = (e / tdl) % kTableTf + 1, i = e / (tdl * kTableTf);
+  for (uint32_t i = 0; i < q.n_score; ++i) {
     const double idf = bt.score_terms[q.score_begin + i].idf;
-    const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
-    const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-    const double numerator = tf * q.k1_plus_1;
-    const double denominator = tf + q.k1 * length_norm;
-    table[e] = idf * numerator / denominator;
-  }
-
-  // bitmap-form operands, in program order: their next tile is touched (loaded and discarded) while the current
-  // tile is being scored, so that the real loads of the next tile hit in L2/L1 instead of paying HBM latency
-  const uint64_t** const pf_base = reinterpret_cast<const uint64_t**>(misc + 8);
-  if (tid == 0) {
-    uint32_t n_pf = 0;
-    for (uint32_t pc = 0; pc < q.n_instr && n_pf < kPrefetchOps; ++pc) {
-      const uint32_t ins = bt.prog[q.prog_begin + pc];
-      if ((ins >> 24) == kOpCount) continue;
-      const DevLeaf lf = bt.leaves[q.leaf_begin + (ins & 0xFFFFFFu)];
-      if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap)
-        pf_base[n_pf++] = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
-                          static_cast<uint64_t>(lf.b) * ix.n_tiles * kWordsPerTile;
+    for (uint32_t tfi = 1; tfi <= kTableTf; ++tfi) {
+      for (uint32_t dli = tid; dli < tdl; dli += kWaveBlock) {
+        const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
+        const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+        const double numerator = tf * q.k1_plus_1;
+        const double denominator = tf + q.k1 * length_norm;
+        table[(i * kTableTf + tfi - 1) * tdl + dli] = idf * numerator / denominator;
+      }
     }
-    misc[4] = n_pf;
   }
 
   WaveTopK tk;
@@ -799,33 +795,38 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
   }
   __syncthreads();
 
-  // per scored term: where its tf column starts, and its idf (for contributions outside the table)
+  // per scored term: tf column start, idf (for contributions outside the table), bitmap row and skip row
   uint64_t tf_base[kWaveScoreSlots];
   double idf_s[kWaveScoreSlots];
+  uint32_t brow[kWaveScoreSlots], trow[kWaveScoreSlots];
 #pragma unroll
   for (int i = 0; i < kWaveScoreSlots; ++i) {
     tf_base[i] = 0;
     idf_s[i] = 0.0;
+    brow[i] = 0;
+    trow[i] = 0;
     if (static_cast<uint32_t>(i) < q.n_score) {
       const DevScoreTerm st = bt.score_terms[q.score_begin + i];
-      tf_base[i] = ix.offsets[leaf[st.leaf].a];
+      const DevLeaf lf = leaf[st.leaf];
+      tf_base[i] = ix.offsets[lf.a];
       idf_s[i] = st.idf;
+      brow[i] = lf.b;
+      trow[i] = lf.row;
     }
   }
+  const uint32_t* const bm32 = reinterpret_cast<const uint32_t*>(ix.gram_bitmaps);
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
   const uint32_t tile_begin = it.tile_begin;
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   const bool desc = q.descending != 0;
 
-  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += 4) {
+  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kWavesPerBlock) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     wave_topk_refresh_gbound(tk);
     uint64_t acc[4] = {0, 0, 0, 0};
 
-    // ---- phase A: program; scored operands are also parked in LDS with, per 32-bit half-word, the number of their
-    // postings that precede it inside the tile --------------------------------------------------------------------
-    uint32_t sseg[kWaveScoreSlots] = {0, 0, 0, 0};  // tile's first posting of each scored operand, list-relative
+    // ---- phase A: program ---------------------------------------------------------------------------------------
     for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
       const uint32_t ins = prog[pc];
       const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
@@ -837,10 +838,8 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
         cnt3 += (arg & 8u) ? pcnt : 0;
         continue;
       }
-      const DevLeaf lf = leaf[arg];
       uint64_t w[4];
-      uint32_t seg_rel;
-      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
+      wave_fetch_operand(ix, bt, leaf[arg], tile, tile_first, scratch, w);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (op == kOpLoad) acc[k] = w[k];
@@ -848,43 +847,20 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
         else if (op == kOpOr) acc[k] |= w[k];
         else if (op == kOpAndNot) acc[k] &= ~w[k];
       }
-      if (lf.score_slot != kNoSlot && !(bt.debug_skip & 4u)) {
-        const uint32_t c = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
-        uint32_t tot;
-        uint32_t run = wave_excl_scan_total(c, &tot);
-        uint64_t* ow = opw + lf.score_slot * kWordsPerTile + lane * 4;
-        uint16_t* op16 = opp + lf.score_slot * (2 * kWordsPerTile) + lane * 8;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ow[k] = w[k];
-          op16[2 * k] = static_cast<uint16_t>(run);
-          run += __popc(static_cast<uint32_t>(w[k]));
-          op16[2 * k + 1] = static_cast<uint16_t>(run);
-          run += __popc(static_cast<uint32_t>(w[k] >> 32));
-        }
-#pragma unroll
-        for (int i = 0; i < kWaveScoreSlots; ++i)
-          if (lf.score_slot == static_cast<uint32_t>(i)) sseg[i] = seg_rel;
-      }
     }
     cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+    if (bt.debug_skip & 2u) continue;
 
-    // Touch this wave's next tile now that this tile's own operand loads have returned (vector memory returns in
-    // issue order, so issuing the touch earlier would only delay them); the touch is waited for at the end of the
-    // iteration, i.e. it overlaps enumeration and scoring.
-    uint4 pfa[kPrefetchOps], pfb[kPrefetchOps];
-    {
-      const uint32_t n_pf = misc[4];
-      const uint32_t nt = tile + 4 < tile_end ? tile + 4 : tile;
+    // tf column position of the tile's first posting, and the half-word row base, per scored term (wave-uniform)
+    uint64_t tf_tile[kWaveScoreSlots];
+    uint64_t hw_base[kWaveScoreSlots];
 #pragma unroll
-      for (int j = 0; j < kPrefetchOps; ++j) {
-        pfa[j] = make_uint4(0, 0, 0, 0);
-        pfb[j] = make_uint4(0, 0, 0, 0);
-        if (static_cast<uint32_t>(j) < n_pf) {
-          const uint64_t* p = pf_base[j] + static_cast<uint64_t>(nt) * kWordsPerTile + lane * 4;
-          pfa[j] = *reinterpret_cast<const uint4*>(p);
-          pfb[j] = *reinterpret_cast<const uint4*>(p + 2);
-        }
+    for (int i = 0; i < kWaveScoreSlots; ++i) {
+      tf_tile[i] = 0;
+      hw_base[i] = 0;
+      if (static_cast<uint32_t>(i) < q.n_score) {
+        tf_tile[i] = tf_base[i] + ix.tile_off[static_cast<uint64_t>(trow[i]) * (ix.n_tiles + 1) + tile];
+        hw_base[i] = (static_cast<uint64_t>(brow[i]) * ix.n_tiles + tile) * (2 * kWordsPerTile);
       }
     }
 
@@ -893,7 +869,7 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
       const uint32_t left = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
       uint32_t n_left;
       const uint32_t my_first = wave_excl_scan_total(left, &n_left);
-      if (n_left == 0 || (bt.debug_skip & 2u)) break;  // wave-uniform
+      if (n_left == 0) break;  // wave-uniform
       // ---- phase B: this lane's next matches, in doc order, into the wave's match buffer ----------------------------
       {
         uint32_t r = my_first;
@@ -913,36 +889,53 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
       // ---- phase C: score them, one match per lane, kScoreUnroll in flight --------------------------------------------
       for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
         bool valid[kScoreUnroll];
-        uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
+        uint32_t slot[kScoreUnroll], dli[kScoreUnroll], mask[kScoreUnroll];
+        uint32_t wbits[kScoreUnroll][kWaveScoreSlots], pre[kScoreUnroll][kWaveScoreSlots];
         uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
+        // stage 1: doc_len, bitmap half-word and rank directory entry of every match x term
 #pragma unroll
         for (int m = 0; m < kScoreUnroll; ++m) {
           valid[m] = false;
           slot[m] = 0;
           dli[m] = 0;
+          mask[m] = 0;
 #pragma unroll
-          for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
+          for (int i = 0; i < kWaveScoreSlots; ++i) {
+            wbits[m][i] = 0;
+            pre[m][i] = 0;
+            tfv[m][i] = 0;
+          }
           if (j0 + m * 64 < nm) {  // wave-uniform
             const uint32_t j = j0 + m * 64 + lane;
             valid[m] = j < nm;
             if (valid[m]) {
               const uint32_t d = mbuf[j];
-              const uint32_t half = d >> 5, mask = 1u << (d & 31);  // 32-bit halves: cheaper than 64-bit VALU ops
+              const uint32_t half = d >> 5;
+              mask[m] = 1u << (d & 31);
               slot[m] = tile * kTileDocs + d;
               dli[m] = ix.doc_len[slot[m]];
 #pragma unroll
               for (int i = 0; i < kWaveScoreSlots; ++i) {
                 if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-                  const uint32_t wbits = opw32[i * (2 * kWordsPerTile) + half];
-                  if (wbits & mask) {
-                    const uint32_t rank = opp[i * (2 * kWordsPerTile) + half] + __popc(wbits & (mask - 1u));
-                    tfv[m][i] = ix.tf[tf_base[i] + sseg[i] + rank];
-                  }
+                  wbits[m][i] = bm32[hw_base[i] + half];
+                  pre[m][i] = ix.gram_rank[hw_base[i] + half];
                 }
               }
             }
           }
         }
+        // stage 2: tf of every term the doc contains
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+#pragma unroll
+          for (int i = 0; i < kWaveScoreSlots; ++i) {
+            if (wbits[m][i] & mask[m]) {
+              const uint32_t rank = pre[m][i] + __popc(wbits[m][i] & (mask[m] - 1u));
+              tfv[m][i] = ix.tf[tf_tile[i] + rank];
+            }
+          }
+        }
+        // stage 3: contributions and top-k
 #pragma unroll
         for (int m = 0; m < kScoreUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
@@ -968,13 +961,6 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
       }
       wave_lds_sync();
     }
-    {
-      uint32_t sink = 0;
-#pragma unroll
-      for (int j = 0; j < kPrefetchOps; ++j)
-        sink ^= pfa[j].x ^ pfa[j].y ^ pfa[j].z ^ pfa[j].w ^ pfb[j].x ^ pfb[j].y ^ pfb[j].z ^ pfb[j].w;
-      __asm__ volatile("" ::"v"(sink));
-    }
   }
 
   {
@@ -988,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
     }
   }
 
-  // ---- merge the four waves' lists into this workgroup's best `needed` (as tile_eval_kernel does) ------------------
+  // ---- merge the waves' lists into this workgroup's best `needed`, best first, to HBM -------------------------------
   wave_topk_truncate(tk);
   if (lane == 0) misc[wave] = tk.have;
   __syncthreads();
@@ -996,24 +982,24 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
     const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + wo.tk_keys);
     const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + wo.tk_docs);
     const uint32_t cap = q.cap;
-    uint32_t have[4];
+    uint32_t have[kWavesPerBlock];
     uint32_t total = 0;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kWavesPerBlock; ++w) {
       have[w] = min(misc[w], q.needed);
       total += have[w];
     }
     const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
-    for (uint32_t e = tid; e < 4 * cap; e += kBlock) {
+    for (uint32_t e = tid; e < kWavesPerBlock * cap; e += kWaveBlock) {
       const uint32_t w = e / cap, i = e % cap;
-      if (i >= have[w]) continue;
+      if (i >= min(misc[w], q.needed)) continue;
       const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
       const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
       uint32_t rank = i;
-      for (uint32_t w2 = 0; w2 < 4; ++w2) {
+      for (uint32_t w2 = 0; w2 < kWavesPerBlock; ++w2) {
         if (w2 == w) continue;
         const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
         const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
-        uint32_t lo = 0, hi = have[w2];
+        uint32_t lo = 0, hi = min(misc[w2], q.needed);
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
           if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
@@ -1025,6 +1011,7 @@ __global__ __launch_bounds__(kBlock) void wave_score_kernel(DevIndex ix, DevBatc
         bt.cand_docs[obase + rank] = d;
       }
     }
+    (void)have;
     if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
   }
 }
@@ -1298,6 +1285,18 @@ int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const ui
   return 0;
 }
 
+int LaunchBuildRankDir(const uint64_t* bitmaps, uint32_t n_rows, uint32_t n_tiles, uint16_t* rank, hipStream_t s) {
+  if (n_rows == 0 || n_tiles == 0) return 0;
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
+    const uint32_t nr = n_rows - r0 < 32768 ? n_rows - r0 : 32768;
+    hipLaunchKernelGGL(build_rank_dir_kernel, dim3(n_tiles, nr), dim3(kBlock), 0, s,
+                       bitmaps + static_cast<uint64_t>(r0) * n_tiles * kWordsPerTile, n_tiles,
+                       rank + static_cast<uint64_t>(r0) * n_tiles * kWordsPerTile * 2);
+    MGX_KCHECK();
+  }
+  return 0;
+}
+
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
                        uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s) {
   if (n_rows == 0) return 0;
@@ -1345,7 +1344,7 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(wave_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan);
+  hipLaunchKernelGGL(wave_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
