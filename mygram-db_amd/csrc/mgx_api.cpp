@@ -104,7 +104,7 @@ struct mgx_index {
   hipStream_t stream = nullptr;
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
-  DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_gram_rank, d_filter_bitmaps;
+  DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_gram_rank, d_filter_bitmaps;
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -205,6 +205,10 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
     MGX_HIP(mgx::Upload(idx->d_tf, d->tf, P, 4));
     MGX_HIP(mgx::Upload(idx->d_doc_len, d->doc_len, n_docs));
     for (uint64_t i = 0; i < n_docs; ++i) max_doc_len = std::max(max_doc_len, d->doc_len[i]);
+    MGX_HIP(idx->d_tfdl.Alloc((P + 4) * sizeof(uint16_t)));
+    MGX_LAUNCH(mgx::LaunchBuildTfDl(idx->d_docids.as<uint32_t>(), idx->d_tf.as<uint8_t>(),
+                                    idx->d_doc_len.as<uint32_t>(), P, d->first_doc_id, idx->d_tfdl.as<uint16_t>(),
+                                    idx->stream));
   }
 
   // which grams get a skip row / a dense bitmap
@@ -258,6 +262,7 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.offsets = idx->d_offsets.as<uint64_t>();
   v.docids = idx->d_docids.as<uint32_t>();
   v.tf = idx->d_tf.as<uint8_t>();
+  v.tfdl = idx->d_tfdl.as<uint16_t>();
   v.doc_len = idx->d_doc_len.as<uint32_t>();
   v.skip_row = idx->d_skip_row.as<uint32_t>();
   v.tile_off = idx->d_tile_off.as<uint32_t>();
@@ -306,7 +311,7 @@ int mgx_posting_size(const mgx_index* idx, uint32_t gram_id, uint64_t* out) {
 int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (out) *out = 0;
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
-  *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
+  *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_tfdl.bytes + idx->d_doc_len.bytes +
          idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_gram_rank.bytes +
          idx->d_filter_bitmaps.bytes;
   return MGX_OK;
@@ -651,8 +656,6 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = b->specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
-      // the wave kernel reads a scored term's tf position through the dense form (bitmap + rank directory)
-      for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
       if (!ok) continue;
       on_wave[i] = 1;
       for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;

@@ -40,7 +40,7 @@ struct DevLeaf {
   uint32_t row;         // the gram's skip row (tile_off), or kNoRow; filled by the host so kernels need not chase it
 };
 constexpr uint32_t kNoSlot = 0xFFu;
-constexpr int kWaveScoreSlots = 4;   // scored terms the wave kernel handles
+constexpr int kWaveScoreSlots = 3;   // scored terms the wave kernel handles
 constexpr int kWaveBlock = 512;      // threads per workgroup of the wave kernel (8 autonomous waves share one BM25 table)
 constexpr int kWavesPerBlock = kWaveBlock / 64;
 constexpr uint32_t kTableTf = 8;     // BM25 contribution tables cover tf 1..8 ...
@@ -92,6 +92,7 @@ struct DevIndex {
   const uint64_t* offsets;
   const uint32_t* docids;
   const uint8_t* tf;
+  const uint16_t* tfdl;       // [P] tf | min(doc_len,255) << 8 of the posting's doc: one gather gives a term's tf and the doc length
   const uint32_t* doc_len;
   const uint32_t* skip_row;   // [G] row in tile_off, or kNoRow
   const uint32_t* tile_off;   // [rows][n_tiles+1]

@@ -143,6 +143,16 @@ __global__ void build_bitmap_kernel(const uint32_t* __restrict__ docids, const u
   }
 }
 
+// tfdl[p] = tf[p] | min(doc_len[slot(p)], 255) << 8
+__global__ void build_tfdl_kernel(const uint32_t* __restrict__ docids, const uint8_t* __restrict__ tf,
+                                  const uint32_t* __restrict__ doc_len, uint64_t n_postings, uint32_t first_doc_id,
+                                  uint16_t* __restrict__ out) {
+  const uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= n_postings) return;
+  const uint32_t dl = doc_len[docids[p] - first_doc_id];
+  out[p] = static_cast<uint16_t>(tf[p] | ((dl < 255u ? dl : 255u) << 8));
+}
+
 // gram_rank[row][tile*512 + h] = set bits of the row's bitmap inside `tile` before 32-bit half-word h.
 // One 256-thread workgroup per (tile, row); thread t owns 64-bit word t.
 __global__ __launch_bounds__(kBlock) void build_rank_dir_kernel(const uint64_t* __restrict__ bitmaps, uint32_t n_tiles,
@@ -620,11 +630,16 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 //     (tile = tile_begin + wave, +8, ...) and never meets a workgroup barrier inside the tile loop;
 //   * phase A: a lane owns 4 consecutive 64-bit words (256 doc slots) of every operand (two 16-byte loads per
 //     bitmap-form operand; sorted lists go through a 2 KiB per-wave LDS bitmap) and evaluates the program in registers;
-//   * phase B: every lane appends its matches (14-bit slots) to the wave's small LDS match buffer;
-//   * phase C: matches are scored one per lane, kScoreUnroll per lane in flight. The posting index of a match in a
-//     scored term's tf column is tile_off[tile] + gram_rank[half-word] + popcount(bits below) — the bitmap half-word
-//     and the rank directory entry are re-read from L1/L2 (the wave has just streamed them), so no operand copy
-//     lives in LDS; then tf and doc_len gathers, then one LDS table read per term;
+//     the words of scored operands stay in registers with the wave-prefix popcount of the lane's first doc slot;
+//   * the tile is then scored in four steps, one per owned word index k: every lane parks word k of each scored
+//     operand in a 512-byte per-wave LDS strip together with the number of the operand's postings that precede its
+//     two 32-bit halves inside the tile (wave-prefix + in-lane popcounts);
+//   * phase B: every lane appends the matches of its word k (12-bit: owner lane, bit) to the wave's match buffer;
+//   * phase C: the step's matches are scored one per lane, kScoreUnroll per lane in flight. The posting index of a
+//     match in a scored term's tf column is tile_off + parked prefix + popcount(parked bits below), so it costs two
+//     LDS reads and exactly ONE gather per scored term: the first term's gather reads the packed (tf, doc_len)
+//     posting column, the others the tf column. The vector L1 handles about one lane-request per clock, so gathers
+//     per match — not bytes — are what this phase is bound by; then one LDS table read per term;
 //   * BM25 term contributions idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) are tabulated once per workgroup in LDS for
 //     tf <= 8 and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84); anything outside
 //     the table is computed directly;
@@ -634,7 +649,7 @@ constexpr uint32_t kWaveMatchBuf = 256;  // matches buffered per wave between en
 constexpr int kScoreUnroll = 2;          // matches in flight per lane in phase C
 
 struct WaveOffsets {
-  uint32_t prog, leaf, table, scratch, mbuf, tk_keys, tk_docs, misc, total;
+  uint32_t prog, leaf, table, scratch, park, mbuf, tk_keys, tk_docs, misc, total;
 };
 
 __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
@@ -645,6 +660,7 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
   o.misc = at;     at += 64;
   o.table = at;    at += p.max_score * kTableTf * p.table_dl * 8;
   o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
+  o.park = at;     at += kWavesPerBlock * p.max_score * 64 * 12;  // per scored operand: 64 x u64 word + 64 x packed u32 prefix
   o.mbuf = at;     at += kWavesPerBlock * kWaveMatchBuf * 2;
   o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
   o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
@@ -693,11 +709,13 @@ __device__ __forceinline__ void wave_scatter_segment(const uint32_t* __restrict_
   }
 }
 
-// This lane's four 64-bit words (256 doc slots) of one operand for `tile`.
+// This lane's four 64-bit words (256 doc slots) of one operand for `tile`; for scored posting-list operands
+// *seg_rel = list-relative index of the tile's first posting (the rank base of the tf column).
 __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
                                                    uint32_t tile, uint64_t tile_first, uint64_t* scratch,
-                                                   uint64_t (&w)[4]) {
+                                                   uint64_t (&w)[4], uint32_t* seg_rel) {
   const uint32_t lane = lane_id();
+  *seg_rel = 0;
   if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap) {
     const uint64_t* rowp = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
                            (static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + lane * 4;
@@ -707,6 +725,8 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
     w[1] = (static_cast<uint64_t>(v0.w) << 32) | v0.z;
     w[2] = (static_cast<uint64_t>(v1.y) << 32) | v1.x;
     w[3] = (static_cast<uint64_t>(v1.w) << 32) | v1.z;
+    if (lf.kind == kLeafGramBitmap && lf.score_slot != kNoSlot)
+      *seg_rel = ix.tile_off[static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1) + tile];
   } else if (lf.kind == kLeafRange) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -730,6 +750,7 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
         a = lower_bound_u32(ids, l0, l1, tile_first);
         b = lower_bound_u32(ids, a, l1, tile_first + kTileDocs);
       }
+      *seg_rel = static_cast<uint32_t>(a - l0);
     } else {
       ids = bt.explicit_pool;
       a = lower_bound_u32(ids, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
@@ -756,6 +777,8 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
   uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
+  // parked strips of this wave: operand i -> 128 x u32 half-words, then 64 x u32 packed prefixes (lo | hi << 16)
+  uint32_t* const park = reinterpret_cast<uint32_t*>(smem + wo.park) + static_cast<size_t>(wave) * plan.max_score * 192;
 
   const DevItem it = bt.items[blockIdx.x];
   const uint32_t qi = it.query;
@@ -798,23 +821,16 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   // per scored term: tf column start, idf (for contributions outside the table), bitmap row and skip row
   uint64_t tf_base[kWaveScoreSlots];
   double idf_s[kWaveScoreSlots];
-  uint32_t brow[kWaveScoreSlots], trow[kWaveScoreSlots];
 #pragma unroll
   for (int i = 0; i < kWaveScoreSlots; ++i) {
     tf_base[i] = 0;
     idf_s[i] = 0.0;
-    brow[i] = 0;
-    trow[i] = 0;
     if (static_cast<uint32_t>(i) < q.n_score) {
       const DevScoreTerm st = bt.score_terms[q.score_begin + i];
-      const DevLeaf lf = leaf[st.leaf];
-      tf_base[i] = ix.offsets[lf.a];
+      tf_base[i] = ix.offsets[leaf[st.leaf].a];
       idf_s[i] = st.idf;
-      brow[i] = lf.b;
-      trow[i] = lf.row;
     }
   }
-  const uint32_t* const bm32 = reinterpret_cast<const uint32_t*>(ix.gram_bitmaps);
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
   const uint32_t tile_begin = it.tile_begin;
@@ -826,7 +842,17 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
     wave_topk_refresh_gbound(tk);
     uint64_t acc[4] = {0, 0, 0, 0};
 
-    // ---- phase A: program ---------------------------------------------------------------------------------------
+    // ---- phase A: program; the words of scored operands stay in registers -----------------------------------------
+    uint64_t sw[kWaveScoreSlots][4];
+    uint32_t srel[kWaveScoreSlots];   // postings of the scored operand inside this tile before this lane's words
+    uint64_t tf_tile[kWaveScoreSlots];  // tf column position of the tile's first posting
+#pragma unroll
+    for (int i = 0; i < kWaveScoreSlots; ++i) {
+      srel[i] = 0;
+      tf_tile[i] = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sw[i][k] = 0;
+    }
     for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
       const uint32_t ins = prog[pc];
       const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
@@ -838,8 +864,10 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
         cnt3 += (arg & 8u) ? pcnt : 0;
         continue;
       }
+      const DevLeaf lf = leaf[arg];
       uint64_t w[4];
-      wave_fetch_operand(ix, bt, leaf[arg], tile, tile_first, scratch, w);
+      uint32_t seg_rel;
+      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (op == kOpLoad) acc[k] = w[k];
@@ -847,119 +875,132 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
         else if (op == kOpOr) acc[k] |= w[k];
         else if (op == kOpAndNot) acc[k] &= ~w[k];
       }
+      if (lf.score_slot != kNoSlot) {
+        uint32_t tot;
+        const uint32_t rel =
+            wave_excl_scan_total(__popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]), &tot);
+#pragma unroll
+        for (int i = 0; i < kWaveScoreSlots; ++i) {
+          if (lf.score_slot == static_cast<uint32_t>(i)) {
+            srel[i] = rel;
+            tf_tile[i] = tf_base[i] + seg_rel;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sw[i][k] = w[k];
+          }
+        }
+      }
     }
     cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
     if (bt.debug_skip & 2u) continue;
 
-    // tf column position of the tile's first posting, and the half-word row base, per scored term (wave-uniform)
-    uint64_t tf_tile[kWaveScoreSlots];
-    uint64_t hw_base[kWaveScoreSlots];
+    // ---- four steps, one per owned word index k ----------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < kWaveScoreSlots; ++i) {
-      tf_tile[i] = 0;
-      hw_base[i] = 0;
-      if (static_cast<uint32_t>(i) < q.n_score) {
-        tf_tile[i] = tf_base[i] + ix.tile_off[static_cast<uint64_t>(trow[i]) * (ix.n_tiles + 1) + tile];
-        hw_base[i] = (static_cast<uint64_t>(brow[i]) * ix.n_tiles + tile) * (2 * kWordsPerTile);
+    for (int k = 0; k < 4; ++k) {
+      if (__ballot(acc[k] != 0) == 0) {  // wave-uniform: no match in this step; only advance the prefixes
+#pragma unroll
+        for (int i = 0; i < kWaveScoreSlots; ++i) srel[i] += __popcll(sw[i][k]);
+        continue;
       }
-    }
-
-    // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc (every lane resumes where it stopped), C scores.
-    for (;;) {
-      const uint32_t left = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
-      uint32_t n_left;
-      const uint32_t my_first = wave_excl_scan_total(left, &n_left);
-      if (n_left == 0) break;  // wave-uniform
-      // ---- phase B: this lane's next matches, in doc order, into the wave's match buffer ----------------------------
-      {
-        uint32_t r = my_first;
+      // park word k of every scored operand with the postings that precede its low / high half inside the tile
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint32_t base = lane * 256 + k * 64;
+      for (int i = 0; i < kWaveScoreSlots; ++i) {
+        if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
+          const uint32_t lo = static_cast<uint32_t>(sw[i][k]), hi = static_cast<uint32_t>(sw[i][k] >> 32);
+          uint32_t* strip = park + i * 192;
+          strip[lane * 2] = lo;
+          strip[lane * 2 + 1] = hi;
+          const uint32_t plo = srel[i], phi = srel[i] + __popc(lo);
+          strip[128 + lane] = plo | (phi << 16);
+          srel[i] = phi + __popc(hi);
+        }
+      }
+      // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc[k] (a lane resumes where it stopped), C scores.
+      for (;;) {
+        uint32_t n_left;
+        const uint32_t my_first = wave_excl_scan_total(__popcll(acc[k]), &n_left);
+        if (n_left == 0) break;  // wave-uniform
+        // ---- phase B: (owner lane, bit) of this lane's next matches into the wave's match buffer --------------------
+        {
+          uint32_t r = my_first;
           while (acc[k] != 0 && r < kWaveMatchBuf) {
             const uint32_t bit = __builtin_ctzll(acc[k]);
             acc[k] &= acc[k] - 1;
-            mbuf[r] = static_cast<uint16_t>(base + bit);
+            mbuf[r] = static_cast<uint16_t>((lane << 6) | bit);
             ++r;
           }
         }
-      }
-      wave_lds_sync();
-      const uint32_t nm = min(kWaveMatchBuf, n_left);
-      // ---- phase C: score them, one match per lane, kScoreUnroll in flight --------------------------------------------
-      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
-        bool valid[kScoreUnroll];
-        uint32_t slot[kScoreUnroll], dli[kScoreUnroll], mask[kScoreUnroll];
-        uint32_t wbits[kScoreUnroll][kWaveScoreSlots], pre[kScoreUnroll][kWaveScoreSlots];
-        uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
-        // stage 1: doc_len, bitmap half-word and rank directory entry of every match x term
+        wave_lds_sync();
+        const uint32_t nm = min(kWaveMatchBuf, n_left);
+        // ---- phase C: score them, one match per lane, kScoreUnroll in flight ----------------------------------------
+        for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
+          bool valid[kScoreUnroll];
+          uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
+          uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
+          // all gathers of the iteration first: (tf, doc_len) of the first scored term's posting, tf of the others
 #pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
-          valid[m] = false;
-          slot[m] = 0;
-          dli[m] = 0;
-          mask[m] = 0;
+          for (int m = 0; m < kScoreUnroll; ++m) {
+            valid[m] = false;
+            slot[m] = 0;
+            dli[m] = 0;
 #pragma unroll
-          for (int i = 0; i < kWaveScoreSlots; ++i) {
-            wbits[m][i] = 0;
-            pre[m][i] = 0;
-            tfv[m][i] = 0;
+            for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
+            if (j0 + m * 64 < nm) {  // wave-uniform
+              const uint32_t j = j0 + m * 64 + lane;
+              valid[m] = j < nm;
+              if (valid[m]) {
+                const uint32_t e = mbuf[j];
+                const uint32_t owner = e >> 6, bit = e & 63u;
+                const uint32_t hw = owner * 2 + (bit >> 5), mask = 1u << (bit & 31u);
+                slot[m] = tile * kTileDocs + owner * 256 + k * 64 + bit;
+                uint32_t packed = 0xFF00u;  // "doc length not known yet"
+#pragma unroll
+                for (int i = 0; i < kWaveScoreSlots; ++i) {
+                  if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
+                    const uint32_t* strip = park + i * 192;
+                    const uint32_t wbits = strip[hw];
+                    if (wbits & mask) {
+                      const uint32_t pp = strip[128 + owner];
+                      const uint32_t rank = ((bit >> 5) ? pp >> 16 : pp & 0xFFFFu) + __popc(wbits & (mask - 1u));
+                      if (i == 0) {
+                        packed = ix.tfdl[tf_tile[0] + rank];
+                        tfv[m][0] = packed & 0xFFu;
+                      } else {
+                        tfv[m][i] = ix.tf[tf_tile[i] + rank];
+                      }
+                    }
+                  }
+                }
+                dli[m] = packed >> 8;
+                if (dli[m] == 255u) dli[m] = ix.doc_len[slot[m]];  // saturated, or the doc lacks the first term
+              }
+            }
           }
-          if (j0 + m * 64 < nm) {  // wave-uniform
-            const uint32_t j = j0 + m * 64 + lane;
-            valid[m] = j < nm;
-            if (valid[m]) {
-              const uint32_t d = mbuf[j];
-              const uint32_t half = d >> 5;
-              mask[m] = 1u << (d & 31);
-              slot[m] = tile * kTileDocs + d;
-              dli[m] = ix.doc_len[slot[m]];
+          // contributions and top-k
+#pragma unroll
+          for (int m = 0; m < kScoreUnroll; ++m) {
+            if (j0 + m * 64 < nm) {  // wave-uniform
+              double score = 0.0;
 #pragma unroll
               for (int i = 0; i < kWaveScoreSlots; ++i) {
-                if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-                  wbits[m][i] = bm32[hw_base[i] + half];
-                  pre[m][i] = ix.gram_rank[hw_base[i] + half];
+                if (tfv[m][i] != 0) {
+                  if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
+                    score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
+                  } else {  // bm25_scorer.cpp:80-84, same operation order as the table
+                    const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
+                    const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+                    const double numerator = tf * q.k1_plus_1;
+                    const double denominator = tf + q.k1 * length_norm;
+                    score += idf_s[i] * numerator / denominator;
+                  }
                 }
               }
+              const uint32_t doc = ix.first_doc_id + slot[m];
+              wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
             }
           }
         }
-        // stage 2: tf of every term the doc contains
-#pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
-#pragma unroll
-          for (int i = 0; i < kWaveScoreSlots; ++i) {
-            if (wbits[m][i] & mask[m]) {
-              const uint32_t rank = pre[m][i] + __popc(wbits[m][i] & (mask[m] - 1u));
-              tfv[m][i] = ix.tf[tf_tile[i] + rank];
-            }
-          }
-        }
-        // stage 3: contributions and top-k
-#pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
-          if (j0 + m * 64 < nm) {  // wave-uniform
-            double score = 0.0;
-#pragma unroll
-            for (int i = 0; i < kWaveScoreSlots; ++i) {
-              if (tfv[m][i] != 0) {
-                if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
-                  score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
-                } else {  // bm25_scorer.cpp:80-84, same operation order as the table
-                  const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
-                  const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-                  const double numerator = tf * q.k1_plus_1;
-                  const double denominator = tf + q.k1 * length_norm;
-                  score += idf_s[i] * numerator / denominator;
-                }
-              }
-            }
-            const uint32_t doc = ix.first_doc_id + slot[m];
-            wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
-          }
-        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
     }
   }
 
@@ -1281,6 +1322,17 @@ int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const ui
   const uint32_t blocks = static_cast<uint32_t>((total + 255) / 256);
   hipLaunchKernelGGL(build_tile_off_kernel, dim3(blocks), dim3(256), 0, s, offsets, docids, rows_gram, n_rows,
                      n_tiles, first_doc_id, tile_off);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* doc_len, uint64_t n_postings,
+                    uint32_t first_doc_id, uint16_t* out, hipStream_t s) {
+  if (n_postings == 0) return 0;
+  const uint64_t blocks = (n_postings + 255) / 256;
+  if (blocks > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(build_tfdl_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, s, docids, tf, doc_len,
+                     n_postings, first_doc_id, out);
   MGX_KCHECK();
   return 0;
 }
