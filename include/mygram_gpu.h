@@ -118,7 +118,8 @@ typedef struct mgx_index_desc {
   const uint32_t* doc_len; /* host, n_docs; NULL => BM25 scoring unavailable */
   /* posting lists at least this dense (|L| / n_docs) are ALSO kept as precomputed bitmaps in HBM and read in that
    * form by the set-algebra kernels (what Roaring bitset containers are to the reference, posting_list.cpp:800-834).
-   * 0 => default (1/32: the bitmap is then never larger than the u32 list); >= 2 => disabled. */
+   * 0 => default (1/256: at most 8x the bytes of the u32 list, bought for latency: bitmap operands need no scatter
+   * and BM25 runs on the wave-autonomous kernel); >= 2 => disabled. */
   double dense_threshold;
 } mgx_index_desc;
 

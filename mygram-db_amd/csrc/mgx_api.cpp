@@ -104,7 +104,7 @@ struct mgx_index {
   hipStream_t stream = nullptr;
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
-  DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_gram_rank, d_filter_bitmaps;
+  DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -112,6 +112,7 @@ struct mgx_index {
   uint64_t n_grams = 0;
   bool can_score = false;
   uint64_t words_per_row = 0;  // n_tiles * 256
+  uint64_t filter_row_stride = 0;  // words; words_per_row + padding
 };
 
 extern "C" {
@@ -212,7 +213,7 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   }
 
   // which grams get a skip row / a dense bitmap
-  double dense_thr = d->dense_threshold == 0.0 ? 1.0 / 32.0 : d->dense_threshold;
+  double dense_thr = d->dense_threshold == 0.0 ? 1.0 / 256.0 : d->dense_threshold;
   const uint64_t skip_min = std::max<uint64_t>(64, static_cast<uint64_t>(n_tiles) + 1);
   idx->h_skip_row.assign(G, mgx::kNoRow);
   idx->h_bm_row.assign(G, mgx::kNoRow);
@@ -250,11 +251,10 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
     MGX_HIP(idx->d_gram_bitmaps.Alloc(bm_grams.size() * idx->words_per_row * sizeof(uint64_t)));
     MGX_HIP(hipMemsetAsync(idx->d_gram_bitmaps.p, 0, idx->d_gram_bitmaps.bytes, idx->stream));
     MGX_LAUNCH(mgx::LaunchBuildBitmaps(idx->d_docids.as<uint32_t>(), d_lo.as<uint64_t>(), d_hi.as<uint64_t>(),
-                                       static_cast<uint32_t>(bm_grams.size()), d->first_doc_id, idx->words_per_row,
-                                       idx->d_gram_bitmaps.as<uint64_t>(), idx->stream));
-    MGX_HIP(idx->d_gram_rank.Alloc(bm_grams.size() * idx->words_per_row * 2 * sizeof(uint16_t)));
-    MGX_LAUNCH(mgx::LaunchBuildRankDir(idx->d_gram_bitmaps.as<uint64_t>(), static_cast<uint32_t>(bm_grams.size()),
-                                       n_tiles, idx->d_gram_rank.as<uint16_t>(), idx->stream));
+                                       static_cast<uint32_t>(bm_grams.size()), d->first_doc_id, 0,
+                                       /*tile_stride=*/bm_grams.size() * mgx::kWordsPerTile,
+                                       /*row_stride=*/mgx::kWordsPerTile, idx->d_gram_bitmaps.as<uint64_t>(),
+                                       idx->stream));
     MGX_HIP(hipStreamSynchronize(idx->stream));
   }
 
@@ -267,7 +267,11 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.skip_row = idx->d_skip_row.as<uint32_t>();
   v.tile_off = idx->d_tile_off.as<uint32_t>();
   v.gram_bitmaps = idx->d_gram_bitmaps.as<uint64_t>();
-  v.gram_rank = idx->d_gram_rank.as<uint16_t>();
+  v.gb_tile_stride = bm_grams.size() * mgx::kWordsPerTile;
+  v.gb_row_stride = mgx::kWordsPerTile;
+  idx->filter_row_stride = idx->words_per_row + 32 * ((n_tiles % 2) ? 1 : 3);  // 256 B / 768 B of padding
+  v.fb_tile_stride = mgx::kWordsPerTile;
+  v.fb_row_stride = idx->filter_row_stride;
   v.filter_bitmaps = nullptr;
   v.first_doc_id = d->first_doc_id;
   v.n_docs = static_cast<uint32_t>(n_docs);
@@ -312,8 +316,7 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (out) *out = 0;
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_tfdl.bytes + idx->d_doc_len.bytes +
-         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_gram_rank.bytes +
-         idx->d_filter_bitmaps.bytes;
+         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes;
   return MGX_OK;
 }
 
@@ -330,18 +333,18 @@ int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t
   if (idx->n_filter_rows == idx->filter_cap_rows) {
     const uint32_t ncap = idx->filter_cap_rows ? idx->filter_cap_rows * 2 : 8;
     DevBuf nb;
-    MGX_HIP(nb.Alloc(static_cast<size_t>(ncap) * idx->words_per_row * sizeof(uint64_t)));
+    MGX_HIP(nb.Alloc(static_cast<size_t>(ncap) * idx->filter_row_stride * sizeof(uint64_t)));
     if (idx->n_filter_rows)
       MGX_HIP(hipMemcpy(nb.p, idx->d_filter_bitmaps.p,
-                        static_cast<size_t>(idx->n_filter_rows) * idx->words_per_row * sizeof(uint64_t),
+                        static_cast<size_t>(idx->n_filter_rows) * idx->filter_row_stride * sizeof(uint64_t),
                         hipMemcpyDeviceToDevice));
     idx->d_filter_bitmaps = std::move(nb);
     idx->filter_cap_rows = ncap;
     idx->dev.filter_bitmaps = idx->d_filter_bitmaps.as<uint64_t>();
   }
   const uint32_t row = idx->n_filter_rows;
-  uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->words_per_row;
-  MGX_HIP(hipMemsetAsync(dst, 0, idx->words_per_row * sizeof(uint64_t), idx->stream));
+  uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->filter_row_stride;
+  MGX_HIP(hipMemsetAsync(dst, 0, idx->filter_row_stride * sizeof(uint64_t), idx->stream));
   if (n) {
     DevBuf d_ids, d_lo, d_hi;
     MGX_HIP(mgx::Upload(d_ids, docids, n));
@@ -349,7 +352,9 @@ int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t
     MGX_HIP(mgx::Upload(d_lo, &lo, 1));
     MGX_HIP(mgx::Upload(d_hi, &hi, 1));
     MGX_LAUNCH(mgx::LaunchBuildBitmaps(d_ids.as<uint32_t>(), d_lo.as<uint64_t>(), d_hi.as<uint64_t>(), 1,
-                                       idx->dev.first_doc_id, idx->words_per_row, dst, idx->stream));
+                                       idx->dev.first_doc_id, row, /*tile_stride=*/mgx::kWordsPerTile,
+                                       /*row_stride=*/idx->filter_row_stride, idx->d_filter_bitmaps.as<uint64_t>(),
+                                       idx->stream));
     MGX_HIP(hipStreamSynchronize(idx->stream));
   } else {
     MGX_HIP(hipStreamSynchronize(idx->stream));
@@ -656,6 +661,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = b->specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
+      // the wave kernel re-reads the words of scored operands from their dense (bitmap) form
+      for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
       if (!ok) continue;
       on_wave[i] = 1;
       for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;
@@ -692,7 +699,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 96.0;
       const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
-      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of 8 waves
+      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
       list_begin[i] = static_cast<uint32_t>(items.size());
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), 0};

@@ -96,9 +96,13 @@ struct DevIndex {
   const uint32_t* doc_len;
   const uint32_t* skip_row;   // [G] row in tile_off, or kNoRow
   const uint32_t* tile_off;   // [rows][n_tiles+1]
+  // bitmap word (tile, row, w) lives at base[tile*tile_stride + row*row_stride + w]. Gram bitmaps are TILE-major
+  // (row_stride = 256): workgroups that walk the same doc range for different queries then read one contiguous
+  // region instead of addresses that differ by a multiple of the row size, which would pile onto few HBM channels.
   const uint64_t* gram_bitmaps;
-  const uint16_t* gram_rank;  // [bitmap rows][n_tiles*512]: postings of the row inside the tile before each 32-bit half-word
-  const uint64_t* filter_bitmaps;
+  uint64_t gb_tile_stride, gb_row_stride;
+  const uint64_t* filter_bitmaps;  // row-major (rows are appended at run time), rows padded off power-of-two strides
+  uint64_t fb_tile_stride, fb_row_stride;
   uint32_t first_doc_id;
   uint32_t n_docs;
   uint32_t n_tiles;

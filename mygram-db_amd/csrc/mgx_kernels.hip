@@ -131,15 +131,17 @@ __global__ void build_tile_off_kernel(const uint64_t* __restrict__ offsets, cons
 
 // One workgroup-strided pass per row: bitmap[row][slot] = 1 for every posting of the row's doc list.
 __global__ void build_bitmap_kernel(const uint32_t* __restrict__ docids, const uint64_t* __restrict__ row_lo,
-                                    const uint64_t* __restrict__ row_hi, uint32_t first_doc_id,
-                                    uint64_t words_per_row, unsigned long long* __restrict__ bitmaps) {
-  uint32_t row = blockIdx.y;
-  uint64_t lo = row_lo[row], hi = row_hi[row];
-  unsigned long long* bm = bitmaps + static_cast<uint64_t>(row) * words_per_row;
+                                    const uint64_t* __restrict__ row_hi, uint32_t first_doc_id, uint32_t row0,
+                                    uint64_t tile_stride, uint64_t row_stride,
+                                    unsigned long long* __restrict__ bitmaps) {
+  const uint32_t row = blockIdx.y;
+  const uint64_t lo = row_lo[row], hi = row_hi[row];
+  unsigned long long* bm = bitmaps + static_cast<uint64_t>(row0 + row) * row_stride;
   for (uint64_t p = lo + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < hi;
        p += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
-    uint32_t slot = docids[p] - first_doc_id;
-    atomicOr(&bm[slot >> 6], 1ull << (slot & 63));
+    const uint32_t slot = docids[p] - first_doc_id;
+    atomicOr(&bm[static_cast<uint64_t>(slot >> kTileShift) * tile_stride + ((slot >> 6) & (kWordsPerTile - 1))],
+             1ull << (slot & 63));
   }
 }
 
@@ -151,26 +153,6 @@ __global__ void build_tfdl_kernel(const uint32_t* __restrict__ docids, const uin
   if (p >= n_postings) return;
   const uint32_t dl = doc_len[docids[p] - first_doc_id];
   out[p] = static_cast<uint16_t>(tf[p] | ((dl < 255u ? dl : 255u) << 8));
-}
-
-// gram_rank[row][tile*512 + h] = set bits of the row's bitmap inside `tile` before 32-bit half-word h.
-// One 256-thread workgroup per (tile, row); thread t owns 64-bit word t.
-__global__ __launch_bounds__(kBlock) void build_rank_dir_kernel(const uint64_t* __restrict__ bitmaps, uint32_t n_tiles,
-                                                                uint16_t* __restrict__ rank) {
-  __shared__ uint32_t s_w[4];
-  const uint32_t tile = blockIdx.x, row = blockIdx.y;
-  const uint64_t base = (static_cast<uint64_t>(row) * n_tiles + tile) * kWordsPerTile;
-  const uint64_t w = bitmaps[base + threadIdx.x];
-  const uint32_t lo = __popc(static_cast<uint32_t>(w)), hi = __popc(static_cast<uint32_t>(w >> 32));
-  const uint32_t inc = wave_incl_scan(lo + hi);
-  if (lane_id() == 63) s_w[wave_id()] = inc;
-  __syncthreads();
-  uint32_t off = 0;
-  for (int i = 0; i < wave_id(); ++i) off += s_w[i];
-  const uint32_t ex = off + inc - (lo + hi);
-  uint16_t* o = rank + base * 2 + threadIdx.x * 2;
-  o[0] = static_cast<uint16_t>(ex);
-  o[1] = static_cast<uint16_t>(ex + lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -376,9 +358,9 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       const DevLeaf lf = leaf[l];
       uint64_t w = 0;
       if (lf.kind == kLeafGramBitmap) {
-        w = ix.gram_bitmaps[(static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + tid];
+        w = ix.gram_bitmaps[tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + tid];
       } else if (lf.kind == kLeafFilterBitmap) {
-        w = ix.filter_bitmaps[(static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + tid];
+        w = ix.filter_bitmaps[tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + tid];
       } else if (lf.kind == kLeafRange) {
         // slots [a, b) of the shard; this thread's word covers slots [s0, s0+64)
         const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + static_cast<uint64_t>(tid) * 64;
@@ -717,8 +699,9 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
   const uint32_t lane = lane_id();
   *seg_rel = 0;
   if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap) {
-    const uint64_t* rowp = (lf.kind == kLeafGramBitmap ? ix.gram_bitmaps : ix.filter_bitmaps) +
-                           (static_cast<uint64_t>(lf.b) * ix.n_tiles + tile) * kWordsPerTile + lane * 4;
+    const uint64_t* rowp = lf.kind == kLeafGramBitmap
+                               ? ix.gram_bitmaps + tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + lane * 4
+                               : ix.filter_bitmaps + tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + lane * 4;
     const uint4 v0 = *reinterpret_cast<const uint4*>(rowp);
     const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + 2);
     w[0] = (static_cast<uint64_t>(v0.y) << 32) | v0.x;
@@ -818,18 +801,16 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   }
   __syncthreads();
 
-  // per scored term: tf column start, idf (for contributions outside the table), bitmap row and skip row
-  uint64_t tf_base[kWaveScoreSlots];
-  double idf_s[kWaveScoreSlots];
+  // per scored term: where its tf column starts (kept in LDS: it is needed once per tile, registers are scarce)
+  uint64_t* const tf_base = reinterpret_cast<uint64_t*>(misc + 8);
+  if (tid < q.n_score) tf_base[tid] = ix.offsets[bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf].a];
+  __syncthreads();
+  const uint64_t* sbits[kWaveScoreSlots];  // bitmap row base of every scored operand (all in dense form here)
 #pragma unroll
   for (int i = 0; i < kWaveScoreSlots; ++i) {
-    tf_base[i] = 0;
-    idf_s[i] = 0.0;
-    if (static_cast<uint32_t>(i) < q.n_score) {
-      const DevScoreTerm st = bt.score_terms[q.score_begin + i];
-      tf_base[i] = ix.offsets[leaf[st.leaf].a];
-      idf_s[i] = st.idf;
-    }
+    sbits[i] = ix.gram_bitmaps;
+    if (static_cast<uint32_t>(i) < q.n_score)
+      sbits[i] = ix.gram_bitmaps + leaf[bt.score_terms[q.score_begin + i].leaf].b * ix.gb_row_stride;
   }
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
@@ -842,16 +823,13 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
     wave_topk_refresh_gbound(tk);
     uint64_t acc[4] = {0, 0, 0, 0};
 
-    // ---- phase A: program; the words of scored operands stay in registers -----------------------------------------
-    uint64_t sw[kWaveScoreSlots][4];
+    // ---- phase A: program ------------------------------------------------------------------------------------------
     uint32_t srel[kWaveScoreSlots];   // postings of the scored operand inside this tile before this lane's words
     uint64_t tf_tile[kWaveScoreSlots];  // tf column position of the tile's first posting
 #pragma unroll
     for (int i = 0; i < kWaveScoreSlots; ++i) {
       srel[i] = 0;
       tf_tile[i] = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) sw[i][k] = 0;
     }
     for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
       const uint32_t ins = prog[pc];
@@ -884,8 +862,6 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
           if (lf.score_slot == static_cast<uint32_t>(i)) {
             srel[i] = rel;
             tf_tile[i] = tf_base[i] + seg_rel;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sw[i][k] = w[k];
           }
         }
       }
@@ -896,16 +872,25 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
     // ---- four steps, one per owned word index k ----------------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // word k of every scored operand again (8 B per lane; the lines were streamed by phase A a moment ago): holding
+      // 4 words x 3 operands in registers across the whole tile costs more (spills) than these L1/L2 hits
+      uint2 swk[kWaveScoreSlots];
+#pragma unroll
+      for (int i = 0; i < kWaveScoreSlots; ++i) {
+        swk[i] = make_uint2(0, 0);
+        if (static_cast<uint32_t>(i) < q.n_score)  // wave-uniform
+          swk[i] = *reinterpret_cast<const uint2*>(sbits[i] + tile * ix.gb_tile_stride + lane * 4 + k);
+      }
       if (__ballot(acc[k] != 0) == 0) {  // wave-uniform: no match in this step; only advance the prefixes
 #pragma unroll
-        for (int i = 0; i < kWaveScoreSlots; ++i) srel[i] += __popcll(sw[i][k]);
+        for (int i = 0; i < kWaveScoreSlots; ++i) srel[i] += __popc(swk[i].x) + __popc(swk[i].y);
         continue;
       }
       // park word k of every scored operand with the postings that precede its low / high half inside the tile
 #pragma unroll
       for (int i = 0; i < kWaveScoreSlots; ++i) {
         if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-          const uint32_t lo = static_cast<uint32_t>(sw[i][k]), hi = static_cast<uint32_t>(sw[i][k] >> 32);
+          const uint32_t lo = swk[i].x, hi = swk[i].y;
           uint32_t* strip = park + i * 192;
           strip[lane * 2] = lo;
           strip[lane * 2 + 1] = hi;
@@ -990,7 +975,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
                     const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
                     const double numerator = tf * q.k1_plus_1;
                     const double denominator = tf + q.k1 * length_norm;
-                    score += idf_s[i] * numerator / denominator;
+                    score += bt.score_terms[q.score_begin + i].idf * numerator / denominator;
                   }
                 }
               }
@@ -1337,26 +1322,15 @@ int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* d
   return 0;
 }
 
-int LaunchBuildRankDir(const uint64_t* bitmaps, uint32_t n_rows, uint32_t n_tiles, uint16_t* rank, hipStream_t s) {
-  if (n_rows == 0 || n_tiles == 0) return 0;
-  for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
-    const uint32_t nr = n_rows - r0 < 32768 ? n_rows - r0 : 32768;
-    hipLaunchKernelGGL(build_rank_dir_kernel, dim3(n_tiles, nr), dim3(kBlock), 0, s,
-                       bitmaps + static_cast<uint64_t>(r0) * n_tiles * kWordsPerTile, n_tiles,
-                       rank + static_cast<uint64_t>(r0) * n_tiles * kWordsPerTile * 2);
-    MGX_KCHECK();
-  }
-  return 0;
-}
-
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
-                       uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s) {
+                       uint32_t first_doc_id, uint32_t first_row, uint64_t tile_stride, uint64_t row_stride,
+                       uint64_t* bitmaps, hipStream_t s) {
   if (n_rows == 0) return 0;
   for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
     const uint32_t nr = n_rows - r0 < 32768 ? n_rows - r0 : 32768;
     hipLaunchKernelGGL(build_bitmap_kernel, dim3(64, nr), dim3(256), 0, s, docids, row_lo + r0, row_hi + r0,
-                       first_doc_id, words_per_row,
-                       reinterpret_cast<unsigned long long*>(bitmaps + static_cast<uint64_t>(r0) * words_per_row));
+                       first_doc_id, first_row + r0, tile_stride, row_stride,
+                       reinterpret_cast<unsigned long long*>(bitmaps));
     MGX_KCHECK();
   }
   return 0;

@@ -9,10 +9,10 @@ namespace mgx {
 int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const uint32_t* rows_gram, uint32_t n_rows,
                        uint32_t n_tiles, uint32_t first_doc_id, uint32_t* tile_off, hipStream_t s);
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
-                       uint32_t first_doc_id, uint64_t words_per_row, uint64_t* bitmaps, hipStream_t s);
+                       uint32_t first_doc_id, uint32_t first_row, uint64_t tile_stride, uint64_t row_stride,
+                       uint64_t* bitmaps, hipStream_t s);
 int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* doc_len, uint64_t n_postings,
                     uint32_t first_doc_id, uint16_t* out, hipStream_t s);
-int LaunchBuildRankDir(const uint64_t* bitmaps, uint32_t n_rows, uint32_t n_tiles, uint16_t* rank, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
