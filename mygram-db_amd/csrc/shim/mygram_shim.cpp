@@ -1,0 +1,591 @@
+// mygram_shim.cpp — host C++17 implementation of mygram_shim.hpp over the C ABI of libmygram_gpu.so.
+// Host-side rules are cited from the reference (paths relative to its tree); all posting work goes to the device.
+#include "mygram_shim.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <mutex>
+
+namespace mygramdb {
+
+using mygram::utils::Error;
+using mygram::utils::ErrorCode;
+using mygram::utils::Expected;
+using mygram::utils::MakeError;
+using mygram::utils::MakeUnexpected;
+
+namespace {
+
+// ---- src/utils/string_utils.cpp: UTF-8 decode (:94-164), IsCJKIdeograph (:441-448), n-gram windows (:382-509) -----
+
+int ParseUtf8(const unsigned char* d, size_t avail, uint32_t* cp) {
+  const unsigned char b0 = d[0];
+  if (b0 < 0x80) {
+    *cp = b0;
+    return 1;
+  }
+  if ((b0 & 0xE0) == 0xC0) {
+    if (b0 < 0xC2 || avail < 2 || (d[1] & 0xC0) != 0x80) return -1;
+    *cp = ((b0 & 0x1Fu) << 6) | (d[1] & 0x3Fu);
+    return 2;
+  }
+  if ((b0 & 0xF0) == 0xE0) {
+    if (avail < 3 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80) return -1;
+    const uint32_t c = ((b0 & 0x0Fu) << 12) | ((d[1] & 0x3Fu) << 6) | (d[2] & 0x3Fu);
+    if (c < 0x800 || (c >= 0xD800 && c <= 0xDFFF)) return -1;
+    *cp = c;
+    return 3;
+  }
+  if ((b0 & 0xF8) == 0xF0) {
+    if (b0 > 0xF4 || avail < 4 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80 || (d[3] & 0xC0) != 0x80) return -1;
+    const uint32_t c = ((b0 & 0x07u) << 18) | ((d[1] & 0x3Fu) << 12) | ((d[2] & 0x3Fu) << 6) | (d[3] & 0x3Fu);
+    if (c < 0x10000 || c > 0x10FFFF) return -1;
+    *cp = c;
+    return 4;
+  }
+  return -1;
+}
+
+struct CodePoints {
+  std::vector<uint32_t> cp;
+  std::vector<std::pair<uint32_t, uint32_t>> span;  // byte [begin, end) of every decoded code point
+};
+
+CodePoints Decode(std::string_view text) {
+  CodePoints out;
+  const auto* d = reinterpret_cast<const unsigned char*>(text.data());
+  size_t i = 0;
+  while (i < text.size()) {
+    uint32_t c = 0;
+    const int k = ParseUtf8(d + i, text.size() - i, &c);
+    if (k > 0) {
+      out.cp.push_back(c);
+      out.span.emplace_back(static_cast<uint32_t>(i), static_cast<uint32_t>(i + k));
+      i += static_cast<size_t>(k);
+    } else {
+      ++i;  // invalid byte skipped (Utf8ToCodepoints :199-218)
+    }
+  }
+  return out;
+}
+
+bool IsCjkIdeograph(uint32_t c) {
+  return (c >= 0x4E00 && c <= 0x9FFF) || (c >= 0x3400 && c <= 0x4DBF) || (c >= 0x20000 && c <= 0x2A6DF) ||
+         (c >= 0x2A700 && c <= 0x2B73F) || (c >= 0x2B740 && c <= 0x2B81F) || (c >= 0xF900 && c <= 0xFAFF);
+}
+
+// bytes of code points [a, b): contiguous in the source when no invalid byte sits between them; re-assembled from the
+// decoded spans otherwise (CodepointsToUtf8 :241-272 re-encodes, which is the same bytes for valid input)
+std::string Window(std::string_view text, const CodePoints& cps, size_t a, size_t b) {
+  std::string s;
+  for (size_t i = a; i < b; ++i) s.append(text.substr(cps.span[i].first, cps.span[i].second - cps.span[i].first));
+  return s;
+}
+
+std::vector<std::string> GenerateNgrams(std::string_view text, int n) {  // :382-423
+  std::vector<std::string> out;
+  const CodePoints cps = Decode(text);
+  if (cps.cp.empty() || n <= 0 || cps.cp.size() < static_cast<size_t>(n)) return out;
+  for (size_t i = 0; i + static_cast<size_t>(n) <= cps.cp.size(); ++i) out.push_back(Window(text, cps, i, i + n));
+  return out;
+}
+
+std::vector<std::string> GenerateHybridNgrams(std::string_view text, int ascii_n, int kanji_n, bool cross) {  // :452-509
+  std::vector<std::string> out;
+  if (ascii_n <= 0 || kanji_n <= 0) return out;
+  const CodePoints cps = Decode(text);
+  for (size_t i = 0; i < cps.cp.size(); ++i) {
+    const bool cjk = IsCjkIdeograph(cps.cp[i]);
+    const size_t n = static_cast<size_t>(cjk ? kanji_n : ascii_n);
+    if (i + n > cps.cp.size()) continue;
+    if (!cross) {
+      bool crossed = false;
+      for (size_t j = 1; j < n; ++j)
+        if (IsCjkIdeograph(cps.cp[i + j]) != cjk) {
+          crossed = true;
+          break;
+        }
+      if (crossed) continue;
+    }
+    out.push_back(Window(text, cps, i, i + n));
+  }
+  return out;
+}
+
+std::vector<std::string> GenerateQueryNgrams(std::string_view normalized, int ngram, int kanji, bool cross) {  // :639-653
+  if (kanji > 0) return GenerateHybridNgrams(normalized, ngram > 0 ? ngram : 2, kanji, cross);
+  if (ngram == 0) return GenerateHybridNgrams(normalized, 2, 1, true);
+  return GenerateNgrams(normalized, ngram);
+}
+
+void DeduplicateSorted(std::vector<std::string>& v) {  // string_utils.h:192-196
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+std::vector<storage::DocId> Take(uint32_t* p, uint64_t n) {
+  std::vector<storage::DocId> v(p, p + n);
+  mgx_free(p);
+  return v;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// index::Index
+// =================================================================================================================
+
+namespace index {
+
+struct Index::Impl {
+  int device = 0;
+  double dense_threshold = 0.0;
+  int query_kanji = 0;  // table-config kanji size used for QUERY n-grams (the Index itself keeps kanji = ngram if 0)
+  mutable std::mutex mu;
+  mutable std::map<DocId, std::string> pending;  // documents recorded before the first search
+  mutable mgx_columns* cols = nullptr;
+  mutable mgx_index* dev = nullptr;
+  mutable mgx_columns_view view{};
+  mutable bool finalized = false;
+  mutable std::string last_error;
+
+  ~Impl() {
+    if (dev) mgx_index_destroy(dev);
+    if (cols) mgx_columns_destroy(cols);
+  }
+  bool Lookup(std::string_view gram, uint32_t* id) const {
+    int found = 0;
+    if (!cols) return false;
+    mgx_columns_lookup(cols, reinterpret_cast<const uint8_t*>(gram.data()), gram.size(), id, &found);
+    return found != 0;
+  }
+  uint64_t Size(uint32_t id) const { return view.offsets[id + 1] - view.offsets[id]; }
+};
+
+Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, bool cross_boundary_ngrams,
+             bool /*normalize_nfkc*/, const std::string& /*normalize_width*/, bool /*normalize_lower*/, int device)
+    : ngram_size_(ngram_size),
+      kanji_ngram_size_(kanji_ngram_size > 0 ? kanji_ngram_size : ngram_size),  // index.cpp:31
+      cross_boundary_(cross_boundary_ngrams),
+      impl_(std::make_unique<Impl>()) {
+  impl_->device = device;
+  impl_->dense_threshold = roaring_threshold;
+  impl_->query_kanji = kanji_ngram_size;
+}
+
+Index::~Index() = default;
+
+bool Index::AddDocument(DocId doc_id, std::string_view text) {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  if (impl_->finalized) {
+    impl_->last_error = "AddDocument after the first search: the device index is static (SURVEY.md 8f N4)";
+    return false;
+  }
+  impl_->pending[doc_id] = std::string(text);
+  return !GenerateHybridNgrams(text, ngram_size_, kanji_ngram_size_, cross_boundary_).empty();  // index.cpp:39-74
+}
+
+void Index::AddDocumentBatch(const std::vector<DocumentItem>& documents) {
+  for (const auto& d : documents) AddDocument(d.doc_id, d.text);
+}
+
+std::string Index::Finalize() const {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  if (impl_->finalized) return impl_->last_error;
+  impl_->finalized = true;
+  // dense id range [first, last]; ids never added are documents without text
+  const DocId first = impl_->pending.empty() ? 1 : impl_->pending.begin()->first;
+  const DocId last = impl_->pending.empty() ? 1 : impl_->pending.rbegin()->first;
+  const uint64_t n = static_cast<uint64_t>(last) - first + 1;
+  std::vector<uint8_t> bytes;
+  std::vector<uint64_t> off(n + 1, 0);
+  {
+    auto it = impl_->pending.begin();
+    for (uint64_t i = 0; i < n; ++i) {
+      if (it != impl_->pending.end() && it->first == first + i) {
+        bytes.insert(bytes.end(), it->second.begin(), it->second.end());
+        ++it;
+      }
+      off[i + 1] = bytes.size();
+    }
+  }
+  bytes.resize(bytes.size() + 16);
+  impl_->pending.clear();
+  mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, ngram_size_, kanji_ngram_size_, cross_boundary_ ? 1 : 0, 0};
+  if (mgx_columns_build(&bp, bytes.data(), off.data(), first, n, &impl_->cols) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return impl_->last_error;
+  }
+  mgx_columns_view_get(impl_->cols, &impl_->view);
+  const auto& v = impl_->view;
+  mgx_index_desc d{sizeof(mgx_index_desc), MGX_ABI_VERSION, impl_->device, 0, v.first_doc_id, v.n_docs, v.n_grams,
+                   v.offsets,               v.docids,        v.tf,          v.doc_len, impl_->dense_threshold};
+  if (mgx_index_create(&d, &impl_->dev) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    impl_->dev = nullptr;
+  }
+  return impl_->last_error;
+}
+
+const std::string& Index::LastError() const { return impl_->last_error; }
+
+std::string Index::NormalizeText(std::string_view text) const {  // non-ICU branch, string_utils.cpp:371-377
+  std::string s(text);
+  for (char& c : s)
+    if (c >= 'A' && c <= 'Z') c = static_cast<char>(c + 32);
+  return s;
+}
+
+uint64_t Index::PostingSize(std::string_view term) const {  // index.cpp:580-584
+  Finalize();
+  uint32_t id = 0;
+  return impl_->Lookup(term, &id) ? impl_->Size(id) : 0;
+}
+uint64_t Index::EstimatePostingSize(std::string_view term) const { return PostingSize(term); }  // index.cpp:756-759
+
+uint64_t Index::Bm25DocCount() const {
+  Finalize();
+  return impl_->view.bm25_doc_count;
+}
+double Index::Bm25AvgDocLength() const {  // server_types.h:182-187
+  Finalize();
+  return impl_->view.bm25_doc_count
+             ? static_cast<double>(impl_->view.bm25_total_len) / static_cast<double>(impl_->view.bm25_doc_count)
+             : 0.0;
+}
+
+Expected<uint32_t, Error> Index::AddFilterBitmap(const std::vector<DocId>& docs) const {
+  Finalize();
+  if (!impl_->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, impl_->last_error));
+  uint32_t id = 0;
+  const int rc = mgx_index_add_filter_bitmap(impl_->dev, docs.data(), docs.size(), &id);
+  if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  return id;
+}
+
+std::vector<DocId> Index::SearchAnd(const std::vector<std::string>& terms, size_t limit, bool reverse) const {
+  if (terms.empty()) return {};  // index.cpp:203
+  Finalize();
+  if (!impl_->dev) return {};
+  std::vector<uint32_t> ids;
+  for (const auto& t : terms) {
+    uint32_t id = 0;
+    if (!impl_->Lookup(t, &id)) return {};  // :211-215 unknown term
+    ids.push_back(id);
+  }
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_and(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), limit, reverse ? 1 : 0, &out, &n) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+std::vector<DocId> Index::SearchOr(const std::vector<std::string>& terms) const {  // index.cpp:418-448
+  if (terms.empty()) return {};
+  Finalize();
+  if (!impl_->dev) return {};
+  std::vector<uint32_t> ids;
+  for (const auto& t : terms) {
+    uint32_t id = 0;
+    if (impl_->Lookup(t, &id)) ids.push_back(id);  // unknown terms are skipped
+  }
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  if (ids.empty()) return {};
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_or(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+std::vector<DocId> Index::SearchNot(const std::vector<DocId>& all_docs, const std::vector<std::string>& terms) const {
+  if (terms.empty()) return all_docs;  // index.cpp:451-453
+  Finalize();
+  if (!impl_->dev) return {};
+  std::vector<uint32_t> ids;
+  for (const auto& t : terms) {
+    uint32_t id = 0;
+    if (impl_->Lookup(t, &id)) ids.push_back(id);
+  }
+  std::sort(ids.begin(), ids.end());
+  ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+  if (ids.empty()) return all_docs;
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_not(impl_->dev, all_docs.data(), all_docs.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) !=
+      MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& terms, size_t threshold) const {
+  if (terms.empty() || threshold == 0) return {};  // index.cpp:489-491
+  std::vector<std::string> uniq = terms;
+  DeduplicateSorted(uniq);                         // :496-497
+  if (threshold > uniq.size()) return {};          // :499-501
+  if (threshold == uniq.size()) return SearchAnd(uniq);  // :504-506
+  Finalize();
+  if (!impl_->dev) return {};
+  std::vector<uint32_t> ids;
+  for (const auto& t : uniq) {
+    uint32_t id = 0;
+    if (impl_->Lookup(t, &id)) ids.push_back(id);  // missing lists do not count (:512-518)
+  }
+  if (ids.size() < threshold) return {};           // :521-523
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_threshold(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), static_cast<uint32_t>(threshold), &out,
+                    &n) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+std::vector<DocId> Index::FilterByNgrams(const std::vector<DocId>& candidates,
+                                         const std::vector<std::string>& terms) const {
+  if (candidates.empty()) return {};  // index.cpp:372-374
+  if (terms.empty()) return candidates;  // :378-380
+  Finalize();
+  if (!impl_->dev) return {};
+  std::vector<uint32_t> ids;
+  for (const auto& t : terms) {
+    uint32_t id = 0;
+    if (!impl_->Lookup(t, &id)) return {};  // :381-385
+    ids.push_back(id);
+  }
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_retain(impl_->dev, candidates.data(), candidates.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out,
+                 &n) != MGX_OK) {
+    impl_->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+// ---- BM25Scorer ---------------------------------------------------------------------------------------------------
+
+double BM25Scorer::ComputeIDF(uint64_t total_docs, uint64_t doc_freq) {  // bm25_scorer.cpp:14-25
+  if (total_docs == 0) return 0.0;
+  if (doc_freq > total_docs) doc_freq = total_docs;
+  const auto n = static_cast<double>(total_docs);
+  const auto df = static_cast<double>(doc_freq);
+  return std::log((n - df + 0.5) / (df + 0.5) + 1.0);
+}
+
+Expected<std::vector<ScoredDoc>, Error> BM25Scorer::ScoreDocuments(const std::vector<DocId>& candidates,
+                                                                  const std::vector<std::string>& search_terms,
+                                                                  const std::vector<uint64_t>& term_doc_freqs,
+                                                                  const Index& index, uint64_t total_docs,
+                                                                  double avg_doc_length, const BM25Params& params) {
+  if (search_terms.size() != term_doc_freqs.size()) {  // bm25_scorer.cpp:51-55
+    return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument,
+                                    "BM25 search_terms and term_doc_freqs must have identical lengths"));
+  }
+  index.Finalize();
+  Index::Impl* im = index.impl();
+  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  std::vector<uint32_t> ids;
+  std::vector<double> idfs;
+  for (size_t i = 0; i < search_terms.size(); ++i) {
+    uint32_t id = 0xFFFFFFFFu;  // a term no document contains: tf = 0 everywhere
+    const auto grams = GenerateQueryNgrams(search_terms[i], index.GetNgramSize(), im->query_kanji,
+                                           index.GetCrossBoundaryNgrams());
+    if (grams.size() > 1)
+      return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
+                                      "BM25 on the device needs search terms that are one n-gram long (SURVEY.md 8f N1)"));
+    im->Lookup(search_terms[i], &id) || (id = 0xFFFFFFFFu);
+    ids.push_back(id);
+    idfs.push_back(ComputeIDF(total_docs, term_doc_freqs[i]));
+  }
+  std::vector<double> scores(candidates.size(), 0.0);
+  const int rc = mgx_score_documents(im->dev, candidates.data(), candidates.size(), ids.data(), idfs.data(),
+                                     static_cast<uint32_t>(ids.size()), avg_doc_length, params.k1, params.b,
+                                     scores.data());
+  if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  std::vector<ScoredDoc> out;
+  out.reserve(candidates.size());
+  for (size_t i = 0; i < candidates.size(); ++i) out.push_back({candidates[i], scores[i]});
+  return out;
+}
+
+}  // namespace index
+
+// =================================================================================================================
+// query::ResultSorter
+// =================================================================================================================
+
+namespace query {
+
+std::vector<DocId> ResultSorter::SortByScore(const index::Index& index, const std::vector<DocId>& results,
+                                             const std::vector<double>& scores, SortOrder order, uint32_t limit,
+                                             uint32_t offset) {
+  if (results.empty()) return {};  // result_sorter.cpp:663-665
+  index.Finalize();
+  index::Index::Impl* im = index.impl();
+  if (!im->dev) return {};
+  uint32_t* out = nullptr;
+  uint64_t n = 0;
+  if (mgx_sort_by_score(im->dev, results.data(), scores.data(), results.size(), order == SortOrder::DESC ? 1 : 0, limit,
+                        offset, &out, &n) != MGX_OK) {
+    im->last_error = mgx_last_error();
+    return {};
+  }
+  return Take(out, n);
+}
+
+}  // namespace query
+
+// =================================================================================================================
+// search_pipeline::ExecuteBatch
+// =================================================================================================================
+
+namespace search_pipeline {
+
+namespace {
+struct TermInfo {  // search_pipeline.h:44-55
+  std::vector<uint32_t> gram_ids;
+  size_t n_grams = 0;
+  uint64_t estimated_size = 0;  // UINT64_MAX = no n-grams
+  uint64_t df = 0;
+  std::string normalized;
+};
+}  // namespace
+
+Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index,
+                                                       const std::vector<BatchQuery>& queries) {
+  index.Finalize();
+  index::Index::Impl* im = index.impl();
+  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  const uint64_t total_docs = index.Bm25DocCount();
+  const double avgdl = index.Bm25AvgDocLength();
+
+  std::vector<BatchResult> out(queries.size());
+  std::vector<size_t> device_slot;  // queries that reach the device, in order
+  std::vector<mgx_query> mq;
+  // storage that must outlive mgx_batch_prepare
+  std::vector<std::vector<mgx_term>> term_store, not_store;
+  std::vector<std::vector<std::vector<uint32_t>>> id_store;
+  std::vector<std::vector<mgx_filter>> filter_store;
+
+  auto make_info = [&](const std::string& raw) {  // GenerateTermInfos, search_pipeline.cpp:569-603
+    TermInfo ti;
+    ti.normalized = index.NormalizeText(raw);
+    auto grams = GenerateQueryNgrams(ti.normalized, index.GetNgramSize(), im->query_kanji,
+                                     index.GetCrossBoundaryNgrams());
+    DeduplicateSorted(grams);
+    ti.n_grams = grams.size();
+    uint64_t mn = UINT64_MAX;
+    for (const auto& g : grams) {
+      uint32_t id = 0;
+      const uint64_t ps = im->Lookup(g, &id) ? im->Size(id) : 0;
+      if (ps > 0) {
+        mn = std::min(mn, ps);
+        ti.gram_ids.push_back(id);
+      } else {
+        mn = 0;
+        break;
+      }
+    }
+    ti.estimated_size = mn;
+    ti.df = (grams.size() == 1 && mn != UINT64_MAX) ? mn : 0;  // one-gram term: df = |posting list|
+    return ti;
+  };
+
+  for (size_t qi = 0; qi < queries.size(); ++qi) {
+    const BatchQuery& q = queries[qi];
+    if (q.terms.empty() || q.terms.size() > MGX_MAX_TERMS || q.not_terms.size() > MGX_MAX_TERMS)
+      return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "query needs 1..64 terms"));
+    std::vector<TermInfo> tis;
+    for (const auto& t : q.terms) tis.push_back(make_info(t));
+    // search_pipeline.cpp:2012-2014 (std::sort on <=16 elements is an insertion sort: equal keys keep their order)
+    std::stable_sort(tis.begin(), tis.end(),
+                     [](const TermInfo& a, const TermInfo& b) { return a.estimated_size < b.estimated_size; });
+    bool empty = false;
+    for (const auto& ti : tis)  // Execute :804-810
+      if ((ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) && (ti.n_grams != 0 || ti.normalized.empty()))
+        empty = true;
+    if (empty) {
+      out[qi].empty_term_detected = true;
+      continue;
+    }
+    for (const auto& ti : tis)
+      if (ti.n_grams == 0)
+        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
+                                        "a term shorter than one n-gram needs SearchNormalizedSubstring (host path)"));
+    id_store.emplace_back();
+    term_store.emplace_back();
+    not_store.emplace_back();
+    filter_store.emplace_back();
+    auto& ids = id_store.back();
+    ids.reserve(q.terms.size() + q.not_terms.size());
+    for (const auto& ti : tis) {
+      if (q.sort_by_score && ti.n_grams != 1)
+        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
+                                        "SORT _score on the device needs one-n-gram terms (SURVEY.md 8f N1)"));
+      ids.push_back(ti.gram_ids);
+      term_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0,
+                                           q.sort_by_score ? index::BM25Scorer::ComputeIDF(total_docs, ti.df) : 0.0});
+    }
+    for (const auto& t : q.not_terms) {  // ApplyNotFilter :871-932
+      TermInfo ti = make_info(t);
+      if (ti.n_grams == 0)
+        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)"));
+      if (ti.estimated_size == 0) continue;  // an unknown gram: the NOT term matches nothing
+      ids.push_back(ti.gram_ids);
+      not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0});
+    }
+    for (const auto& f : q.filters) filter_store.back().push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    mgx_query m{};
+    m.terms = term_store.back().data();
+    m.n_terms = static_cast<uint32_t>(term_store.back().size());
+    m.not_terms = not_store.back().data();
+    m.n_not_terms = static_cast<uint32_t>(not_store.back().size());
+    m.filters = filter_store.back().data();
+    m.n_filters = static_cast<uint32_t>(filter_store.back().size());
+    m.sort = q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID;
+    m.limit = q.limit;
+    m.offset = q.offset;
+    m.reverse = q.order == query::SortOrder::DESC ? 1 : 0;
+    m.k1 = q.bm25.k1;
+    m.b = q.bm25.b;
+    m.total_docs = total_docs;
+    m.avg_doc_length = avgdl;
+    mq.push_back(m);
+    device_slot.push_back(qi);
+  }
+  if (mq.empty()) return out;
+  mgx_batch* batch = nullptr;
+  int rc = mgx_batch_prepare(im->dev, mq.data(), static_cast<uint32_t>(mq.size()), &batch);
+  if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> guard(batch, mgx_batch_destroy);
+  rc = mgx_batch_execute(batch, nullptr);
+  if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  mgx_result_view v{};
+  rc = mgx_batch_fetch(batch, &v);
+  if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  for (size_t k = 0; k < device_slot.size(); ++k) {
+    const mgx_query_result& r = v.queries[k];
+    BatchResult& o = out[device_slot[k]];
+    o.total = r.total;
+    o.total_candidates = r.total_candidates;
+    o.after_intersection = r.after_intersection;
+    o.after_not = r.after_not;
+    o.after_filters = r.after_filters;
+    o.results.assign(v.docs + r.docs_begin, v.docs + r.docs_begin + r.n_docs);
+    o.scores.assign(v.scores + r.docs_begin, v.scores + r.docs_begin + r.n_docs);
+  }
+  return out;
+}
+
+}  // namespace search_pipeline
+}  // namespace mygramdb

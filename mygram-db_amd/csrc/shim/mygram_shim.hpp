@@ -1,0 +1,224 @@
+// mygram_shim.hpp — the reference's C++ operator surface for the query hot path, re-exposed over libmygram_gpu.so.
+//
+// A MygramDB maintainer swaps these classes in behind the call sites listed in INTEGRATION.md; signatures, argument
+// meaning and error behaviour follow the reference (paths below are relative to the reference tree):
+//   mygramdb::index::Index          src/index/index.h:46-300      read side: SearchAnd / SearchOr / SearchNot /
+//                                                                 SearchByThreshold / FilterByNgrams / PostingSize /
+//                                                                 EstimatePostingSize / Count / GetNgramSize / ...
+//   mygramdb::index::BM25Scorer     src/index/bm25_scorer.h:43-83 ComputeIDF, ScoreDocuments
+//   mygramdb::query::ResultSorter   src/query/result_sorter.h:75-76 SortByScore
+//   mygramdb::search_pipeline::ExecuteBatch   NEW: N parsed queries at once (the reference runs one per request,
+//                                             src/server/search_pipeline.cpp:1757); plans each like Execute :795-869
+// Everything that touches postings runs on the device through the C ABI (include/mygram_gpu.h); the host keeps what
+// the reference also does on the host per query: normalisation, n-gram generation, dictionary lookup, term
+// ordering, the empty / unknown-term rules. No exception leaves these classes (request_dispatcher.cpp:188-192).
+//
+// Differences a maintainer must know (also listed in INTEGRATION.md):
+//   * the index is static: AddDocument() only records documents until the first search; then the column arrays are
+//     built and uploaded once (binlog updates are SURVEY.md §8f N4, not built);
+//   * BM25Scorer::ScoreDocuments takes the Index where the reference takes a DocumentStore: tf and doc length come
+//     from the index's own columns, which is exact for search terms that are one n-gram long;
+//   * NormalizeText lower-cases ASCII only (ICU NFKC / width folding is not rebuilt).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../../../include/mygram_gpu.h"
+
+namespace mygram::utils {
+
+// values of src/utils/error.h:35+ that this path can return
+enum class ErrorCode : std::uint16_t {
+  kSuccess = 0,
+  kInvalidArgument = 2,
+  kOutOfRange = 3,
+  kNotImplemented = 4,
+  kInternalError = 5,
+  kQueryInvalidSort = 3007,
+  kIndexNotFound = 4000,
+};
+
+class Error {
+ public:
+  Error() = default;
+  Error(ErrorCode code, std::string message) : code_(code), message_(std::move(message)) {}
+  [[nodiscard]] ErrorCode code() const { return code_; }
+  [[nodiscard]] const std::string& message() const { return message_; }
+
+ private:
+  ErrorCode code_ = ErrorCode::kSuccess;
+  std::string message_;
+};
+
+inline Error MakeError(ErrorCode code, std::string message) { return Error(code, std::move(message)); }
+
+template <typename E>
+struct Unexpected {
+  E error;
+};
+template <typename E>
+Unexpected<std::decay_t<E>> MakeUnexpected(E&& e) {
+  return Unexpected<std::decay_t<E>>{std::forward<E>(e)};
+}
+
+// Minimal value-or-error carrier with the interface the call sites use (has_value, operator bool, *, ->, error()).
+template <typename T, typename E>
+class Expected {
+ public:
+  Expected(T value) : v_(std::move(value)) {}                       // NOLINT(google-explicit-constructor)
+  Expected(Unexpected<E> u) : v_(std::move(u.error)) {}             // NOLINT(google-explicit-constructor)
+  [[nodiscard]] bool has_value() const { return v_.index() == 0; }
+  explicit operator bool() const { return has_value(); }
+  T& operator*() { return std::get<0>(v_); }
+  const T& operator*() const { return std::get<0>(v_); }
+  T* operator->() { return &std::get<0>(v_); }
+  const T* operator->() const { return &std::get<0>(v_); }
+  T& value() { return std::get<0>(v_); }
+  const T& value() const { return std::get<0>(v_); }
+  const E& error() const { return std::get<1>(v_); }
+
+ private:
+  std::variant<T, E> v_;
+};
+
+}  // namespace mygram::utils
+
+namespace mygramdb::storage {
+using DocId = uint32_t;  // src/types/doc_id.h:31
+}
+
+namespace mygramdb::index {
+
+using DocId = storage::DocId;
+
+class Index {
+ public:
+  // src/index/index.h:58-60 (roaring_threshold becomes the dense-bitmap density threshold of the device index;
+  // 0 keeps the library default)
+  explicit Index(int ngram_size = 2, int kanji_ngram_size = 1, double roaring_threshold = 0.0,
+                 bool cross_boundary_ngrams = true, bool normalize_nfkc = true,
+                 const std::string& normalize_width = "keep", bool normalize_lower = true, int device = 0);
+  ~Index();
+  Index(const Index&) = delete;
+  Index& operator=(const Index&) = delete;
+
+  struct DocumentItem {
+    DocId doc_id;
+    std::string text;  // normalized
+  };
+
+  // Recorded on the host until the first search (static index). Returns whether the text yields any n-gram.
+  bool AddDocument(DocId doc_id, std::string_view text);
+  void AddDocumentBatch(const std::vector<DocumentItem>& documents);
+
+  [[nodiscard]] std::vector<DocId> SearchAnd(const std::vector<std::string>& terms, size_t limit = 0,
+                                             bool reverse = false) const;
+  [[nodiscard]] std::vector<DocId> FilterByNgrams(const std::vector<DocId>& candidates,
+                                                  const std::vector<std::string>& terms) const;
+  [[nodiscard]] std::vector<DocId> SearchOr(const std::vector<std::string>& terms) const;
+  [[nodiscard]] std::vector<DocId> SearchNot(const std::vector<DocId>& all_docs,
+                                             const std::vector<std::string>& terms) const;
+  [[nodiscard]] std::vector<DocId> SearchByThreshold(const std::vector<std::string>& terms, size_t threshold) const;
+  [[nodiscard]] uint64_t PostingSize(std::string_view term) const;
+  [[nodiscard]] uint64_t EstimatePostingSize(std::string_view term) const;
+  [[nodiscard]] uint64_t Count(std::string_view term) const { return PostingSize(term); }
+  [[nodiscard]] int GetNgramSize() const { return ngram_size_; }
+  [[nodiscard]] int GetKanjiNgramSize() const { return kanji_ngram_size_; }
+  [[nodiscard]] bool GetCrossBoundaryNgrams() const { return cross_boundary_; }
+  [[nodiscard]] std::string NormalizeText(std::string_view text) const;
+
+  // BM25Stats of the table (src/server/server_types.h:157-193), computed when the index is finalised.
+  [[nodiscard]] uint64_t Bm25DocCount() const;
+  [[nodiscard]] double Bm25AvgDocLength() const;
+  // FilterIndex (column,value) doc set -> device bitmap id usable in search_pipeline::BatchQuery::filters.
+  [[nodiscard]] mygram::utils::Expected<uint32_t, mygram::utils::Error> AddFilterBitmap(
+      const std::vector<DocId>& docs) const;
+
+  // internals shared with BM25Scorer / ResultSorter / search_pipeline
+  struct Impl;
+  [[nodiscard]] Impl* impl() const { return impl_.get(); }
+  // Builds the column arrays and the device index now (otherwise done by the first search). Returns an error message
+  // or "" — searches on an index that failed to build return empty results and keep the message in LastError().
+  std::string Finalize() const;
+  [[nodiscard]] const std::string& LastError() const;
+
+ private:
+  int ngram_size_, kanji_ngram_size_;
+  bool cross_boundary_;
+  std::unique_ptr<Impl> impl_;
+};
+
+struct BM25Params {  // src/index/bm25_scorer.h:20-23
+  double k1 = 1.2;
+  double b = 0.75;
+};
+
+struct ScoredDoc {  // src/index/bm25_scorer.h:28-31
+  DocId doc_id;
+  double score;
+};
+
+class BM25Scorer {
+ public:
+  static double ComputeIDF(uint64_t total_docs, uint64_t doc_freq);
+  // src/index/bm25_scorer.h:79-82 — `index` stands where the reference passes the DocumentStore (see header note).
+  static mygram::utils::Expected<std::vector<ScoredDoc>, mygram::utils::Error> ScoreDocuments(
+      const std::vector<DocId>& candidates, const std::vector<std::string>& search_terms,
+      const std::vector<uint64_t>& term_doc_freqs, const Index& index, uint64_t total_docs, double avg_doc_length,
+      const BM25Params& params);
+};
+
+}  // namespace mygramdb::index
+
+namespace mygramdb::query {
+
+using DocId = storage::DocId;
+enum class SortOrder : uint8_t { ASC, DESC };  // src/query/query_parser.h
+
+class ResultSorter {
+ public:
+  // src/query/result_sorter.h:75-76. Runs on the device of `index` (any finalised index: only its stream is used).
+  static std::vector<DocId> SortByScore(const index::Index& index, const std::vector<DocId>& results,
+                                        const std::vector<double>& scores, SortOrder order, uint32_t limit,
+                                        uint32_t offset);
+};
+
+}  // namespace mygramdb::query
+
+namespace mygramdb::search_pipeline {
+
+using DocId = storage::DocId;
+
+// The parts of query::Query (src/query/query_parser.h:207-243) the hot path consumes.
+struct BatchQuery {
+  std::vector<std::string> terms;      // search_text + and_terms (raw; normalised here)
+  std::vector<std::string> not_terms;
+  std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
+  bool sort_by_score = false;          // SORT _score
+  query::SortOrder order = query::SortOrder::DESC;
+  uint32_t limit = 100;                // api.default_limit (src/config/config.h:61)
+  uint32_t offset = 0;
+  index::BM25Params bm25;
+};
+
+// SearchPipelineResult (src/server/search_pipeline.h:58-65) plus the page the handler would format.
+struct BatchResult {
+  std::vector<DocId> results;          // the page, in rank order
+  std::vector<double> scores;          // parallel to results for SORT _score
+  uint64_t total = 0;                  // results.size() before pagination
+  size_t total_candidates = 0, after_intersection = 0, after_not = 0, after_filters = 0;
+  bool empty_term_detected = false;
+};
+
+// N queries planned like ExecuteFullPipeline's regular branch (GenerateTermInfos with df, sort by estimated size,
+// Execute, BM25 + SortByScore) and run as ONE device batch.
+mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> ExecuteBatch(
+    const index::Index& index, const std::vector<BatchQuery>& queries);
+
+}  // namespace mygramdb::search_pipeline

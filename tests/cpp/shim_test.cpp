@@ -1,0 +1,170 @@
+// shim_test.cpp — the reference's own known-answer tests, written against the shim classes exactly the way the
+// reference's gtest files call the originals (expected values transcribed as data from /root/reference/tests; the
+// file:line of every case is given). Needs a GPU; built and run by tests/test_gpu_shim.py.
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../mygram-db_amd/csrc/shim/mygram_shim.hpp"
+
+using mygramdb::index::BM25Params;
+using mygramdb::index::BM25Scorer;
+using mygramdb::index::DocId;
+using mygramdb::index::Index;
+using mygramdb::query::ResultSorter;
+using mygramdb::query::SortOrder;
+
+static int g_failed = 0, g_checked = 0;
+#define EXPECT(cond)                                                      \
+  do {                                                                    \
+    ++g_checked;                                                          \
+    if (!(cond)) {                                                        \
+      ++g_failed;                                                         \
+      std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);         \
+    }                                                                     \
+  } while (0)
+using V = std::vector<DocId>;
+
+static V Range(DocId a, DocId b, int step) {
+  V v;
+  for (long x = a; step > 0 ? x <= b : x >= static_cast<long>(b); x += step) v.push_back(static_cast<DocId>(x));
+  return v;
+}
+
+int main() {
+  {  // tests/index/index_search_test.cpp:22-59
+    Index index(1);
+    index.AddDocument(1, "abc");
+    index.AddDocument(2, "bcd");
+    index.AddDocument(3, "cde");
+    EXPECT(index.SearchAnd({"b"}) == (V{1, 2}));
+    EXPECT(index.SearchAnd({"b", "c"}) == (V{1, 2}));
+    EXPECT(index.SearchAnd({"c", "d"}) == (V{2, 3}));
+    EXPECT(index.SearchAnd({}).empty());   // :423-437
+    EXPECT(index.SearchOr({}).empty());
+    EXPECT(index.SearchAnd({"a", "x"}, 10, true).empty());  // :568-585 unknown term
+    if (!index.LastError().empty()) std::printf("index error: %s\n", index.LastError().c_str());
+  }
+  {  // :460-489
+    Index index(2);
+    index.AddDocument(100, "hello");
+    index.AddDocument(200, "help");
+    index.AddDocument(300, "yellow");
+    index.AddDocument(400, "hello world");
+    index.AddDocument(500, "shell");
+    EXPECT(index.SearchAnd({"he", "el"}, 0, false) == (V{100, 200, 400, 500}));
+    EXPECT(index.SearchAnd({"he", "he", "el"}) == (V{100, 200, 400, 500}));  // duplicate grams harmless (:439-446)
+  }
+  {  // :587-620 Roaring chain + top-10 reverse; :622-660 limit/reverse matrix
+    Index index(1);
+    for (DocId i = 1; i <= 15000; ++i) index.AddDocument(i, "ab");
+    for (DocId i = 15001; i <= 15100; ++i) index.AddDocument(i, "a");
+    EXPECT(index.SearchAnd({"a", "b"}, 10, true) == Range(15000, 14991, -1));
+    EXPECT(index.SearchAnd({"a", "b"}, 10, false) == Range(1, 10, 1));
+    EXPECT(index.SearchAnd({"a"}, 5, true) == Range(15100, 15096, -1));
+    EXPECT(index.SearchAnd({"a", "b"}).size() == 15000);
+  }
+  {  // OR / NOT: :101-120, :202-222, :227-258
+    Index index(1);
+    index.AddDocument(1, "abc");
+    index.AddDocument(2, "def");
+    index.AddDocument(3, "ghi");
+    index.AddDocument(4, "jkl");
+    EXPECT(index.SearchOr({"a", "d"}) == (V{1, 2}));
+    EXPECT(index.SearchOr({"a", "d", "g"}) == (V{1, 2, 3}));
+    EXPECT(index.SearchOr({"z"}).empty());
+    EXPECT(index.SearchOr({"a", "z"}) == (V{1}));
+    EXPECT(index.SearchNot({1, 2, 3, 4}, {"a", "d"}) == (V{3, 4}));
+    EXPECT(index.SearchNot({1, 2, 3, 4}, {"a", "d", "g"}) == (V{4}));
+    EXPECT(index.SearchNot({1, 2, 3, 4}, {"z"}) == (V{1, 2, 3, 4}));
+    EXPECT(index.SearchNot({1, 2, 3, 4}, {}) == (V{1, 2, 3, 4}));
+  }
+  {  // tests/index/search_by_threshold_test.cpp:41-167
+    Index index(2);
+    index.AddDocument(1, "hello");
+    index.AddDocument(2, "help");
+    index.AddDocument(3, "world");
+    EXPECT(index.SearchByThreshold({"he", "el", "ll", "lo"}, 4) == (V{1}));
+    EXPECT(index.SearchByThreshold({"he", "el", "ll", "lo"}, 2) == (V{1, 2}));
+    EXPECT(index.SearchByThreshold({"he", "wo"}, 1) == (V{1, 2, 3}));
+    EXPECT(index.SearchByThreshold({"he", "el", "zz"}, 2) == (V{1, 2}));
+    EXPECT(index.SearchByThreshold({}, 1).empty());
+    EXPECT(index.SearchByThreshold({"he"}, 0).empty());
+    EXPECT(index.SearchByThreshold({"zz", "yy", "xx"}, 1).empty());
+    EXPECT(index.SearchByThreshold({"he", "el", "lp"}, 3) == (V{2}));
+    EXPECT(index.SearchByThreshold({"he", "he", "wo"}, 2).empty());
+    EXPECT(index.SearchByThreshold({"he", "he"}, 2).empty());
+  }
+  {  // tests/index/index_search_test.cpp:662-701 FilterByNgrams
+    Index index(1, 0);
+    for (DocId d = 1; d <= 6000; ++d) index.AddDocument(d, d % 3 == 0 ? "ab" : "a");
+    V cand, want;
+    for (DocId d = 1; d <= 6000; d += 7) {
+      cand.push_back(d);
+      if (d % 3 == 0) want.push_back(d);
+    }
+    EXPECT(index.FilterByNgrams(cand, {"a", "b"}) == want);
+    EXPECT(index.FilterByNgrams(cand, {"a", "z"}).empty());
+    EXPECT(index.FilterByNgrams(cand, {}) == cand);
+    EXPECT(index.FilterByNgrams({}, {"a"}).empty());
+    EXPECT(index.FilterByNgrams({3, 3, 6000, 6001}, {"b"}) == (V{3, 3, 6000}));
+  }
+  {  // tests/index/bm25_scorer_test.cpp:21-48
+    EXPECT(std::fabs(BM25Scorer::ComputeIDF(100, 10) - std::log(90.5 / 10.5 + 1.0)) < 1e-10);
+    EXPECT(BM25Scorer::ComputeIDF(0, 10) == 0.0);
+    EXPECT(BM25Scorer::ComputeIDF(10, 20) == BM25Scorer::ComputeIDF(10, 10));
+  }
+  {  // tests/server/http_server_search_test.cpp:498-529 worked example; bm25_scorer_test.cpp:175-184 error case
+    Index index(5);  // "alpha" is one 5-gram
+    index.AddDocument(1, "alpha");
+    index.AddDocument(2, "alpha alpha alpha");
+    auto scored = BM25Scorer::ScoreDocuments({1, 2}, {"alpha"}, {2}, index, 2, 11.0, BM25Params{1.2, 0.75});
+    EXPECT(scored.has_value());
+    if (scored) {
+      EXPECT(std::fabs((*scored)[0].score - 0.2346905145964735) < 1e-12);
+      EXPECT(std::fabs((*scored)[1].score - 0.25652219037288959) < 1e-12);
+      EXPECT((*scored)[0].doc_id == 1 && (*scored)[1].doc_id == 2);
+    }
+    auto bad = BM25Scorer::ScoreDocuments({1}, {"alpha", "world"}, {1}, index, 1, 1.0, {});
+    EXPECT(!bad.has_value() && bad.error().code() == mygram::utils::ErrorCode::kInvalidArgument);
+    EXPECT(bad.error().message().find("identical lengths") != std::string::npos);
+    // tests/query/bm25_sort_test.cpp:15-75
+    EXPECT(ResultSorter::SortByScore(index, {1, 2, 3, 4}, {1.0, 3.0, 2.0, 4.0}, SortOrder::DESC, 0, 0) == (V{4, 2, 3, 1}));
+    EXPECT(ResultSorter::SortByScore(index, {1, 2, 3}, {3.0, 1.0, 2.0}, SortOrder::ASC, 0, 0) == (V{2, 3, 1}));
+    EXPECT(ResultSorter::SortByScore(index, {1, 2, 3, 4, 5}, {1, 5, 3, 2, 4}, SortOrder::DESC, 3, 0) == (V{2, 5, 3}));
+    EXPECT(ResultSorter::SortByScore(index, {1, 2, 3, 4}, {1, 4, 3, 2}, SortOrder::DESC, 2, 1) == (V{3, 4}));
+    EXPECT(ResultSorter::SortByScore(index, {3, 1, 2}, {1, 1, 1}, SortOrder::ASC, 0, 0) == (V{1, 2, 3}));
+    EXPECT(ResultSorter::SortByScore(index, {3, 1, 2}, {1, 1, 1}, SortOrder::DESC, 0, 0) == (V{3, 2, 1}));
+    EXPECT(ResultSorter::SortByScore(index, {}, {}, SortOrder::DESC, 0, 0).empty());
+  }
+  {  // tests/server/search_pipeline_test.cpp:916-995 fixture through the batched entry
+    using namespace mygramdb::search_pipeline;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning techniques");
+    index.AddDocument(3, "old article about cats");
+    auto status1 = index.AddFilterBitmap({1, 2});
+    EXPECT(status1.has_value());
+    std::vector<BatchQuery> qs(3);
+    qs[0].terms = {"learning"};
+    qs[1].terms = {"learning", "machine"};
+    qs[1].not_terms = {"basics"};
+    qs[1].filters = {{status1 ? *status1 : 0u, false}};
+    qs[2].terms = {"LEARNING", "zzzz"};  // unknown gram: empty before the device
+    for (auto& q : qs) q.order = SortOrder::ASC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      EXPECT((*r)[0].results == (V{1, 2}) && (*r)[0].total == 2);
+      EXPECT((*r)[1].results.empty());
+      EXPECT((*r)[1].total_candidates == 1 && (*r)[1].after_intersection == 1 && (*r)[1].after_not == 0 &&
+             (*r)[1].after_filters == 0);
+      EXPECT((*r)[2].empty_term_detected && (*r)[2].results.empty());
+    } else {
+      std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
+    }
+  }
+  std::printf("shim_test: %d checks, %d failed\n", g_checked, g_failed);
+  return g_failed == 0 ? 0 : 1;
+}

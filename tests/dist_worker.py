@@ -1,0 +1,110 @@
+"""Worker of the world_size-2 sharding tests (launched by tests/test_dist_cpu.py / tests/test_gpu_dist.py).
+
+mode=cpu : gloo, no device. Checks the sharding design with host code only: shard ranges, the global statistics every
+           rank must agree on (gram sizes aligned by gram bytes, BM25 N / total length), and that per-shard top-k
+           lists scored with the GLOBAL idf merge into exactly the unsharded ranking (oracle as the checker).
+mode=gpu : gloo for the exchange (both ranks share the one GPU of the box, which RCCL refuses), device kernels for
+           everything else: ShardedTable.run -> export_topk -> all-gather -> merge_shards kernel -> fetch, compared
+           with the oracle on the whole corpus.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from pkg import mg  # noqa: E402
+from mygram_db_amd import dist as mdist  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+N_DOCS = 40_000
+
+
+def queries_for(keys, sizes, n=24, limit=10):
+    rng = np.random.default_rng(5)
+    cand = [k for k, s in zip(keys, sizes) if b" " not in k and s > 0]
+    w = np.asarray([s for k, s in zip(keys, sizes) if b" " not in k and s > 0], dtype=np.float64)
+    out = []
+    for i in range(n):
+        pick = rng.choice(len(cand), size=3, replace=False, p=w / w.sum())
+        out.append(mg.engine.Query([cand[j].decode() for j in pick], sort_score=True, limit=limit,
+                                   offset=[0, 2][i % 2]))
+    return out
+
+
+def oracle_whole():
+    corpus = mg.Corpus.synthetic(N_DOCS, seed=11)
+    cols = mg.Columns(corpus, 1, 2, 0, True)
+    oidx = O.Index.from_csr(2, 0, True, cols.key_bytes, cols.key_off, cols.offsets, cols.docids)
+    ostore = O.DocumentStore.from_arrays(corpus.text_bytes, corpus.text_off)
+    return corpus, cols, oidx, ostore
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    before, mine = mdist.shard_range(N_DOCS, rank, world)
+    assert sum(mdist.shard_range(N_DOCS, r, world)[1] for r in range(world)) == N_DOCS
+    shard_corpus = mg.Corpus.synthetic(mine, seed=11, global_first=before)
+    corpus, cols, oidx, ostore = oracle_whole()
+    keys_w = [cols.gram(g) for g in range(cols.n_grams)]
+    sizes_w = np.diff(cols.offsets.astype(np.int64))
+
+    if mode == "cpu":
+        scols = mg.Columns(shard_corpus, 1 + before, 2, 0, True)
+        keys = [scols.gram(g) for g in range(scols.n_grams)]
+        sizes = np.diff(scols.offsets.astype(np.int64))
+        gsizes, n, total_len = mdist.global_table_stats(keys, sizes, scols.bm25_doc_count, scols.bm25_total_len)
+        whole = dict(zip(keys_w, sizes_w.tolist()))
+        assert [whole[k] for k in keys] == gsizes.tolist()
+        assert (n, total_len) == (cols.bm25_doc_count, cols.bm25_total_len)
+        # per-shard oracle top-k with GLOBAL statistics, gathered and merged == unsharded oracle ranking
+        sidx = O.Index.from_csr(2, 0, True, scols.key_bytes, scols.key_off, scols.offsets, scols.docids)
+        shard_texts = [shard_corpus.text(i) for i in range(mine)]
+        sstore = O.DocumentStore()
+        for i, t in enumerate(shard_texts):
+            sstore.add(1 + before + i, t)
+        avg = total_len / n
+        for q in queries_for(keys_w, sizes_w):
+            terms = sorted(q.terms, key=lambda t: whole[t.encode()])
+            dfs = [whole[t.encode()] for t in terms]
+            res = sidx.search_and(terms)
+            sc = O.score_documents(sstore, res, terms, dfs, n, avg)
+            top = O.sort_by_score(res, sc, True, q.offset + q.limit, 0)
+            lookup = dict(zip(res.tolist(), sc.tolist()))
+            mine_list = [(lookup[d], d) for d in top.tolist()]
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (mine_list, len(res)))
+            merged = sorted((x for lst, _ in gathered for x in lst), key=lambda x: (-x[0], -x[1]))
+            page = merged[q.offset:q.offset + q.limit]
+            total, docs, scores = O.search_scored(oidx, ostore, q.terms, n, avg, limit=q.limit, offset=q.offset)
+            assert sum(c for _, c in gathered) == total
+            assert [d for _, d in page] == docs.tolist()
+            assert [s for s, _ in page] == scores.tolist()
+    else:
+        torch.cuda.set_device(0)
+        table = mdist.ShardedTable(shard_corpus, first_doc_id=1 + before, device=0)
+        assert table.index.total_docs == cols.bm25_doc_count
+        qs = queries_for(keys_w, sizes_w)
+        batch = table.prepare(qs)
+        for _ in range(2):  # a prepared batch can be run repeatedly
+            table.run(batch)
+            got = batch.fetch()
+        n, avg = cols.bm25_doc_count, cols.avg_doc_length()
+        for q, g in zip(qs, got):
+            total, docs, scores = O.search_scored(oidx, ostore, q.terms, n, avg, limit=q.limit, offset=q.offset)
+            assert g.total == total, (q.terms, g.total, total)
+            assert g.docs.tolist() == docs.tolist(), q.terms
+            assert np.array_equal(g.scores, scores), q.terms
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()
