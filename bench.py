@@ -169,6 +169,15 @@ def main():
     alg_total = sum(alg)
     achieved = alg_total / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
 
+    # HBM bytes per launch from the committed PMC summary of this same command (profiles/pmc_traffic_current.json:
+    # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide says)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch_dominant_kernels"] if world == 1 else None
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     results0 = None
     cpu = None
     if rank == 0 and world == 1 and cpu_seconds > 0:
@@ -194,7 +203,7 @@ def main():
                        "mean_list_len_of_queries": alg[0] / 4 / batch_size / 3,
                        "dense_threshold": dense if dense else 1.0 / 256, "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 + per-wave top-k; queries with a sparse scored "
                                    "gram run on mgx::tile_eval_kernel<0> inside the same timed region)",
                          "kernel_ms": k_ms, "launches_timed": k_n,
