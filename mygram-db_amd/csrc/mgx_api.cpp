@@ -103,7 +103,6 @@ struct mgx_index {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // the few queries the wave kernel cannot take run here, beside the main launch
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
@@ -190,8 +189,6 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   MGX_HIP(hipSetDevice(d->device));
   MGX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
   MGX_HIP(hipStreamCreateWithFlags(&idx->side_stream, hipStreamNonBlocking));
-  MGX_HIP(hipEventCreateWithFlags(&idx->fork_ev, hipEventDisableTiming));
-  MGX_HIP(hipEventCreateWithFlags(&idx->join_ev, hipEventDisableTiming));
 
   const uint64_t G = d->n_grams;
   const uint64_t P = G ? d->offsets[G] : 0;
@@ -307,8 +304,6 @@ void mgx_index_destroy(mgx_index* idx) {
   (void)hipSetDevice(idx->device);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   if (idx->side_stream) (void)hipStreamDestroy(idx->side_stream);
-  if (idx->fork_ev) (void)hipEventDestroy(idx->fork_ev);
-  if (idx->join_ev) (void)hipEventDestroy(idx->join_ev);
   delete idx;
 }
 
@@ -602,6 +597,7 @@ struct mgx_batch {
   std::vector<double> h_scores;
   bool executed = false;
   hipStream_t last_stream = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;  // fork/join of the side-stream launch (owned by the batch)
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -822,12 +818,16 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     }
     if (g.n_items != 0 && g.n_items_wave != 0) {
       // fork: the general kernel's (small) share runs on the side stream while the wave kernel fills the chip
-      MGX_HIP(hipEventRecord(idx->fork_ev, s));
-      MGX_HIP(hipStreamWaitEvent(idx->side_stream, idx->fork_ev, 0));
+      if (!b->fork_ev) {
+        MGX_HIP(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
+        MGX_HIP(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
+      }
+      MGX_HIP(hipEventRecord(b->fork_ev, s));
+      MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
-      MGX_HIP(hipEventRecord(idx->join_ev, idx->side_stream));
+      MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
       MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
-      MGX_HIP(hipStreamWaitEvent(s, idx->join_ev, 0));
+      MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
       MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
@@ -1104,6 +1104,8 @@ void mgx_batch_destroy(mgx_batch* batch) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
+  if (batch->fork_ev) (void)hipEventDestroy(batch->fork_ev);
+  if (batch->join_ev) (void)hipEventDestroy(batch->join_ev);
   delete batch;
 }
 
