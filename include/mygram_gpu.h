@@ -159,6 +159,19 @@ typedef struct mgx_filter {
   uint32_t negate;    /* 0: EQ (AND), 1: NE (ANDNOT) — search_pipeline.cpp:1196-1237 */
 } mgx_filter;
 
+/* Boolean expression over the positive terms (query::QueryNode, src/query/query_ast.h:52-83), in POSTFIX order.
+ * Evaluated like EvaluateBooleanAstExpanded (src/server/search_pipeline.cpp:327-378): TERM = the term's doc set,
+ * AND = intersection of its children, OR = union, NOT = universe minus child, where the universe is
+ * DocumentStore::GetAllDocIds() (document_store_retrieval.cpp:242-258). */
+#define MGX_EXPR_TERM 0u  /* arg = index into mgx_query.terms */
+#define MGX_EXPR_EMPTY 1u /* a term the caller already knows to match nothing (unknown gram) */
+#define MGX_EXPR_AND 2u   /* arg = number of children (>= 1), already on the stack */
+#define MGX_EXPR_OR 3u    /* arg = number of children (>= 1) */
+#define MGX_EXPR_NOT 4u   /* one child */
+typedef struct mgx_expr_token {
+  uint32_t op, arg;
+} mgx_expr_token;
+
 typedef struct mgx_query {
   /* positive terms, ALREADY in the order search_pipeline.cpp:2012-2014 leaves them (estimated_size ascending):
    * BM25 sums term contributions in this order (bm25_scorer.cpp:77-86) */
@@ -175,6 +188,14 @@ typedef struct mgx_query {
   double k1, b;     /* BM25Params (bm25_scorer.h:20-23) */
   uint64_t total_docs;    /* BM25Stats::doc_count; only documents the caller's idf values already encode */
   double avg_doc_length;  /* BM25Stats::avg_doc_length() */
+  /* Optional boolean expression (ExecuteWithBooleanAst, search_pipeline.cpp:1408-1578). When n_expr > 0 the positive
+   * part of the query is the expression instead of the plain AND of `terms`; NOT terms and filters still apply to its
+   * result. The NOT universe is the doc-id range [universe_first, universe_first + universe_count) clipped to the
+   * index (universe_count 0 => every slot of the index). */
+  const mgx_expr_token* expr;
+  uint32_t n_expr;
+  uint32_t universe_first;
+  uint64_t universe_count;
 } mgx_query;
 
 typedef struct mgx_batch mgx_batch;

@@ -56,7 +56,16 @@ class Query(C.Structure):
     _fields_ = [("terms", C.c_void_p), ("n_terms", C.c_uint32), ("not_terms", C.c_void_p),
                 ("n_not_terms", C.c_uint32), ("filters", C.c_void_p), ("n_filters", C.c_uint32),
                 ("sort", C.c_uint32), ("limit", C.c_uint32), ("offset", C.c_uint32), ("reverse", C.c_uint32),
-                ("k1", C.c_double), ("b", C.c_double), ("total_docs", C.c_uint64), ("avg_doc_length", C.c_double)]
+                ("k1", C.c_double), ("b", C.c_double), ("total_docs", C.c_uint64), ("avg_doc_length", C.c_double),
+                ("expr", C.c_void_p), ("n_expr", C.c_uint32), ("universe_first", C.c_uint32),
+                ("universe_count", C.c_uint64)]
+
+
+class ExprToken(C.Structure):
+    _fields_ = [("op", C.c_uint32), ("arg", C.c_uint32)]
+
+
+EXPR_TERM, EXPR_EMPTY, EXPR_AND, EXPR_OR, EXPR_NOT = 0, 1, 2, 3, 4
 
 
 class QueryResult(C.Structure):

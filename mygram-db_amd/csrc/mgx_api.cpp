@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -481,19 +482,97 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     }
     out->est_density = dens;
   }
-  c.LoadTerm(in.terms[0]);
-  c.Emit(kOpCount, 0);
-  for (uint32_t i = 1; i < in.n_terms; ++i) {
-    const mgx_term& t = in.terms[i];
-    if (t.threshold != 0 && t.threshold < t.n_grams) {
-      c.Emit(kOpPush);
-      c.LoadTerm(t);
-      c.Emit(kOpPopAnd);
-    } else {
-      for (uint32_t g = 0; g < t.n_grams; ++g) c.Emit(kOpAnd, c.GramLeaf(t.gram_ids[g]));
+  if (in.n_expr > 0) {
+    // ExecuteWithBooleanAst: the positive part is a boolean tree over the terms. Postfix -> tree -> accumulator code.
+    if (!in.expr) return Fail(MGX_ERR_INVALID_ARGUMENT, "n_expr without expr");
+    if (in.n_expr > 512) return Fail(MGX_ERR_OUT_OF_RANGE, "expression longer than 512 tokens");
+    struct Node {
+      uint32_t op, arg;
+      std::vector<int> kids;
+    };
+    std::vector<Node> nodes;
+    std::vector<int> st;
+    for (uint32_t k = 0; k < in.n_expr; ++k) {
+      const mgx_expr_token tk = in.expr[k];
+      Node n{tk.op, tk.arg, {}};
+      if (tk.op == MGX_EXPR_TERM) {
+        if (tk.arg >= in.n_terms) return Fail(MGX_ERR_OUT_OF_RANGE, "expression refers to a term that is not given");
+      } else if (tk.op == MGX_EXPR_AND || tk.op == MGX_EXPR_OR || tk.op == MGX_EXPR_NOT) {
+        const uint32_t nk = tk.op == MGX_EXPR_NOT ? 1u : tk.arg;
+        if (nk == 0 || nk > st.size()) return Fail(MGX_ERR_INVALID_ARGUMENT, "malformed postfix expression");
+        n.kids.assign(st.end() - nk, st.end());
+        st.resize(st.size() - nk);
+      } else if (tk.op != MGX_EXPR_EMPTY) {
+        return Fail(MGX_ERR_INVALID_ARGUMENT, "unknown expression token");
+      }
+      nodes.push_back(std::move(n));
+      st.push_back(static_cast<int>(nodes.size()) - 1);
     }
+    if (st.size() != 1) return Fail(MGX_ERR_INVALID_ARGUMENT, "postfix expression does not reduce to one result");
+    // operand for the NOT universe / the empty set: a slot range of this shard
+    auto range_leaf = [&](uint64_t lo, uint64_t hi) {
+      DevLeaf lf{};
+      lf.score_slot = kNoSlot;
+      lf.row = kNoRow;
+      lf.kind = kLeafRange;
+      lf.a = static_cast<uint32_t>(lo);
+      lf.b = static_cast<uint32_t>(hi);
+      out->leaves.push_back(lf);
+      return static_cast<uint32_t>(out->leaves.size() - 1);
+    };
+    const uint64_t base = idx->dev.first_doc_id, span = idx->dev.n_docs;
+    uint64_t ulo = 0, uhi = span;
+    if (in.universe_count != 0) {
+      const uint64_t a = in.universe_first, b2 = a + in.universe_count;
+      ulo = a > base ? std::min(a - base, span) : 0;
+      uhi = b2 > base ? std::min(b2 - base, span) : 0;
+    }
+    uint32_t universe = kNoRow, empty = kNoRow;
+    std::function<void(int)> emit = [&](int ni) {
+      const Node& n = nodes[ni];
+      switch (n.op) {
+        case MGX_EXPR_TERM: c.LoadTerm(in.terms[n.arg]); break;
+        case MGX_EXPR_EMPTY:
+          if (empty == kNoRow) empty = range_leaf(0, 0);
+          c.Emit(kOpLoad, empty);
+          break;
+        case MGX_EXPR_AND:
+        case MGX_EXPR_OR:
+          emit(n.kids[0]);
+          for (size_t k = 1; k < n.kids.size(); ++k) {
+            c.Emit(kOpPush);
+            emit(n.kids[k]);
+            c.Emit(n.op == MGX_EXPR_AND ? kOpPopAnd : kOpPopOr);
+          }
+          break;
+        default:  // NOT: universe & ~child
+          if (universe == kNoRow) universe = range_leaf(ulo, uhi);
+          c.Emit(kOpLoad, universe);
+          c.Emit(kOpPush);
+          emit(n.kids[0]);
+          c.Emit(kOpPopAndNot);
+          break;
+      }
+    };
+    emit(st[0]);
+    if (out->stack_depth > 40) return Fail(MGX_ERR_OUT_OF_RANGE, "expression nests deeper than 40 levels");
+    c.Emit(kOpCount, 0);
+    c.Emit(kOpCount, 1);
+  } else {
+    c.LoadTerm(in.terms[0]);
+    c.Emit(kOpCount, 0);
+    for (uint32_t i = 1; i < in.n_terms; ++i) {
+      const mgx_term& t = in.terms[i];
+      if (t.threshold != 0 && t.threshold < t.n_grams) {
+        c.Emit(kOpPush);
+        c.LoadTerm(t);
+        c.Emit(kOpPopAnd);
+      } else {
+        for (uint32_t g = 0; g < t.n_grams; ++g) c.Emit(kOpAnd, c.GramLeaf(t.gram_ids[g]));
+      }
+    }
+    c.Emit(kOpCount, 1);
   }
-  c.Emit(kOpCount, 1);
   for (uint32_t i = 0; i < in.n_not_terms; ++i) {
     const mgx_term& t = in.not_terms[i];
     if (t.n_grams == 1 && !(t.threshold != 0 && t.threshold < t.n_grams)) {

@@ -208,11 +208,27 @@ class DeviceIndex:
 class Query:
     """The parts of query::Query (src/query/query_parser.h:207-243) the hot path consumes."""
 
-    def __init__(self, terms, not_terms=(), filters=(), sort_score=False, limit=100, offset=0, descending=True,
-                 k1=1.2, b=0.75, fuzzy=0):
+    def __init__(self, terms=(), not_terms=(), filters=(), sort_score=False, limit=100, offset=0, descending=True,
+                 k1=1.2, b=0.75, fuzzy=0, expr=None, universe=None):
+        """`expr`: boolean tree over term strings instead of the plain AND of `terms` (query::QueryNode):
+        "term" | ("and", e, ...) | ("or", e, ...) | ("not", e). `universe` = (first_doc_id, count) of the NOT universe
+        (DocumentStore::GetAllDocIds); None = every slot of the index."""
         self.terms, self.not_terms, self.filters = list(terms), list(not_terms), list(filters)
         self.sort_score, self.limit, self.offset, self.descending = sort_score, limit, offset, descending
         self.k1, self.b, self.fuzzy = k1, b, fuzzy
+        self.expr, self.universe = expr, universe
+        if expr is not None and not self.terms:
+            seen = []
+
+            def walk(e):
+                if isinstance(e, str):
+                    if e not in seen:
+                        seen.append(e)
+                else:
+                    for c in e[1:]:
+                        walk(c)
+            walk(expr)
+            self.terms = seen
 
 
 class TermInfo:
@@ -488,17 +504,43 @@ class Index:
         cqueries, keep, shells, orders = [], [], [], []
         for q in queries:
             tis = [self.term_info(t, q.fuzzy) for t in q.terms]
-            order = sorted(range(len(tis)), key=lambda i: (float("inf") if tis[i].estimated_size is None
-                                                           else tis[i].estimated_size))  # stable, :2012-2014
+            if q.expr is not None:
+                order = list(range(len(tis)))  # expression leaves keep their first-use order
+            else:
+                order = sorted(range(len(tis)), key=lambda i: (float("inf") if tis[i].estimated_size is None
+                                                               else tis[i].estimated_size))  # stable, :2012-2014
             tis = [tis[i] for i in order]
             shell = SearchResult()
             shell.term_order = order
             orders.append(order)
-            if any(t.estimated_size in (0, None) and (t.grams or not t.normalized) for t in tis):
+            expr_tokens = None
+            if q.expr is not None:
+                # ExecuteWithBooleanAst (search_pipeline.cpp:1408-1578): a term with an unknown gram is an empty
+                # doc set inside the tree, not the end of the query
+                toks = []
+
+                def emit(e):
+                    if isinstance(e, str):
+                        i = q.terms.index(e)
+                        toks.append((_capi.EXPR_EMPTY, 0) if tis[i].estimated_size in (0, None)
+                                    else (_capi.EXPR_TERM, i))
+                        return
+                    for c in e[1:]:
+                        emit(c)
+                    op = {"and": _capi.EXPR_AND, "or": _capi.EXPR_OR, "not": _capi.EXPR_NOT}[e[0]]
+                    toks.append((op, len(e) - 1))
+                emit(q.expr)
+                expr_tokens = (_capi.ExprToken * len(toks))(*[_capi.ExprToken(o, a) for o, a in toks])
+                keep.append(expr_tokens)
+                # placeholder grams for EMPTY leaves so that every mgx_term stays well-formed
+                for t in tis:
+                    if t.estimated_size in (0, None):
+                        t.gram_ids = [0]
+            elif any(t.estimated_size in (0, None) and (t.grams or not t.normalized) for t in tis):
                 shell.empty_term_detected = True  # Execute :804-810
                 shells.append(shell)
                 continue
-            if any(not t.grams for t in tis):
+            if q.expr is None and any(not t.grams for t in tis):
                 raise _capi.MgxError(4, "a term shorter than one n-gram needs the substring fallback "
                                         "(SearchNormalizedSubstring), which is not on the device path")
             cterms = (_capi.Term * len(tis))()
@@ -533,6 +575,11 @@ class Index:
                              C.cast(cf, C.c_void_p), len(q.filters),
                              _capi.SORT_SCORE if q.sort_score else _capi.SORT_DOCID, q.limit, q.offset,
                              int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
+            if expr_tokens is not None:
+                cq.expr = C.cast(expr_tokens, C.c_void_p)
+                cq.n_expr = len(expr_tokens)
+                if q.universe is not None:
+                    cq.universe_first, cq.universe_count = q.universe
             cqueries.append(cq)
             shells.append(None)
         return PreparedBatch(self, cqueries, keep, shells, orders)

@@ -134,6 +134,52 @@ def test_multi_gram_terms_docid_order(pair60k):
     pair60k.check(queries)
 
 
+def test_boolean_expressions(pair60k):
+    """ExecuteWithBooleanAst / EvaluateBooleanAstExpanded shapes: nested AND/OR/NOT over terms, then NOT terms and
+    filters (full-pipeline vectors of search_pipeline_test.cpp:1122-1348 in test_pipeline_fixture)."""
+    c, sizes, grams = _letter_grams(pair60k)
+    rng = np.random.default_rng(9)
+    words = sorted({w for i in range(300) for w in pair60k.corpus.text(i).decode().split(" ") if len(w) >= 3})
+    f_even = pair60k.add_filter(range(2, c.n_docs + 1, 2))
+
+    def term():
+        if rng.random() < 0.3:
+            return str(rng.choice(words))
+        if rng.random() < 0.1:
+            return "zq"  # unknown gram: an empty set inside the tree
+        return c.gram(int(rng.choice(grams[:150]))).decode()
+
+    def tree(depth):
+        r = rng.random()
+        if depth == 0 or r < 0.25:
+            return term()
+        if r < 0.5:
+            return ("not", tree(depth - 1))
+        return (("and", "or")[int(rng.integers(0, 2))],) + tuple(tree(depth - 1) for _ in range(int(rng.integers(2, 4))))
+
+    queries = []
+    for it in range(40):
+        nots = [c.gram(int(rng.choice(grams[:200]))).decode()] if it % 4 == 0 else []
+        filters = [(f_even, bool(it % 2))] if it % 5 == 0 else []
+        universe = None if it % 3 else (1, int(c.n_docs * 0.7))
+        queries.append(Query(expr=tree(3), not_terms=nots, filters=filters, limit=int(rng.choice([0, 17])),
+                             descending=bool(it % 2), universe=universe))
+    pair60k.check(queries)
+
+
+def test_pipeline_fixture_boolean_vectors():
+    # tests/server/search_pipeline_test.cpp:916-951 fixture; :1122-1134 "basics OR cats" -> [d1,d3];
+    # :1321-1334 "(basics OR cats)" + and_terms ["old"] -> [d3]; :1336-1348 "basics OR cats NOT old" -> [d1]
+    p = Pair(docs=[(1, "machine learning basics"), (2, "deep learning techniques"), (3, "old article about cats")],
+             ngram=2, kanji=0, cross=False)
+    got = p.dev.search_batch([
+        Query(expr=("or", "basics", "cats"), limit=0, descending=False),
+        Query(expr=("and", ("or", "basics", "cats"), "old"), limit=0, descending=False),
+        Query(expr=("or", "basics", ("and", "cats", ("not", "old"))), limit=0, descending=False),
+    ])
+    assert [g.docs.tolist() for g in got] == [[1, 3], [3], [1]]
+
+
 def test_fuzzy_threshold_terms(pair60k):
     # ExecuteWithFuzzy: per term "at least theta of its grams", AND across terms; checked against the oracle's
     # SearchByThreshold composition
