@@ -656,7 +656,7 @@ struct mgx_batch {
     // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
     // separately, over disjoint item lists, into the same candidate arrays
     mgx::DevBatch dev_wave{};
-    DevBuf d_items_wave;
+    DevBuf d_items_wave, d_tables;
     uint32_t n_items_wave = 0;
     DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident, d_items, d_list_begin;
     uint32_t n_items = 0;
@@ -779,7 +779,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = b->specs[g.qids[i]];
       static const double kMatchesPerUnit = std::getenv("MGX_ITEM_MATCHES") ? atof(std::getenv("MGX_ITEM_MATCHES")) : 256.0;
-      static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 96.0;
+      static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 192.0;
       const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
       tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
@@ -792,8 +792,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     list_begin[n] = static_cast<uint32_t>(items.size());
     for (uint32_t k = 0; k < items.size(); ++k) items[k].list = k;  // candidate lists stay grouped by query
     // launch order: by doc range (coarsely), then by query, so concurrent workgroups share operand tiles in L2
+    static const uint32_t kSortTiles = std::getenv("MGX_SORT_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_SORT_TILES"))) : 16u;
     std::stable_sort(items.begin(), items.end(), [](const DevItem& a, const DevItem& c) {
-      return a.tile_begin / kMaxTilesPerItem < c.tile_begin / kMaxTilesPerItem;
+      return a.tile_begin / kSortTiles < c.tile_begin / kSortTiles;
     });
   }
   const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
@@ -855,6 +856,35 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     MGX_HIP(Upload(b->d_reverse, rev.data(), n));
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
+  }
+  if (score_mode && g.n_items_wave != 0) {
+    // BM25 contribution tables of the wave kernel: idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) for tf 1..8 and every doc
+    // length below table_dl, per query and scored term — bm25_scorer.cpp:80-84 operation by operation (this file is
+    // compiled with -ffp-contract=off), so a table entry is bit-identical to the direct evaluation on the device
+    const uint32_t tdl = g.wplan.table_dl;
+    const uint32_t stride = (g.wplan.max_score * kTableTf * tdl + 1) & ~1u;
+    std::vector<double> tables(static_cast<size_t>(n) * stride, 0.0);
+    for (uint32_t i = 0; i < n; ++i) {
+      if (!on_wave[i]) continue;
+      const QuerySpec& s = b->specs[g.qids[i]];
+      const double one_minus_b = 1.0 - s.b, k1_plus_1 = s.k1 + 1.0, avg = std::max(s.avgdl, 1.0);
+      double* t = tables.data() + static_cast<size_t>(i) * stride;
+      for (size_t term = 0; term < s.score.size(); ++term) {
+        const double idf = s.score[term].idf;
+        for (uint32_t tfi = 1; tfi <= kTableTf; ++tfi) {
+          for (uint32_t dli = 0; dli < tdl; ++dli) {
+            const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
+            const double length_norm = one_minus_b + s.b * dl / avg;
+            const double numerator = tf * k1_plus_1;
+            const double denominator = tf + s.k1 * length_norm;
+            t[(term * kTableTf + tfi - 1) * tdl + dli] = idf * numerator / denominator;
+          }
+        }
+      }
+    }
+    MGX_HIP(Upload(g.d_tables, tables.data(), tables.size()));
+    d.tables = g.d_tables.as<double>();
+    d.table_stride = stride;
   }
   g.dev_wave = d;
   g.dev_wave.items = g.d_items_wave.as<DevItem>();

@@ -640,7 +640,8 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
   o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
   o.prog = at;     at += align8(p.max_instr * 4);
   o.misc = at;     at += 64;
-  o.table = at;    at += p.max_score * kTableTf * p.table_dl * 8;
+  at = (at + 15u) & ~15u;
+  o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
   o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
   o.park = at;     at += kWavesPerBlock * p.max_score * 64 * 12;  // per scored operand: 64 x u64 word + 64 x packed u32 prefix
   o.mbuf = at;     at += kWavesPerBlock * kWaveMatchBuf * 2;
@@ -770,18 +771,13 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   const uint32_t tdl = plan.table_dl;
   for (uint32_t i = tid; i < n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
   for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
-  // BM25 contribution tables: table[(i*kTableTf + tf-1)*tdl + dl]
-  for (uint32_t i = 0; i < q.n_score; ++i) {
-    const double idf = bt.score_terms[q.score_begin + i].idf;
-    for (uint32_t tfi = 1; tfi <= kTableTf; ++tfi) {
-      for (uint32_t dli = tid; dli < tdl; dli += kWaveBlock) {
-        const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
-        const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-        const double numerator = tf * q.k1_plus_1;
-        const double denominator = tf + q.k1 * length_norm;
-        table[(i * kTableTf + tfi - 1) * tdl + dli] = idf * numerator / denominator;
-      }
-    }
+  // BM25 contribution tables table[(i*kTableTf + tf-1)*tdl + dl]: built on the host when the batch was prepared (same
+  // fp64 operation order as bm25_scorer.cpp:80-84), copied here with 16-byte loads
+  {
+    const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
+    const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
+    double2* dst = reinterpret_cast<double2*>(table);
+    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
   }
 
   WaveTopK tk;
