@@ -664,8 +664,17 @@ struct mgx_batch {
   };
   Group score, bitmap;
   // score group outputs
-  DevBuf d_cand_keys, d_cand_docs, d_cand_n, d_top_keys, d_top_docs, d_top_n, d_page_docs, d_page_scores, d_page_n;
-  DevBuf d_total_override;
+  DevBuf d_cand_keys, d_cand_docs, d_cand_n, d_top_keys, d_top_docs, d_top_n;
+  // Everything mgx_batch_fetch needs from a score group sits in ONE device block, copied with one async memcpy into
+  // pinned host memory: [counters n*9 u64 | total_override n u64 | page_scores n*L f64 | page_docs n*L u32 | page_n n u32]
+  DevBuf d_score_out;
+  void* h_score_out = nullptr;  // hipHostMalloc
+  size_t so_override = 0, so_scores = 0, so_docs = 0, so_n = 0, so_bytes = 0;
+  unsigned long long* sc_counters() const { return d_score_out.as<unsigned long long>(); }
+  uint64_t* sc_override() const { return reinterpret_cast<uint64_t*>(static_cast<char*>(d_score_out.p) + so_override); }
+  double* sc_scores() const { return reinterpret_cast<double*>(static_cast<char*>(d_score_out.p) + so_scores); }
+  uint32_t* sc_docs() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(d_score_out.p) + so_docs); }
+  uint32_t* sc_n() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(d_score_out.p) + so_n); }
   uint32_t top_stride = 0, page_stride = 0;
   bool merged_shards = false;
   // bitmap group outputs
@@ -765,7 +774,19 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   MGX_HIP(Upload(g.d_score, score.data(), score.size()));
   MGX_HIP(Upload(g.d_explicit, expl.data(), expl.size(), 4));
   // [n][8] counters followed by [n] pruning bounds: one memset clears both before every execute
-  MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 9 * sizeof(unsigned long long)));
+  if (score_mode) {
+    uint32_t max_limit = 1;
+    for (const DevQuery& q : dq) max_limit = std::max(max_limit, q.limit);
+    b->so_override = static_cast<size_t>(n) * 9 * 8;
+    b->so_scores = b->so_override + static_cast<size_t>(n) * 8;
+    b->so_docs = b->so_scores + static_cast<size_t>(n) * max_limit * 8;
+    b->so_n = b->so_docs + static_cast<size_t>(n) * max_limit * 4;
+    b->so_bytes = b->so_n + static_cast<size_t>(n) * 4;
+    MGX_HIP(b->d_score_out.Alloc(b->so_bytes));
+    MGX_HIP(hipHostMalloc(&b->h_score_out, b->so_bytes, hipHostMallocDefault));
+  } else {
+    MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 9 * sizeof(unsigned long long)));
+  }
   g.h_counters.assign(static_cast<size_t>(n) * 8, 0);
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
@@ -817,7 +838,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   d.score_terms = g.d_score.as<DevScoreTerm>();
   d.explicit_pool = g.d_explicit.as<uint32_t>();
   d.n_queries = n;
-  d.counters = g.d_counters.as<unsigned long long>();
+  d.counters = score_mode ? b->sc_counters() : g.d_counters.as<unsigned long long>();
   d.bounds = score_mode ? d.counters + static_cast<size_t>(n) * 8 : nullptr;
   d.debug_skip = std::getenv("MGX_DEBUG_SKIP") ? static_cast<uint32_t>(atoi(std::getenv("MGX_DEBUG_SKIP"))) : 0u;
   if (score_mode) {
@@ -836,10 +857,6 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     MGX_HIP(b->d_top_keys.Alloc(static_cast<size_t>(n) * max_needed * 8));
     MGX_HIP(b->d_top_docs.Alloc(static_cast<size_t>(n) * max_needed * 4));
     MGX_HIP(b->d_top_n.Alloc(static_cast<size_t>(n) * 4));
-    MGX_HIP(b->d_page_docs.Alloc(static_cast<size_t>(n) * max_limit * 4));
-    MGX_HIP(b->d_page_scores.Alloc(static_cast<size_t>(n) * max_limit * 8));
-    MGX_HIP(b->d_page_n.Alloc(static_cast<size_t>(n) * 4));
-    MGX_HIP(b->d_total_override.Alloc(static_cast<size_t>(n) * 8));
     d.cand_keys = b->d_cand_keys.as<uint64_t>();
     d.cand_docs = b->d_cand_docs.as<uint32_t>();
     d.cand_n = b->d_cand_n.as<uint32_t>();
@@ -921,7 +938,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
   bool timed = false;
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
-    MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
+    MGX_HIP(hipMemsetAsync(b->d_score_out.p, 0, b->so_override, s));
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
@@ -949,8 +966,8 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, 0, g.dev.cand_keys, g.dev.cand_docs,
                                g.dev.cand_n, /*kq=*/0, /*kj=*/g.dev.cand_stride, /*cq=*/0, /*cj=*/1,
                                b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
-                               b->d_top_n.as<uint32_t>(), b->top_stride, b->d_page_docs.as<uint32_t>(),
-                               b->d_page_scores.as<double>(), b->d_page_n.as<uint32_t>(), b->page_stride,
+                               b->d_top_n.as<uint32_t>(), b->top_stride, b->sc_docs(), b->sc_scores(), b->sc_n(),
+                               b->page_stride,
                                g.d_list_begin.as<uint32_t>(), s));
   }
   if (!b->bitmap.qids.empty()) {
@@ -984,27 +1001,27 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   mgx_index* idx = b->idx;
   MGX_HIP(hipSetDevice(idx->device));
   hipStream_t s = b->last_stream;
-  MGX_HIP(hipStreamSynchronize(s));
   b->h_docs.clear();
   b->h_scores.clear();
-  // ---- score group ----
-  std::vector<uint32_t> page_n, page_docs;
-  std::vector<double> page_scores;
-  std::vector<unsigned long long> override_tot;
+  // ---- score group: one async copy of the packed result block, then the only synchronisation of the step ----
+  const uint32_t* page_n = nullptr;
+  const uint32_t* page_docs = nullptr;
+  const double* page_scores = nullptr;
+  const unsigned long long* override_tot = nullptr;
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
     const size_t n = g.qids.size();
-    page_n.resize(n);
-    page_docs.resize(n * b->page_stride);
-    page_scores.resize(n * b->page_stride);
-    MGX_HIP(hipMemcpy(g.h_counters.data(), g.d_counters.p, n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    MGX_HIP(hipMemcpy(page_n.data(), b->d_page_n.p, n * 4, hipMemcpyDeviceToHost));
-    MGX_HIP(hipMemcpy(page_docs.data(), b->d_page_docs.p, page_docs.size() * 4, hipMemcpyDeviceToHost));
-    MGX_HIP(hipMemcpy(page_scores.data(), b->d_page_scores.p, page_scores.size() * 8, hipMemcpyDeviceToHost));
-    if (b->merged_shards) {
-      override_tot.resize(n);
-      MGX_HIP(hipMemcpy(override_tot.data(), b->d_total_override.p, n * 8, hipMemcpyDeviceToHost));
-    }
+    MGX_HIP(hipMemcpyAsync(b->h_score_out, b->d_score_out.p, b->so_bytes, hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+    const char* h = static_cast<const char*>(b->h_score_out);
+    const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(h);
+    for (size_t i = 0; i < n * 8; ++i) g.h_counters[i] = hc[i];
+    override_tot = reinterpret_cast<const unsigned long long*>(h + b->so_override);
+    page_scores = reinterpret_cast<const double*>(h + b->so_scores);
+    page_docs = reinterpret_cast<const uint32_t*>(h + b->so_docs);
+    page_n = reinterpret_cast<const uint32_t*>(h + b->so_n);
+  } else {
+    MGX_HIP(hipStreamSynchronize(s));
   }
   // ---- bitmap group: totals -> page sizes -> expand ----
   std::vector<uint64_t> totals, take, out_off;
@@ -1133,7 +1150,7 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
   MGX_HIP(hipSetDevice(batch->idx->device));
   MGX_HIP(hipMemcpyAsync(blob64, batch->d_top_keys.p, ks * 8, hipMemcpyDeviceToDevice, s));
   // totals: counter slot 4 of every query
-  MGX_HIP(hipMemcpy2DAsync(blob64 + ks, 8, static_cast<char*>(batch->score.d_counters.p) + 4 * 8, 64, 8, n,
+  MGX_HIP(hipMemcpy2DAsync(blob64 + ks, 8, static_cast<char*>(batch->d_score_out.p) + 4 * 8, 64, 8, n,
                            hipMemcpyDeviceToDevice, s));
   MGX_HIP(hipMemcpyAsync(blob32, batch->d_top_docs.p, ks * 4, hipMemcpyDeviceToDevice, s));
   MGX_HIP(hipMemcpyAsync(blob32 + ks, batch->d_top_n.p, n * 4, hipMemcpyDeviceToDevice, s));
@@ -1153,10 +1170,10 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
   MGX_LAUNCH(mgx::LaunchMergeTopK(batch->score.dev.queries, batch->score.d_ident.as<uint32_t>(), n, n_shards, blob64,
                                   blob32, blob32 + static_cast<uint64_t>(n) * batch->top_stride,
                                   /*kq=*/batch->top_stride, /*kj=*/pitch, /*cq=*/1, /*cj=*/pitch, nullptr, nullptr,
-                                  nullptr, 0, batch->d_page_docs.as<uint32_t>(), batch->d_page_scores.as<double>(),
-                                  batch->d_page_n.as<uint32_t>(), batch->page_stride, nullptr, s));
+                                  nullptr, 0, batch->sc_docs(), batch->sc_scores(), batch->sc_n(), batch->page_stride,
+                                  nullptr, s));
   MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch,
-                                  batch->d_total_override.as<uint64_t>(), s));
+                                  batch->sc_override(), s));
   batch->merged_shards = true;
   batch->last_stream = s;
   return MGX_OK;
@@ -1215,6 +1232,7 @@ void mgx_batch_destroy(mgx_batch* batch) {
   }
   if (batch->fork_ev) (void)hipEventDestroy(batch->fork_ev);
   if (batch->join_ev) (void)hipEventDestroy(batch->join_ev);
+  if (batch->h_score_out) (void)hipHostFree(batch->h_score_out);
   delete batch;
 }
 
