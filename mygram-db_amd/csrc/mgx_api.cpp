@@ -653,6 +653,7 @@ struct mgx_batch {
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
     mgx::WavePlan wplan{};
+    bool use_sub = false;  // wave share runs on sub_score_kernel (all operands in bitmap form)
     // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
     // separately, over disjoint item lists, into the same candidate arrays
     mgx::DevBatch dev_wave{};
@@ -763,7 +764,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       wi = std::max<uint32_t>(wi, dq[i].n_instr);
       wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
+    static const bool kWantSub = std::getenv("MGX_SCORE_KERNEL") && std::string(std::getenv("MGX_SCORE_KERNEL")) == "sub";
+    g.use_sub = kWantSub && !has_list && wsc <= kWaveScoreSlots;
+    g.wplan = g.use_sub ? PlanSub(wl, wsc, wi, wc, b->idx->dev.max_doc_len)
+                        : PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
     if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
   if (g.plan.bytes > 160 * 1024)
@@ -803,7 +807,11 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 192.0;
       const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
-      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
+      // whole rounds of the waves of a workgroup
+      if (score_mode && g.use_sub && on_wave[i])
+        tiles = std::max<uint32_t>(1, std::min<uint32_t>(tiles, kMaxTilesPerItem) / kSubWavesHost) * kSubWavesHost;
+      else
+        tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;
       list_begin[i] = static_cast<uint32_t>(items.size());
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), 0};
@@ -817,6 +825,37 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     std::stable_sort(items.begin(), items.end(), [](const DevItem& a, const DevItem& c) {
       return a.tile_begin / kSortTiles < c.tile_begin / kSortTiles;
     });
+    // Inside a doc band, workgroup j runs on XCD j % 8 (round-robin dispatch) and every XCD has its own L2: give each
+    // XCD the queries that share their largest gram, whose tf column and bitmap are the lines the band re-reads most.
+    static const bool kXcdAffinity = std::getenv("MGX_XCD_AFFINITY") ? atoi(std::getenv("MGX_XCD_AFFINITY")) != 0 : true;
+    if (kXcdAffinity && score_mode) {
+      std::vector<uint32_t> heavy(n, 0);
+      for (uint32_t i = 0; i < n; ++i) {
+        uint64_t best = 0;
+        for (const DevLeaf& lf : b->specs[g.qids[i]].leaves) {
+          if (lf.kind != kLeafGramBitmap && lf.kind != kLeafList) continue;
+          const uint64_t sz = b->idx->h_offsets[lf.a + 1] - b->idx->h_offsets[lf.a];
+          if (sz > best) {
+            best = sz;
+            heavy[i] = lf.a;
+          }
+        }
+      }
+      std::vector<DevItem> band;
+      for (size_t lo = 0; lo < items.size();) {
+        size_t hi = lo;
+        while (hi < items.size() && items[hi].tile_begin / kSortTiles == items[lo].tile_begin / kSortTiles) ++hi;
+        std::stable_sort(items.begin() + lo, items.begin() + hi,
+                         [&](const DevItem& a, const DevItem& c) { return heavy[a.query] < heavy[c.query]; });
+        const size_t m = hi - lo, per = (m + 7) / 8;
+        band.assign(items.begin() + lo, items.begin() + hi);
+        size_t w = lo;
+        for (size_t r = 0; r < per; ++r)
+          for (size_t x = 0; x < 8; ++x)
+            if (x * per + r < m) items[w++] = band[x * per + r];
+        lo = hi;
+      }
+    }
   }
   const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
   std::vector<DevItem> items_wave, items_block;
@@ -952,10 +991,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
       MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH((g.use_sub ? LaunchSubScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH((g.use_sub ? LaunchSubScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {

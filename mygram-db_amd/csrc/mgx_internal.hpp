@@ -156,6 +156,7 @@ struct WavePlan {
   uint32_t has_list;      // some operand needs the per-wave scatter bitmap
   uint32_t bytes;
 };
+WavePlan PlanSub(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len);
 WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
                   bool has_list);
 
