@@ -181,6 +181,14 @@ def main():
     except (OSError, KeyError, ValueError):
         traffic = None
 
+    # second denominator: this box's streaming-read bandwidth, measured in the same job (read-only kernel, 2 GiB)
+    measured_peak = None
+    if rank == 0:
+        import ctypes
+        gbs = ctypes.c_double(0.0)
+        if mg._capi.load().mgxt_measure_read_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(gbs)) == 0:
+            measured_peak = gbs.value
+
     results0 = None
     cpu = None
     if rank == 0 and world == 1 and cpu_seconds > 0:
@@ -207,8 +215,12 @@ def main():
                        "dense_threshold": dense if dense else 1.0 / 256, "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 + per-wave top-k; queries with a sparse scored "
-                                   "gram run on mgx::tile_eval_kernel<0> inside the same timed region)",
+                         "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic and k_ms > 0 else None,
+                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k_ms > 0 else None,
+                         "peak_measured_read": measured_peak,
+                         "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
+                         "kernel": "mgx::wave_score_kernel<false> (set algebra + fused BM25 + per-wave top-k; queries with a sparse "
+                                   "scored gram run on mgx::tile_eval_kernel<0> on a side stream inside the same timed region)",
                          "kernel_ms": k_ms, "launches_timed": k_n,
                          "algorithmic_bytes_per_launch": alg_total,
                          "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1],

@@ -132,6 +132,10 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out);
 /* Registers one FilterIndex (column,value) doc set (src/storage/filter_index.h:39-124) as a device bitmap usable
  * as a filter operand; docids ascending, inside the owned range. */
 int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id);
+/* Keeps the NORMALIZED text of the shard's docs resident in HBM (what DocumentStore::VisitNormalizedTextsFor hands
+ * to BM25Scorer::ScoreDocuments, document_store_retrieval.cpp:289-322), by local slot: doc first_doc_id + i is
+ * text_bytes[text_off[i] .. text_off[i+1]). Needed by text-level scored terms (mgx_term.text). Host arrays are copied. */
+int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint64_t* text_off);
 
 /* =====================================================================================================
  * Batched search (new: the reference executes one query per request, request_dispatcher.cpp:93-193)
@@ -151,7 +155,15 @@ typedef struct mgx_term {
   /* FUZZY terms (search_pipeline.cpp:1697-1702): docs in at least `threshold` of the distinct grams;
    * 0 => plain AND of all grams. */
   uint32_t threshold;
-  double idf; /* BM25Scorer::ComputeIDF(N, df) for MGX_SORT_SCORE; scored terms must have n_grams == 1 */
+  double idf; /* BM25Scorer::ComputeIDF(N, df) for MGX_SORT_SCORE when the term is exactly one n-gram (text == NULL):
+               * its tf is the gram's tf column, its df the posting count */
+  /* Text-level scored term (a search term that spans several n-grams, or differs from its single gram): the
+   * normalized term bytes. In a MGX_SORT_SCORE query tf is then BM25Scorer::CountTermOccurrences over the doc text
+   * (bm25_scorer.cpp:27-45) and df is counted per execute as PopulateTermDocumentFrequency does
+   * (search_pipeline.cpp:542-565: docs of the gram AND whose text contains the term); idf = ComputeIDF(total_docs,
+   * df) is evaluated by the library and the `idf` field is ignored. Needs mgx_index_attach_text. NULL otherwise. */
+  const uint8_t* text;
+  uint32_t text_len;
 } mgx_term;
 
 typedef struct mgx_filter {
@@ -235,6 +247,12 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
  * final page and total of every query, on `hip_stream`; read the result with mgx_batch_fetch. */
 int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, const uint32_t* blob32,
                            void* hip_stream);
+/* Text-level terms across shards: df must be table-wide before idf is taken. mgx_batch_count_df enqueues only the df
+ * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per term, in
+ * batch order: query-major, then term order), which the caller sums over ranks in place (one RCCL all-reduce); the next
+ * mgx_batch_execute then uses those counts instead of running its own df pass. *n == 0: nothing to exchange. */
+int mgx_batch_count_df(mgx_batch* batch, void* hip_stream);
+int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n);
 /* Algorithmic bytes of one execute (4*sum|L_i| + R*(T+4) + 12*min(k,R), summed over queries); R is
  * taken from the last fetched execute. */
 int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes, uint64_t* topk_bytes);

@@ -22,6 +22,11 @@ int mgxt_corpus_generate(uint64_t seed, uint64_t global_first, uint64_t n_docs, 
 int mgxt_corpus_view(const mgxt_corpus* c, const uint8_t** text_bytes, const uint64_t** text_off, uint64_t* n_docs);
 void mgxt_corpus_destroy(mgxt_corpus* c);
 
+/* Streaming-read bandwidth of `device` in GB/s: a read-only kernel over a `bytes`-sized buffer (larger than the
+ * 256 MiB Infinity Cache), best of `iters` timed launches (HIP events). bench.py reports it next to the datasheet peak
+ * as the measured roofline denominator. */
+int mgxt_measure_read_bandwidth(int device, uint64_t bytes, int iters, double* gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

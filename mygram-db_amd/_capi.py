@@ -17,11 +17,11 @@ EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
     "mgx_columns_build", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
-    "mgx_index_add_filter_bitmap",
+    "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer",
     "mgx_batch_prepare", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
-    "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy",
+    "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth",
 ]
 
 
@@ -45,7 +45,8 @@ class IndexDesc(C.Structure):
 
 
 class Term(C.Structure):
-    _fields_ = [("gram_ids", C.c_void_p), ("n_grams", C.c_uint32), ("threshold", C.c_uint32), ("idf", C.c_double)]
+    _fields_ = [("gram_ids", C.c_void_p), ("n_grams", C.c_uint32), ("threshold", C.c_uint32), ("idf", C.c_double),
+                ("text", C.c_void_p), ("text_len", C.c_uint32)]
 
 
 class Filter(C.Structure):
@@ -115,6 +116,9 @@ def load():
     L.mgx_batch_prepare.argtypes = [vp, C.POINTER(Query), u32, C.POINTER(vp)]
     L.mgx_batch_execute.argtypes = [vp, vp]
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
+    L.mgx_index_attach_text.argtypes = [vp, vp, vp]
+    L.mgx_batch_count_df.argtypes = [vp, vp]
+    L.mgx_batch_df_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
     L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, vp, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
@@ -133,6 +137,7 @@ def load():
     L.mgxt_corpus_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.mgxt_corpus_destroy.argtypes = [vp]
     L.mgxt_corpus_destroy.restype = None
+    L.mgxt_measure_read_bandwidth.argtypes = [i32, u64, i32, C.POINTER(C.c_double)]
     _lib = L
     return L
 

@@ -23,6 +23,7 @@
 #include "mgx_host.hpp"
 #include "mgx_internal.hpp"
 #include "mgx_launch.hpp"
+#include "mygram_tools.h"
 
 namespace mgx {
 
@@ -107,6 +108,7 @@ struct mgx_index {
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
+  DevBuf d_text, d_text_off;  // mgx_index_attach_text
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -320,7 +322,27 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (out) *out = 0;
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_tfdl.bytes + idx->d_doc_len.bytes +
-         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes;
+         idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes +
+         idx->d_text.bytes + idx->d_text_off.bytes;
+  return MGX_OK;
+}
+
+int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint64_t* text_off) {
+  if (!idx || !text_off) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_attach_text: null argument");
+  const uint64_t n = idx->dev.n_docs;
+  for (uint64_t i = 0; i < n; ++i)
+    if (text_off[i + 1] < text_off[i] || text_off[i + 1] - text_off[i] > 0xFFFFFFFFull)
+      return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_attach_text: offsets must ascend");
+  const uint64_t total = text_off[n] - text_off[0];
+  if (total && !text_bytes) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_attach_text: null text");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  MGX_HIP(hipSetDevice(idx->device));
+  std::vector<uint64_t> rel(n + 1);
+  for (uint64_t i = 0; i <= n; ++i) rel[i] = text_off[i] - text_off[0];
+  MGX_HIP(mgx::Upload(idx->d_text, text_bytes ? text_bytes + text_off[0] : nullptr, total, 16));
+  MGX_HIP(mgx::Upload(idx->d_text_off, rel.data(), rel.size()));
+  idx->dev.text = idx->d_text.as<uint8_t>();
+  idx->dev.text_off = idx->d_text_off.as<uint64_t>();
   return MGX_OK;
 }
 
@@ -389,6 +411,15 @@ struct QuerySpec {
   uint64_t list_postings = 0;  // sum of |L| over gram operands (algorithmic bytes = 4x)
   bool wave_ok = true;         // flat program + every scored term in its own register slot
   double est_density = 0.0;    // estimated fraction of docs that match (work per tile grows with it)
+  // text-level scored terms (mgx_term.text): pattern bytes and the grams whose AND is the term's candidate set
+  struct TextTerm {
+    std::string pattern;
+    std::vector<uint32_t> grams;
+    uint32_t score_index = 0;  // position among the query's scored terms
+  };
+  std::vector<TextTerm> text_terms;
+  uint64_t total_docs = 0;       // N of ComputeIDF for the text-level terms
+  uint32_t pat_off = 0, pat_len = 0;  // kModeTextDf specs: the term in the batch's pattern pool
 };
 
 struct Compiler {
@@ -612,11 +643,31 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
                   "mgx_sort_by_score");
     if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 16 scored terms");
     out->mode = kModeScore;
+    out->total_docs = in.total_docs;
     for (uint32_t i = 0; i < in.n_terms; ++i) {
       const mgx_term& t = in.terms[i];
+      if (t.text != nullptr) {
+        // tf from the doc text, df from a scan of the term's candidates (N1: terms that are not one n-gram)
+        if (!idx->dev.text)
+          return Fail(MGX_ERR_INVALID_ARGUMENT, "text-level scored term without mgx_index_attach_text");
+        if (t.text_len == 0 || t.text_len > 4096)
+          return Fail(MGX_ERR_OUT_OF_RANGE, "text-level scored term: length must be 1..4096 bytes");
+        if (t.threshold != 0 && t.threshold < t.n_grams)
+          return Fail(MGX_ERR_NOT_IMPLEMENTED, "text-level scored term with a fuzzy threshold");
+        QuerySpec::TextTerm tt;
+        tt.pattern.assign(reinterpret_cast<const char*>(t.text), t.text_len);
+        tt.grams.assign(t.gram_ids, t.gram_ids + t.n_grams);
+        tt.score_index = i;
+        out->text_terms.push_back(std::move(tt));
+        DevScoreTerm st{};
+        st.leaf = kNoLeaf;
+        out->wave_ok = false;  // the wave kernel scores from tf columns only
+        out->score.push_back(st);
+        continue;
+      }
       if (t.n_grams != 1)
-        return Fail(MGX_ERR_NOT_IMPLEMENTED,
-                    "BM25 on the device needs every scored term to be exactly one n-gram long (tf column)");
+        return Fail(MGX_ERR_INVALID_ARGUMENT,
+                    "a scored term of several n-grams needs its text (mgx_term.text) for tf and df");
       DevScoreTerm st{};
       st.leaf = c.GramLeaf(t.gram_ids[0]);
       st.idf = t.idf;
@@ -653,7 +704,6 @@ struct mgx_batch {
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
     mgx::WavePlan wplan{};
-    bool use_sub = false;  // wave share runs on sub_score_kernel (all operands in bitmap form)
     // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
     // separately, over disjoint item lists, into the same candidate arrays
     mgx::DevBatch dev_wave{};
@@ -664,6 +714,13 @@ struct mgx_batch {
     std::vector<unsigned long long> h_counters;
   };
   Group score, bitmap;
+  // df pass of the text-level scored terms: one kModeTextDf query per term (the AND of its grams + a text scan)
+  Group textdf;
+  std::vector<mgx::QuerySpec> df_specs;
+  DevBuf d_patterns, d_text_terms, d_text_idf, d_text_df;
+  std::vector<uint64_t> h_text_df, text_total_docs;
+  std::vector<double> h_text_idf;
+  bool df_ready = false;  // mgx_batch_count_df ran (and the caller summed the counts) for the next execute
   // score group outputs
   DevBuf d_cand_keys, d_cand_docs, d_cand_n, d_top_keys, d_top_docs, d_top_n;
   // Everything mgx_batch_fetch needs from a score group sits in ONE device block, copied with one async memcpy into
@@ -695,7 +752,8 @@ struct mgx_batch {
 
 namespace mgx {
 
-static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
+static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const std::vector<QuerySpec>& specs) {
+  const bool score_mode = mode == kModeScore, df_mode = mode == kModeTextDf;
   const uint32_t n = static_cast<uint32_t>(g.qids.size());
   if (n == 0) return MGX_OK;
   std::vector<DevQuery> dq(n);
@@ -705,7 +763,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   std::vector<uint32_t> expl;
   uint32_t max_leaves = 0, max_score = 0, max_stack = 0, max_instr = 0, max_cap = 64;
   for (uint32_t i = 0; i < n; ++i) {
-    const QuerySpec& s = b->specs[g.qids[i]];
+    const QuerySpec& s = specs[g.qids[i]];
     DevQuery& q = dq[i];
     std::memset(&q, 0, sizeof(q));
     q.leaf_begin = static_cast<uint32_t>(leaves.size());
@@ -724,6 +782,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     q.descending = s.reverse;
     q.stack_depth = s.stack_depth;
     q.out_slot = i;
+    q.pat_off = s.pat_off;
+    q.pat_len = s.pat_len;
     q.k1 = s.k1;
     q.b = s.b;
     q.one_minus_b = 1.0 - s.b;
@@ -743,16 +803,16 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     max_stack = std::max(max_stack, q.stack_depth);
     max_instr = std::max(max_instr, q.n_instr);
     max_cap = std::max(max_cap, q.cap);
-    b->list_bytes += 4 * s.list_postings;
+    if (!df_mode) b->list_bytes += 4 * s.list_postings;
   }
-  g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode);
+  g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode || df_mode);
   std::vector<uint8_t> on_wave(n, 0);
   if (score_mode) {
     const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
     uint32_t wl = 0, wsc = 0, wi = 0, wc = 64;
     bool has_list = false;
     for (uint32_t i = 0; i < n; ++i) {
-      const QuerySpec& s = b->specs[g.qids[i]];
+      const QuerySpec& s = specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
       // the wave kernel re-reads the words of scored operands from their dense (bitmap) form
       for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
@@ -764,10 +824,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       wi = std::max<uint32_t>(wi, dq[i].n_instr);
       wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    static const bool kWantSub = std::getenv("MGX_SCORE_KERNEL") && std::string(std::getenv("MGX_SCORE_KERNEL")) == "sub";
-    g.use_sub = kWantSub && !has_list && wsc <= kWaveScoreSlots;
-    g.wplan = g.use_sub ? PlanSub(wl, wsc, wi, wc, b->idx->dev.max_doc_len)
-                        : PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
+    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
     if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
   if (g.plan.bytes > 160 * 1024)
@@ -802,16 +859,13 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   {
     const uint32_t n_tiles = b->idx->dev.n_tiles;
     for (uint32_t i = 0; i < n; ++i) {
-      const QuerySpec& s = b->specs[g.qids[i]];
+      const QuerySpec& s = specs[g.qids[i]];
       static const double kMatchesPerUnit = std::getenv("MGX_ITEM_MATCHES") ? atof(std::getenv("MGX_ITEM_MATCHES")) : 256.0;
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 192.0;
-      const double per_tile = 1.0 + (score_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
+      // (a text scan per candidate costs about what scoring a match does)
+      const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
-      // whole rounds of the waves of a workgroup
-      if (score_mode && g.use_sub && on_wave[i])
-        tiles = std::max<uint32_t>(1, std::min<uint32_t>(tiles, kMaxTilesPerItem) / kSubWavesHost) * kSubWavesHost;
-      else
-        tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;
+      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
       list_begin[i] = static_cast<uint32_t>(items.size());
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), 0};
@@ -832,7 +886,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
       std::vector<uint32_t> heavy(n, 0);
       for (uint32_t i = 0; i < n; ++i) {
         uint64_t best = 0;
-        for (const DevLeaf& lf : b->specs[g.qids[i]].leaves) {
+        for (const DevLeaf& lf : specs[g.qids[i]].leaves) {
           if (lf.kind != kLeafGramBitmap && lf.kind != kLeafList) continue;
           const uint64_t sz = b->idx->h_offsets[lf.a + 1] - b->idx->h_offsets[lf.a];
           if (sz > best) {
@@ -876,6 +930,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
   d.prog = g.d_prog.as<uint32_t>();
   d.score_terms = g.d_score.as<DevScoreTerm>();
   d.explicit_pool = g.d_explicit.as<uint32_t>();
+  d.patterns = b->d_patterns.as<uint8_t>();
+  d.text_terms = b->d_text_terms.as<DevTextTerm>();
+  d.text_idf = b->d_text_idf.as<double>();
   d.n_queries = n;
   d.counters = score_mode ? b->sc_counters() : g.d_counters.as<unsigned long long>();
   d.bounds = score_mode ? d.counters + static_cast<size_t>(n) * 8 : nullptr;
@@ -899,7 +956,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     d.cand_keys = b->d_cand_keys.as<uint64_t>();
     d.cand_docs = b->d_cand_docs.as<uint32_t>();
     d.cand_n = b->d_cand_n.as<uint32_t>();
-  } else {
+  } else if (!df_mode) {
     const size_t tiles = b->idx->dev.n_tiles;
     MGX_HIP(b->d_rbits.Alloc(static_cast<size_t>(n) * tiles * kWordsPerTile * 8));
     MGX_HIP(b->d_tile_cnt.Alloc(static_cast<size_t>(n) * tiles * 4));
@@ -908,7 +965,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     MGX_HIP(b->d_take.Alloc(static_cast<size_t>(n) * 8));
     MGX_HIP(b->d_out_off.Alloc(static_cast<size_t>(n) * 8));
     std::vector<uint32_t> rev(n);
-    for (uint32_t i = 0; i < n; ++i) rev[i] = b->specs[g.qids[i]].reverse;
+    for (uint32_t i = 0; i < n; ++i) rev[i] = specs[g.qids[i]].reverse;
     MGX_HIP(Upload(b->d_reverse, rev.data(), n));
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
@@ -922,7 +979,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, bool score_mode) {
     std::vector<double> tables(static_cast<size_t>(n) * stride, 0.0);
     for (uint32_t i = 0; i < n; ++i) {
       if (!on_wave[i]) continue;
-      const QuerySpec& s = b->specs[g.qids[i]];
+      const QuerySpec& s = specs[g.qids[i]];
       const double one_minus_b = 1.0 - s.b, k1_plus_1 = s.k1 + 1.0, avg = std::max(s.avgdl, 1.0);
       double* t = tables.data() + static_cast<size_t>(i) * stride;
       for (size_t term = 0; term < s.score.size(); ++term) {
@@ -956,12 +1013,68 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
   for (uint32_t i = 0; i < b->n_queries; ++i)
     (b->specs[i].mode == kModeScore ? b->score : b->bitmap).qids.push_back(i);
   MGX_HIP(hipSetDevice(idx->device));
-  int rc = UploadGroup(b.get(), b->score, true);
+  // text-level scored terms: number them across the batch, pool their bytes, and give each one a df query
+  {
+    std::string pool;
+    std::vector<DevTextTerm> tts;
+    for (QuerySpec& s : b->specs) {
+      for (const QuerySpec::TextTerm& tt : s.text_terms) {
+        const uint32_t id = static_cast<uint32_t>(tts.size());
+        DevTextTerm d{static_cast<uint32_t>(pool.size()), static_cast<uint32_t>(tt.pattern.size())};
+        pool += tt.pattern;
+        tts.push_back(d);
+        s.score[tt.score_index].text_term = id;
+        b->text_total_docs.push_back(s.total_docs);
+        QuerySpec ds;
+        ds.mode = kModeTextDf;
+        ds.pat_off = d.pat_off;
+        ds.pat_len = d.pat_len;
+        Compiler c{idx, &ds, {}, 0};
+        double dens = 1.0;
+        uint64_t mn = ~0ull;
+        c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
+        for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
+        for (uint32_t gid : tt.grams) mn = std::min<uint64_t>(mn, idx->h_offsets[gid + 1] - idx->h_offsets[gid]);
+        dens = static_cast<double>(mn) / static_cast<double>(std::max<uint32_t>(idx->dev.n_docs, 1));
+        ds.est_density = dens;
+        if (ds.leaves.size() > kMaxLeaves)
+          return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct n-grams in one text-level term");
+        b->df_specs.push_back(std::move(ds));
+      }
+    }
+    const uint32_t n_tt = static_cast<uint32_t>(tts.size());
+    if (n_tt != 0) {
+      MGX_HIP(Upload(b->d_patterns, reinterpret_cast<const uint8_t*>(pool.data()), pool.size(), 16));
+      MGX_HIP(Upload(b->d_text_terms, tts.data(), tts.size()));
+      MGX_HIP(b->d_text_idf.Alloc(static_cast<size_t>(n_tt) * sizeof(double)));
+      MGX_HIP(b->d_text_df.Alloc(static_cast<size_t>(n_tt) * sizeof(uint64_t)));
+      b->h_text_df.assign(n_tt, 0);
+      b->h_text_idf.assign(n_tt, 0.0);
+      for (uint32_t i = 0; i < n_tt; ++i) b->textdf.qids.push_back(i);
+    }
+  }
+  int rc = UploadGroup(b.get(), b->score, kModeScore, b->specs);
   if (rc) return rc;
-  rc = UploadGroup(b.get(), b->bitmap, false);
+  rc = UploadGroup(b.get(), b->bitmap, kModeBitmap, b->specs);
+  if (rc) return rc;
+  rc = UploadGroup(b.get(), b->textdf, kModeTextDf, b->df_specs);
   if (rc) return rc;
   b->h_results.assign(b->n_queries, mgx_query_result{});
   *out = b.release();
+  return MGX_OK;
+}
+
+// df pass of the text-level terms: counts land in d_text_df[term]
+static int CountDfImpl(mgx_batch* b, hipStream_t s) {
+  mgx_index* idx = b->idx;
+  mgx_batch::Group& g = b->textdf;
+  if (g.qids.empty()) return MGX_OK;
+  MGX_HIP(hipSetDevice(idx->device));
+  MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
+  MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s));
+  // counter slot 5 of every df query -> contiguous u64 array (the buffer ranks all-reduce)
+  MGX_HIP(hipMemcpy2DAsync(b->d_text_df.p, sizeof(uint64_t), g.d_counters.as<unsigned long long>() + 5,
+                           8 * sizeof(uint64_t), sizeof(uint64_t), g.qids.size(), hipMemcpyDeviceToDevice, s));
   return MGX_OK;
 }
 
@@ -975,6 +1088,26 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     MGX_HIP(hipEventCreate(&ev1));
   }
   bool timed = false;
+  if (!b->textdf.qids.empty()) {
+    // text-level terms: df pass (unless the caller ran and reduced it), then idf on the host — log() of the host libm,
+    // like the reference and the oracle, so that scores stay bit-identical — and back to the device
+    if (!b->df_ready) {
+      int rc = CountDfImpl(b, s);
+      if (rc) return rc;
+    }
+    b->df_ready = false;
+    const size_t n_tt = b->h_text_df.size();
+    MGX_HIP(hipMemcpyAsync(b->h_text_df.data(), b->d_text_df.p, n_tt * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n_tt; ++i) {
+      // BM25Scorer::ComputeIDF, bm25_scorer.cpp:14-25
+      const uint64_t total = b->text_total_docs[i];
+      const uint64_t dfc = std::min<uint64_t>(b->h_text_df[i], total);
+      const double nn = static_cast<double>(total), df = static_cast<double>(dfc);
+      b->h_text_idf[i] = total == 0 ? 0.0 : std::log((nn - df + 0.5) / (df + 0.5) + 1.0);
+    }
+    MGX_HIP(hipMemcpyAsync(b->d_text_idf.p, b->h_text_idf.data(), n_tt * sizeof(double), hipMemcpyHostToDevice, s));
+  }
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
     MGX_HIP(hipMemsetAsync(b->d_score_out.p, 0, b->so_override, s));
@@ -991,10 +1124,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
       MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
-      MGX_LAUNCH((g.use_sub ? LaunchSubScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
-      MGX_LAUNCH((g.use_sub ? LaunchSubScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {
@@ -1172,6 +1305,27 @@ int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out) {
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_fetch: ") + e.what());
   }
+}
+
+int mgx_batch_count_df(mgx_batch* batch, void* hip_stream) {
+  if (!batch) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_count_df: null batch");
+  try {
+    int rc = mgx::CountDfImpl(batch, static_cast<hipStream_t>(hip_stream));
+    if (rc) return rc;
+    batch->df_ready = true;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_count_df: ") + e.what());
+  }
+}
+
+int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n) {
+  if (device_counts) *device_counts = nullptr;
+  if (n) *n = 0;
+  if (!batch || !device_counts || !n) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_df_buffer: null argument");
+  *device_counts = batch->d_text_df.as<uint64_t>();
+  *n = static_cast<uint32_t>(batch->h_text_df.size());
+  return MGX_OK;
 }
 
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride,
@@ -1528,3 +1682,42 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
 }
 
 }  // extern "C"
+
+extern "C" int mgxt_measure_read_bandwidth(int device, uint64_t bytes, int iters, double* gb_per_s) {
+  if (!gb_per_s || bytes < (1ull << 20) || iters < 1) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "read probe: bad arguments");
+  *gb_per_s = 0.0;
+  MGX_HIP(hipSetDevice(device));
+  bytes &= ~static_cast<uint64_t>(15);
+  void* buf = nullptr;
+  uint32_t* sink = nullptr;
+  MGX_HIP(hipMalloc(&buf, bytes));
+  if (hipMalloc(reinterpret_cast<void**>(&sink), 4) != hipSuccess) {
+    (void)hipFree(buf);
+    return mgx::Fail(MGX_ERR_INTERNAL, "read probe: hipMalloc failed");
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = MGX_OK;
+  float best = 0.f;
+  do {
+    if (hipMemset(buf, 0x5A, bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess) {
+      rc = mgx::Fail(MGX_ERR_INTERNAL, "read probe: setup failed");
+      break;
+    }
+    for (int i = 0; i < iters + 1 && rc == MGX_OK; ++i) {  // first launch is a warm-up
+      (void)hipEventRecord(e0, nullptr);
+      if (mgx::LaunchReadProbe(buf, bytes, sink, nullptr) != 0) rc = mgx::Fail(MGX_ERR_INTERNAL, "read probe: launch failed");
+      (void)hipEventRecord(e1, nullptr);
+      if (hipEventSynchronize(e1) != hipSuccess) rc = mgx::Fail(MGX_ERR_INTERNAL, "read probe: kernel failed");
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (i > 0 && ms > 0.f && (best == 0.f || ms < best)) best = ms;
+    }
+  } while (false);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(sink);
+  (void)hipFree(buf);
+  if (rc == MGX_OK && best > 0.f) *gb_per_s = static_cast<double>(bytes) / (best * 1e-3) / 1e9;
+  return rc;
+}

@@ -63,15 +63,24 @@ enum Op : uint32_t {
 };
 inline constexpr uint32_t MakeInstr(Op op, uint32_t arg) { return (static_cast<uint32_t>(op) << 24) | (arg & 0xFFFFFFu); }
 
+// A scored term takes its tf either from the tf column of ONE gram operand (term == that gram) or, for terms that span
+// several grams, from the doc text (CountTermOccurrences, bm25_scorer.cpp:27-45); the latter's idf comes from the
+// batch's df pass (DevBatch::text_idf).
+constexpr uint32_t kNoLeaf = 0xFFFFFFFFu;
 struct DevScoreTerm {
-  uint32_t leaf;  // operand whose posting list carries the tf column
-  uint32_t pad;
-  double idf;
+  uint32_t leaf;       // operand whose posting list carries the tf column, or kNoLeaf for a text-level term
+  uint32_t text_term;  // text-level term: index into DevBatch::text_terms / text_idf
+  double idf;          // column terms only
+};
+
+struct DevTextTerm {
+  uint32_t pat_off, pat_len;  // the normalized term in DevBatch::patterns
 };
 
 enum QueryMode : uint32_t {
   kModeScore = 0,   // fused BM25 + per-workgroup top-k
   kModeBitmap = 1,  // result bitmaps + per-tile counts to HBM (expanded to docids afterwards)
+  kModeTextDf = 2,  // df of one text-level term: candidates of its gram AND whose text contains it (counter slot 5)
 };
 
 struct DevQuery {
@@ -85,6 +94,7 @@ struct DevQuery {
   uint32_t descending;
   uint32_t stack_depth;
   uint32_t out_slot;  // row of this query in the per-mode output arrays
+  uint32_t pat_off, pat_len;  // kModeTextDf: the term searched in the candidates' text
   double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;  // BM25 constants, pre-evaluated on the host
 };
 
@@ -103,6 +113,8 @@ struct DevIndex {
   uint64_t gb_tile_stride, gb_row_stride;
   const uint64_t* filter_bitmaps;  // row-major (rows are appended at run time), rows padded off power-of-two strides
   uint64_t fb_tile_stride, fb_row_stride;
+  const uint8_t* text;        // normalized doc text by local slot (mgx_index_attach_text), or null
+  const uint64_t* text_off;   // [n_docs+1]
   uint32_t first_doc_id;
   uint32_t n_docs;
   uint32_t n_tiles;
@@ -124,6 +136,9 @@ struct DevBatch {
   const uint32_t* prog;
   const DevScoreTerm* score_terms;
   const uint32_t* explicit_pool;
+  const uint8_t* patterns;         // text-level terms of the batch, concatenated
+  const DevTextTerm* text_terms;
+  const double* text_idf;          // [n_text_terms] ComputeIDF(N, df) of the current execute's df pass
   uint32_t n_queries;
   // outputs
   unsigned long long* counters;  // [n_queries][8]: funnel slots 0..3, slot 4 = final result count
@@ -156,7 +171,6 @@ struct WavePlan {
   uint32_t has_list;      // some operand needs the per-wave scatter bitmap
   uint32_t bytes;
 };
-WavePlan PlanSub(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len);
 WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
                   bool has_list);
 

@@ -274,10 +274,32 @@ __device__ __forceinline__ void wave_topk_offer(WaveTopK& t, bool valid, uint64_
   t.pend += ns;
 }
 
+// BM25Scorer::CountTermOccurrences (bm25_scorer.cpp:27-45): non-overlapping occurrences of `pat` in `text`, found
+// left to right; with first_only the scan stops at the first one (std::string::find != npos, search_pipeline.cpp:556-563).
+__device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __restrict__ text, uint32_t len,
+                                                           const uint8_t* __restrict__ pat, uint32_t plen,
+                                                           bool first_only) {
+  if (len == 0 || plen == 0 || plen > len) return 0;
+  const uint8_t p0 = pat[0];
+  uint32_t count = 0, pos = 0;
+  while (pos + plen <= len) {
+    bool hit = text[pos] == p0;
+    for (uint32_t k = 1; hit && k < plen; ++k) hit = text[pos + k] == pat[k];
+    if (hit) {
+      ++count;
+      if (first_only) break;
+      pos += plen;
+    } else {
+      ++pos;
+    }
+  }
+  return count;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsOffsets lo_ = carve(plan, MODE == kModeScore);
+  const LdsOffsets lo_ = carve(plan, MODE != kModeBitmap);
   uint64_t* const bm64 = reinterpret_cast<uint64_t*>(smem + lo_.bm);
   uint64_t* const stack = reinterpret_cast<uint64_t*>(smem + lo_.stack);
   uint64_t* const seg_lo = reinterpret_cast<uint64_t*>(smem + lo_.seg_lo);
@@ -318,7 +340,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       tk.docs[i] = 0;
     }
   }
-  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0, cnt_df = 0;
+  const uint32_t n_score = MODE == kModeScore ? q.n_score : 0u;
 
   const uint32_t tile_begin = it.tile_begin;
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
@@ -462,15 +485,18 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 
     // ---- D. (score mode) ranks: exclusive prefix popcounts of the result and of every scored operand ----------
     // quantities are packed two per u32 (a tile holds at most 16384 set bits, so 16 bits each)
-    const uint32_t n_q = 1 + q.n_score;
+    // (text-level terms have no operand of their own: their rows stay unused; kModeTextDf ranks the result only)
+    const uint32_t n_q = 1 + n_score;
     const uint32_t n_packed = (n_q + 1) >> 1;
     uint32_t excl_res = 0;
+    auto operand_pop = [&](uint32_t term) -> uint32_t {
+      const uint32_t lf = bt.score_terms[q.score_begin + term].leaf;
+      return lf == kNoLeaf ? 0u : static_cast<uint32_t>(__popcll(bm64[lf * kBlock + tid]));
+    };
     for (uint32_t pk = 0; pk < n_packed; ++pk) {
       const uint32_t qa = 2 * pk, qb = 2 * pk + 1;
-      const uint32_t va = qa == 0 ? my_cnt
-                                  : __popcll(bm64[bt.score_terms[q.score_begin + qa - 1].leaf * kBlock + tid]);
-      const uint32_t vb =
-          qb < n_q ? __popcll(bm64[bt.score_terms[q.score_begin + qb - 1].leaf * kBlock + tid]) : 0u;
+      const uint32_t va = qa == 0 ? my_cnt : operand_pop(qa - 1);
+      const uint32_t vb = qb < n_q ? operand_pop(qb - 1) : 0u;
       const uint32_t v = va | (vb << 16);
       const uint32_t inc = wave_incl_scan(v);
       if (lane_id() == 63) scan_tot[wave_id() * 16 + pk] = inc;
@@ -515,6 +541,16 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       for (uint32_t j0 = 0; j0 < nm; j0 += kBlock) {
         const uint32_t j = j0 + tid;
         const bool valid = j < nm;
+        if (MODE == kModeTextDf) {
+          // PopulateTermDocumentFrequency (search_pipeline.cpp:556-563): candidates whose text contains the term
+          if (valid) {
+            const uint32_t slot = tile * kTileDocs + matchbuf[j];
+            const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
+            cnt_df += text_count_occurrences(ix.text + t0, static_cast<uint32_t>(t1 - t0), bt.patterns + q.pat_off,
+                                             q.pat_len, true);
+          }
+          continue;
+        }
         double score = 0.0;
         uint32_t doc = 0;
         if (valid) {
@@ -526,15 +562,26 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
           const double dl = static_cast<double>(ix.doc_len[slot]);
           // bm25_scorer.cpp:80-84, same operation order
           const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-          for (uint32_t i = 0; i < q.n_score; ++i) {
+          for (uint32_t i = 0; i < n_score; ++i) {
             const DevScoreTerm st = bt.score_terms[q.score_begin + i];
-            const uint64_t wbits = bm64[st.leaf * kBlock + word];
-            if ((wbits >> bit) & 1ull) {
-              const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
-              const double tf = static_cast<double>(ix.tf[seg_lo[st.leaf] + rank]);
+            double tf = 0.0, idf = st.idf;
+            if (st.leaf == kNoLeaf) {
+              const DevTextTerm tt = bt.text_terms[st.text_term];
+              const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
+              tf = static_cast<double>(text_count_occurrences(ix.text + t0, static_cast<uint32_t>(t1 - t0),
+                                                              bt.patterns + tt.pat_off, tt.pat_len, false));
+              idf = bt.text_idf[st.text_term];
+            } else {
+              const uint64_t wbits = bm64[st.leaf * kBlock + word];
+              if ((wbits >> bit) & 1ull) {
+                const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
+                tf = static_cast<double>(ix.tf[seg_lo[st.leaf] + rank]);
+              }
+            }
+            if (tf > 0.0) {
               const double numerator = tf * q.k1_plus_1;
               const double denominator = tf + q.k1 * length_norm;
-              score += st.idf * numerator / denominator;
+              score += idf * numerator / denominator;
             }
           }
         }
@@ -548,9 +595,9 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 
   // ---- funnel counters: one atomic per wave per slot -----------------------------------------------------------
   {
-    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+    uint32_t v[6] = {cnt0, cnt1, cnt2, cnt3, cnt_res, cnt_df};
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
+    for (int s = 0; s < 6; ++s) {
       uint32_t x = v[s];
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
@@ -694,6 +741,7 @@ __device__ __forceinline__ void wave_scatter_segment(const uint32_t* __restrict_
 
 // This lane's four 64-bit words (256 doc slots) of one operand for `tile`; for scored posting-list operands
 // *seg_rel = list-relative index of the tile's first posting (the rank base of the tf column).
+template <bool kLists>
 __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
                                                    uint32_t tile, uint64_t tile_first, uint64_t* scratch,
                                                    uint64_t (&w)[4], uint32_t* seg_rel) {
@@ -720,7 +768,7 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
       const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
       w[k] = hi_mask & ~lo_mask;
     }
-  } else {  // sorted list (posting list or explicit ids): scatter into this wave's LDS bitmap
+  } else if constexpr (kLists) {  // sorted list (posting list or explicit ids): scatter into this wave's LDS bitmap
     uint64_t a, b;
     const uint32_t* ids;
     if (lf.kind == kLeafList) {
@@ -751,6 +799,7 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
   }
 }
 
+template <bool kLists>  // false: the host found no sorted-list operand in the launch (the usual case for dense grams)
 __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WaveOffsets wo = carve_wave(plan);
@@ -841,7 +890,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
       const DevLeaf lf = leaf[arg];
       uint64_t w[4];
       uint32_t seg_rel;
-      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
+      wave_fetch_operand<kLists>(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (op == kOpLoad) acc[k] = w[k];
@@ -1038,303 +1087,6 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
       }
     }
     (void)have;
-    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// sub-tile scoring kernel: the wave kernel's algorithm at 4096-doc granularity, built for occupancy
-// ---------------------------------------------------------------------------------------------------------------
-//
-// Everything in this path waits on memory (operand words, then tf gathers), a wave cannot overlap its own loads
-// (vector memory returns in issue order), so throughput is set by how many waves a CU keeps in flight. This variant
-// of wave_score_kernel therefore spends as few registers and LDS bytes per wave as possible:
-//   * the unit of work is a SUB-TILE of 4096 docs: a lane owns ONE 64-bit word of every operand (no 4-word arrays);
-//     a wave walks the four sub-tiles of its tile in order, carrying each scored term's posting count, so the rank
-//     base is still tile_off + running popcount;
-//   * per wave LDS is the parked words of the scored terms (768 B each), a 128-entry match buffer and the running
-//     top-k; a workgroup is kSubWaves waves sharing one BM25 table;
-//   * all operands must be in bitmap form (dense grams, filters, ranges); queries with sorted-list operands go to
-//     wave_score_kernel / tile_eval_kernel.
-
-constexpr int kSubWaves = 12;
-constexpr int kSubBlock = kSubWaves * 64;
-constexpr uint32_t kSubMatchBuf = 128;
-constexpr int kSubUnroll = 2;
-constexpr int kSubWordsPerSub = 64;  // 64-bit words per sub-tile
-
-struct SubOffsets {
-  uint32_t prog, leaf, table, park, mbuf, tk_keys, tk_docs, misc, total;
-};
-
-__host__ __device__ inline SubOffsets carve_sub(const WavePlan& p) {
-  SubOffsets o;
-  uint32_t at = 0;
-  o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
-  o.prog = at;     at += align8(p.max_instr * 4);
-  o.misc = at;     at += 128 + kSubWaves * kWaveScoreSlots * 4 + 48;
-  at = (at + 15u) & ~15u;
-  o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
-  o.park = at;     at += kSubWaves * p.max_score * 64 * 12;
-  o.mbuf = at;     at += kSubWaves * kSubMatchBuf * 2;
-  o.tk_keys = at;  at += kSubWaves * 2 * p.max_cap * 8;
-  o.tk_docs = at;  at += kSubWaves * 2 * p.max_cap * 4;
-  o.total = at;
-  return o;
-}
-
-WavePlan PlanSub(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len) {
-  WavePlan p{max_leaves ? max_leaves : 1, max_score, max_instr ? max_instr : 1, max_cap, 0, 0u, 0};
-  p.table_dl = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
-  p.bytes = carve_sub(p).total;
-  return p;
-}
-
-__global__ __launch_bounds__(kSubBlock, 6) void sub_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const SubOffsets so = carve_sub(plan);
-  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + so.leaf);
-  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + so.prog);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + so.misc);
-  double* const table = reinterpret_cast<double*>(smem + so.table);
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + so.mbuf) + static_cast<size_t>(wave) * kSubMatchBuf;
-  uint32_t* const park = reinterpret_cast<uint32_t*>(smem + so.park) + static_cast<size_t>(wave) * plan.max_score * 192;
-
-  const DevItem it = bt.items[blockIdx.x];
-  const uint32_t qi = it.query;
-  const DevQuery q = bt.queries[qi];
-  const uint32_t tdl = plan.table_dl;
-  for (uint32_t i = tid; i < q.n_leaves; i += kSubBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
-  for (uint32_t i = tid; i < q.n_instr; i += kSubBlock) prog[i] = bt.prog[q.prog_begin + i];
-  {
-    const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
-    const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
-    double2* dst = reinterpret_cast<double2*>(table);
-    for (uint32_t e = tid; e < n_pairs; e += kSubBlock) dst[e] = src[e];
-  }
-  // per scored term, in LDS (read once per tile): tf column start, tile_off row
-  uint64_t* const tf_base = reinterpret_cast<uint64_t*>(misc + 16);
-  const uint32_t** const toff_row = reinterpret_cast<const uint32_t**>(misc + 16 + 2 * kWaveScoreSlots);
-  if (tid < q.n_score) {
-    const DevLeaf lf = bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf];
-    tf_base[tid] = ix.offsets[lf.a];
-    toff_row[tid] = ix.tile_off + static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1);
-  }
-
-  WaveTopK tk;
-  tk.cap = q.cap;
-  tk.needed = q.needed;
-  tk.keys = reinterpret_cast<uint64_t*>(smem + so.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
-  tk.docs = reinterpret_cast<uint32_t*>(smem + so.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
-  tk.have = 0;
-  tk.pend = 0;
-  tk.bound_key = 0;
-  tk.bound_doc = 0;
-  tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
-  tk.gbound = 0;
-  for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
-    tk.keys[i] = 0;
-    tk.docs[i] = 0;
-  }
-  __syncthreads();
-
-  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
-  const uint32_t tile_begin = it.tile_begin;
-  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
-  const bool desc = q.descending != 0;
-
-  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kSubWaves) {
-    wave_topk_refresh_gbound(tk);
-    // tf column position of the tile's first posting, per scored term; advanced by the popcounts of finished sub-tiles
-    uint64_t tf_pos[kWaveScoreSlots];
-#pragma unroll
-    for (int i = 0; i < kWaveScoreSlots; ++i) {
-      tf_pos[i] = 0;
-      if (static_cast<uint32_t>(i) < q.n_score) tf_pos[i] = tf_base[i] + toff_row[i][tile];
-    }
-    for (uint32_t sub = 0; sub < 4; ++sub) {
-      // ---- phase A: program on this lane's word ---------------------------------------------------------------------
-      uint64_t acc = 0;
-      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
-        const uint32_t ins = prog[pc];
-        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
-        if (op == kOpCount) {
-          const uint32_t pcnt = __popcll(acc);
-          cnt0 += (arg & 1u) ? pcnt : 0;
-          cnt1 += (arg & 2u) ? pcnt : 0;
-          cnt2 += (arg & 4u) ? pcnt : 0;
-          cnt3 += (arg & 8u) ? pcnt : 0;
-          continue;
-        }
-        const DevLeaf lf = leaf[arg];
-        uint64_t w;
-        const uint32_t widx = sub * kSubWordsPerSub + lane;
-        if (lf.kind == kLeafGramBitmap) {
-          w = ix.gram_bitmaps[tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + widx];
-        } else if (lf.kind == kLeafFilterBitmap) {
-          w = ix.filter_bitmaps[tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + widx];
-        } else {  // kLeafRange
-          const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + static_cast<uint64_t>(widx) * 64;
-          const uint64_t ra = lf.a > s0 ? lf.a - s0 : 0, rb = lf.b > s0 ? lf.b - s0 : 0;
-          const uint64_t hi_mask = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
-          const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
-          w = hi_mask & ~lo_mask;
-        }
-        if (op == kOpLoad) acc = w;
-        else if (op == kOpAnd) acc &= w;
-        else if (op == kOpOr) acc |= w;
-        else if (op == kOpAndNot) acc &= ~w;
-        if (lf.score_slot != kNoSlot) {
-          // park the word with the postings that precede its two halves inside the sub-tile
-          const uint32_t lo = static_cast<uint32_t>(w), hi = static_cast<uint32_t>(w >> 32);
-          uint32_t tot;
-          const uint32_t plo = wave_excl_scan_total(__popc(lo) + __popc(hi), &tot);
-          uint32_t* strip = park + lf.score_slot * 192;
-          strip[lane * 2] = lo;
-          strip[lane * 2 + 1] = hi;
-          strip[128 + lane] = plo | ((plo + __popc(lo)) << 16);
-          if (lane == 0) misc[32 + wave * kWaveScoreSlots + lf.score_slot] = tot;  // sub-tile posting count
-        }
-      }
-      cnt_res += __popcll(acc);
-      const bool skip_scoring = (bt.debug_skip & 2u) != 0;
-
-      // Rounds of at most kSubMatchBuf matches: B consumes bits of acc, C scores.
-      while (!skip_scoring) {
-        uint32_t n_left;
-        const uint32_t my_first = wave_excl_scan_total(__popcll(acc), &n_left);
-        if (n_left == 0) break;  // wave-uniform
-        {
-          uint32_t r = my_first;
-          while (acc != 0 && r < kSubMatchBuf) {
-            const uint32_t bit = __builtin_ctzll(acc);
-            acc &= acc - 1;
-            mbuf[r] = static_cast<uint16_t>((lane << 6) | bit);
-            ++r;
-          }
-        }
-        wave_lds_sync();
-        const uint32_t nm = min(kSubMatchBuf, n_left);
-        for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kSubUnroll) {
-          bool valid[kSubUnroll];
-          uint32_t slot[kSubUnroll], dli[kSubUnroll];
-          uint32_t tfv[kSubUnroll][kWaveScoreSlots];
-#pragma unroll
-          for (int m = 0; m < kSubUnroll; ++m) {
-            valid[m] = false;
-            slot[m] = 0;
-            dli[m] = 0;
-#pragma unroll
-            for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
-            if (j0 + m * 64 < nm) {  // wave-uniform
-              const uint32_t j = j0 + m * 64 + lane;
-              valid[m] = j < nm;
-              if (valid[m]) {
-                const uint32_t e = mbuf[j];
-                const uint32_t owner = e >> 6, bit = e & 63u;
-                const uint32_t hw = owner * 2 + (bit >> 5), mask = 1u << (bit & 31u);
-                slot[m] = tile * kTileDocs + sub * 4096 + owner * 64 + bit;
-                uint32_t packed = 0xFF00u;
-#pragma unroll
-                for (int i = 0; i < kWaveScoreSlots; ++i) {
-                  if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-                    const uint32_t* strip = park + i * 192;
-                    const uint32_t wbits = strip[hw];
-                    if (wbits & mask) {
-                      const uint32_t pp = strip[128 + owner];
-                      const uint32_t rank = ((bit >> 5) ? pp >> 16 : pp & 0xFFFFu) + __popc(wbits & (mask - 1u));
-                      if (i == 0) {
-                        packed = ix.tfdl[tf_pos[0] + rank];
-                        tfv[m][0] = packed & 0xFFu;
-                      } else {
-                        tfv[m][i] = ix.tf[tf_pos[i] + rank];
-                      }
-                    }
-                  }
-                }
-                dli[m] = packed >> 8;
-                if (dli[m] == 255u) dli[m] = ix.doc_len[slot[m]];
-              }
-            }
-          }
-#pragma unroll
-          for (int m = 0; m < kSubUnroll; ++m) {
-            if (j0 + m * 64 < nm) {  // wave-uniform
-              double score = 0.0;
-#pragma unroll
-              for (int i = 0; i < kWaveScoreSlots; ++i) {
-                if (tfv[m][i] != 0) {
-                  if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
-                    score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
-                  } else {  // bm25_scorer.cpp:80-84, same operation order as the table
-                    const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
-                    const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-                    const double numerator = tf * q.k1_plus_1;
-                    const double denominator = tf + q.k1 * length_norm;
-                    score += bt.score_terms[q.score_begin + i].idf * numerator / denominator;
-                  }
-                }
-              }
-              const uint32_t doc = ix.first_doc_id + slot[m];
-              wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
-            }
-          }
-        }
-        wave_lds_sync();
-      }
-      // advance every scored term's column position past this sub-tile's postings
-      wave_lds_sync();
-#pragma unroll
-      for (int i = 0; i < kWaveScoreSlots; ++i)
-        if (static_cast<uint32_t>(i) < q.n_score) tf_pos[i] += misc[32 + wave * kWaveScoreSlots + i];
-      wave_lds_sync();
-    }
-  }
-
-  {
-    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      uint32_t x = v[s];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
-    }
-  }
-
-  wave_topk_truncate(tk);
-  if (lane == 0) misc[wave] = tk.have;
-  __syncthreads();
-  {
-    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + so.tk_keys);
-    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + so.tk_docs);
-    const uint32_t cap = q.cap;
-    uint32_t total = 0;
-    for (int w = 0; w < kSubWaves; ++w) total += min(misc[w], q.needed);
-    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
-    for (uint32_t e = tid; e < kSubWaves * cap; e += kSubBlock) {
-      const uint32_t w = e / cap, i = e % cap;
-      if (i >= min(misc[w], q.needed)) continue;
-      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
-      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
-      uint32_t rank = i;
-      for (uint32_t w2 = 0; w2 < kSubWaves; ++w2) {
-        if (w2 == w) continue;
-        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
-        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
-        uint32_t lo = 0, hi = min(misc[w2], q.needed);
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
-        }
-        rank += lo;
-      }
-      if (rank < q.needed) {
-        bt.cand_keys[obase + rank] = k;
-        bt.cand_docs[obase + rank] = d;
-      }
-    }
     if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
   }
 }
@@ -1637,23 +1389,15 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  if (mode == kModeScore) {
-    if (plan.bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_eval_kernel<kModeScore>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
-      if (e != hipSuccess) return static_cast<int>(e);
-    }
-    hipLaunchKernelGGL(tile_eval_kernel<kModeScore>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s,
-                       ix, bt, plan);
-  } else {
-    if (plan.bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_eval_kernel<kModeBitmap>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
-      if (e != hipSuccess) return static_cast<int>(e);
-    }
-    hipLaunchKernelGGL(tile_eval_kernel<kModeBitmap>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes,
-                       s, ix, bt, plan);
+  auto* kernel = mode == kModeScore    ? &tile_eval_kernel<kModeScore>
+                 : mode == kModeBitmap ? &tile_eval_kernel<kModeBitmap>
+                                       : &tile_eval_kernel<kModeTextDf>;
+  if (plan.bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
   }
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
@@ -1662,26 +1406,31 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  auto* kernel = plan.has_list ? &wave_score_kernel<true> : &wave_score_kernel<false>;
   if (plan.bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wave_score_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(wave_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
 
-int LaunchSubScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
-  const uint64_t grid = bt.n_items;
-  if (grid == 0) return 0;
-  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  if (plan.bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sub_score_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
-    if (e != hipSuccess) return static_cast<int>(e);
+// read-only streaming probe: the box's attainable HBM read bandwidth, the second roofline denominator of bench.py
+typedef uint32_t probe_vec4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_probe_kernel(const probe_vec4* __restrict__ src, uint64_t n_vec, uint32_t* sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec;
+       i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const probe_vec4 v = __builtin_nontemporal_load(src + i);
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
   }
-  hipLaunchKernelGGL(sub_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kSubBlock), plan.bytes, s, ix, bt, plan);
+  if (acc == 0x9E3779B9u) *sink = acc;  // never true for the probe's fill; keeps the loads alive
+}
+
+int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s) {
+  hipLaunchKernelGGL(read_probe_kernel, dim3(256 * 16), dim3(256), 0, s, static_cast<const probe_vec4*>(src), bytes / 16, sink);
   MGX_KCHECK();
   return 0;
 }

@@ -15,8 +15,8 @@ int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* d
                     uint32_t first_doc_id, uint16_t* out, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
-int LaunchSubScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
-constexpr int kSubWavesHost = 12;  // waves per workgroup of sub_score_kernel (items are whole rounds of them)
+int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
+
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
                     uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,

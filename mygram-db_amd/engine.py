@@ -194,6 +194,10 @@ class DeviceIndex:
         check(load().mgx_index_memory_bytes(self._h, C.byref(n)))
         return int(n.value)
 
+    def attach_text(self, corpus):
+        """Normalized doc text into HBM (text-level BM25 terms: tf/df by text scan)."""
+        check(load().mgx_index_attach_text(self._h, corpus.text_bytes.ctypes.data, corpus.text_off.ctypes.data))
+
     def add_filter_bitmap(self, docids):
         a = np.ascontiguousarray(docids, dtype=np.uint32)
         out = C.c_uint32()
@@ -317,6 +321,16 @@ class PreparedBatch:
         check(load().mgx_batch_fetch(self._h, C.byref(v)))
         return v
 
+    def count_df(self, stream=None):
+        """df pass of the text-level terms only (sharded tables reduce the counts before execute)."""
+        check(load().mgx_batch_count_df(self._h, stream))
+
+    def df_buffer(self):
+        """-> (device pointer of the u64 df counts, number of text-level terms)."""
+        p, n = C.c_void_p(), C.c_uint32()
+        check(load().mgx_batch_df_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, int(n.value)
+
     def topk_stride(self):
         s = C.c_uint32()
         check(load().mgx_batch_export_topk(self._h, None, None, C.byref(s), None))
@@ -347,6 +361,8 @@ class Index:
         self.cross_boundary = cross_boundary
         self.columns = Columns(corpus, first_doc_id, ngram_size, kanji_ngram_size, cross_boundary, n_threads)
         self.device_index = DeviceIndex(self.columns, device, dense_threshold)
+        self.corpus = corpus        # the DocumentStore's normalized texts
+        self._text_attached = False
         self.total_docs = self.columns.bm25_doc_count if total_docs is None else total_docs
         self.avg_doc_length = self.columns.avg_doc_length() if avg_doc_length is None else avg_doc_length
         # df source: posting sizes of the WHOLE table (a shard passes the global sizes so idf is identical everywhere)
@@ -362,6 +378,12 @@ class Index:
         return int(self.columns.offsets[gid + 1] - self.columns.offsets[gid])
 
     estimate_posting_size = posting_size  # index.cpp:756-759
+
+    def ensure_text(self):
+        """Text-level BM25 terms scan doc text on the device: upload it on first use."""
+        if not self._text_attached:
+            self.device_index.attach_text(self.corpus)
+            self._text_attached = True
 
     def _ids(self, terms):
         """gram strings -> (ids of known grams, saw_unknown)."""
@@ -489,7 +511,9 @@ class Index:
                 size = 0
                 break
         ti.estimated_size = size
-        ti.df = size if (len(ti.grams) == 1 and size) else None
+        # a term that IS its single n-gram scores from the gram's tf column (df = posting count); any other term
+        # needs the text: tf by CountTermOccurrences, df by PopulateTermDocumentFrequency (search_pipeline.cpp:542-565)
+        ti.df = size if (len(ti.grams) == 1 and size and ti.grams[0] == ti.normalized.encode("utf-8")) else None
         ti.threshold = 0
         if fuzzy and ti.grams:
             # ExecuteWithFuzzy, search_pipeline.cpp:1697-1700
@@ -548,12 +572,16 @@ class Index:
                 ids = np.asarray(t.gram_ids, dtype=np.uint32)
                 keep.append(ids)
                 thr = t.threshold if (q.fuzzy and t.threshold < len(ids)) else 0
-                idf = 0.0
+                idf, text_ptr, text_len = 0.0, None, 0
                 if q.sort_score:
-                    if t.df is None:
-                        raise _capi.MgxError(4, "SORT _score on the device needs single-n-gram terms")
-                    idf = compute_idf(self.total_docs, t.df)
-                cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, idf)
+                    if t.df is None:  # text-level term
+                        self.ensure_text()
+                        tb = np.frombuffer(t.normalized.encode("utf-8"), dtype=np.uint8).copy()
+                        keep.append(tb)
+                        text_ptr, text_len = tb.ctypes.data, len(tb)
+                    else:
+                        idf = compute_idf(self.total_docs, t.df)
+                cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, idf, text_ptr, text_len)
             nts = []
             for nt in q.not_terms:
                 ti = self.term_info(nt)
@@ -566,7 +594,7 @@ class Index:
             for j, t in enumerate(nts):
                 ids = np.asarray(t.gram_ids, dtype=np.uint32)
                 keep.append(ids)
-                cnots[j] = _capi.Term(ids.ctypes.data, len(ids), 0, 0.0)
+                cnots[j] = _capi.Term(ids.ctypes.data, len(ids), 0, 0.0, None, 0)
             cf = (_capi.Filter * max(len(q.filters), 1))()
             for j, (bid, negate) in enumerate(q.filters):
                 cf[j] = _capi.Filter(bid, int(negate))

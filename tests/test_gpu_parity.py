@@ -241,3 +241,72 @@ def test_spans_many_tiles_and_workgroups(score_kernel):
     qs += [Query([c.gram(int(g)).decode() for g in rng.choice(grams[100:300], size=2, replace=False)],
                  limit=25, descending=True) for _ in range(4)]
     p.check(qs)
+
+
+# ---- N1: text-level BM25 terms (terms that are not exactly one n-gram) ------------------------------------------------
+
+def _words(pair, n_docs=400, min_len=3):
+    return sorted({w for i in range(n_docs) for w in pair.corpus.text(i).decode().split(" ") if len(w) >= min_len})
+
+
+def test_text_level_terms_scored_bit_exact(pair60k):
+    # SEARCH "word" AND "other" SORT _score: candidates = AND of each term's grams (verify_text off), tf =
+    # CountTermOccurrences over the text, df = candidates whose text contains the term (search_pipeline.cpp:542-565)
+    c, sizes, grams = _letter_grams(pair60k)
+    words = _words(pair60k)
+    rng = np.random.default_rng(11)
+    queries = []
+    for it in range(36):
+        k = int(rng.integers(1, 4))
+        terms = [str(w) for w in rng.choice(words, size=k, replace=False)]
+        if it % 3 == 0:  # mixed: one single-gram term scored from its tf column next to the text-level ones
+            terms.append(c.gram(int(rng.choice(grams[:40]))).decode())
+        if it % 5 == 0:  # a prefix of a word: n-gram candidates that are real, overlapping occurrences possible
+            terms.append(terms[0][:3])
+        queries.append(Query(terms, sort_score=True, limit=int(rng.choice([1, 10, 50])),
+                             offset=int(rng.choice([0, 0, 2])), descending=bool(it % 4 != 3)))
+    # n-gram false positives: "aaa" on a bigram index has the single gram "aa" but is not that gram
+    queries.append(Query(["the", "and"], sort_score=True, limit=10))
+    queries.append(Query(["THE", "And"], sort_score=True, limit=10))  # normalisation
+    pair60k.check(queries)
+
+
+def test_text_level_false_positives_and_overlaps():
+    # "aba" (grams ab, ba): doc 3 has both grams but not the term -> stays in the result (verify_text off) with the
+    # term's tf 0; "aa" inside "aaaa" counts 2 non-overlapping occurrences; repeated-gram term "aaa" -> gram "aa"
+    docs = [(1, "aba cd"), (2, "ababa cd"), (3, "ab ba cd"), (4, "aaaa cd"), (5, "xaaax aba"), (6, "cd cd"),
+            (7, "aaa aaa aba")]
+    p = Pair(docs=docs)
+    p.check([Query(["aba"], sort_score=True, limit=10),
+             Query(["aba", "cd"], sort_score=True, limit=10),
+             Query(["aaa"], sort_score=True, limit=10),
+             Query(["aaa", "aba"], sort_score=True, limit=10, descending=False),
+             Query(["aba"], ["cd"], sort_score=True, limit=10)])
+
+
+def test_text_level_terms_cjk_trigram():
+    # config-3 shape: 3-gram index over ideographs, terms of 3-6 code points
+    rng = np.random.default_rng(12)
+    chars = [chr(0x4E00 + i) for i in range(40)] + [chr(0x3042 + i) for i in range(8)]
+    docs = [(i + 1, "".join(rng.choice(chars, size=int(rng.integers(8, 40))))) for i in range(3000)]
+    p = Pair(docs=docs, ngram=3, kanji=3)
+    qs = []
+    for it in range(30):
+        d = docs[int(rng.integers(0, len(docs)))][1]
+        terms = []
+        for _ in range(int(rng.integers(1, 3))):
+            L = int(rng.integers(3, 7))
+            s = int(rng.integers(0, max(1, len(d) - L)))
+            terms.append(d[s:s + L])
+        qs.append(Query(terms, sort_score=True, limit=10, descending=bool(it % 2)))
+    p.check(qs)
+
+
+def test_text_level_spans_many_tiles():
+    corpus = mg.Corpus.synthetic(300_000, seed=9)
+    p = Pair(corpus=corpus)
+    words = _words(p, 200, 4)
+    rng = np.random.default_rng(13)
+    qs = [Query([str(w) for w in rng.choice(words, size=2, replace=False)], sort_score=True, limit=10)
+          for _ in range(6)]
+    p.check(qs)
