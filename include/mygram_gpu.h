@@ -145,6 +145,9 @@ int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint6
 #define MGX_SORT_SCORE 1u /* SORT _score: BM25 + ResultSorter::SortByScore */
 
 #define MGX_MAX_TERMS 64u /* query_parser.h:270-272 */
+/* Gram id of an n-gram the TABLE knows but this doc-range shard holds no posting for: an empty doc set. (A gram the
+ * whole table lacks never reaches the device, see mgx_term.) Keeps the batch layout identical on every shard. */
+#define MGX_GRAM_ABSENT 0xFFFFFFFFu
 
 /* One search term = the AND of its (deduplicated) n-grams, as search_pipeline::GenerateTermInfos leaves it
  * (search_pipeline.cpp:569-603). Unknown grams must be resolved by the caller: a positive term with an unknown

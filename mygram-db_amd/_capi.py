@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_gpu.so")
 
 ABI_VERSION = 1
+GRAM_ABSENT = 0xFFFFFFFF
 SORT_DOCID, SORT_SCORE = 0, 1
 
 # every symbol include/mygram_gpu.h and include/mygram_tools.h declare

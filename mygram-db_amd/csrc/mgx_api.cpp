@@ -433,6 +433,14 @@ struct Compiler {
     if (it != gram_leaf.end()) return it->second;
     DevLeaf lf{};
     lf.score_slot = kNoSlot;
+    if (g == MGX_GRAM_ABSENT) {  // known to the table, no posting in this shard: the empty slot range
+      lf.kind = kLeafRange;
+      lf.row = kNoRow;
+      const uint32_t id = static_cast<uint32_t>(q->leaves.size());
+      q->leaves.push_back(lf);
+      gram_leaf[g] = id;
+      return id;
+    }
     lf.a = g;
     lf.row = idx->h_skip_row[g];
     if (idx->h_bm_row[g] != kNoRow) {
@@ -482,7 +490,8 @@ static int ValidateTerm(const mgx_index* idx, const mgx_term& t, const char* wha
   if (t.n_grams == 0 || !t.gram_ids) return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": term without grams");
   if (t.n_grams > 127) return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": more than 127 grams in a term");
   for (uint32_t i = 0; i < t.n_grams; ++i)
-    if (t.gram_ids[i] >= idx->n_grams) return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": unknown gram id");
+    if (t.gram_ids[i] >= idx->n_grams && t.gram_ids[i] != MGX_GRAM_ABSENT)
+      return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": unknown gram id");
   return MGX_OK;
 }
 
@@ -507,7 +516,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       uint64_t mn = ~0ull;
       for (uint32_t g = 0; g < in.terms[i].n_grams; ++g) {
         const uint32_t id = in.terms[i].gram_ids[g];
-        mn = std::min<uint64_t>(mn, idx->h_offsets[id + 1] - idx->h_offsets[id]);
+        mn = std::min<uint64_t>(mn, id == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[id + 1] - idx->h_offsets[id]);
       }
       dens *= static_cast<double>(mn) / static_cast<double>(idx->dev.n_docs);
     }
@@ -672,7 +681,9 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       st.leaf = c.GramLeaf(t.gram_ids[0]);
       st.idf = t.idf;
       // the same gram scored twice (a repeated term) keeps the first slot; the block kernel handles that shape
-      if (out->leaves[st.leaf].score_slot == kNoSlot && i < static_cast<uint32_t>(kWaveScoreSlots))
+      if (t.gram_ids[0] == MGX_GRAM_ABSENT)
+        out->wave_ok = false;  // an empty operand: never a member, contributes nothing
+      else if (out->leaves[st.leaf].score_slot == kNoSlot && i < static_cast<uint32_t>(kWaveScoreSlots))
         out->leaves[st.leaf].score_slot = i;
       else
         out->wave_ok = false;
@@ -1034,7 +1045,8 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
         uint64_t mn = ~0ull;
         c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
         for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
-        for (uint32_t gid : tt.grams) mn = std::min<uint64_t>(mn, idx->h_offsets[gid + 1] - idx->h_offsets[gid]);
+        for (uint32_t gid : tt.grams)
+          mn = std::min<uint64_t>(mn, gid == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[gid + 1] - idx->h_offsets[gid]);
         dens = static_cast<double>(mn) / static_cast<double>(std::max<uint32_t>(idx->dev.n_docs, 1));
         ds.est_density = dens;
         if (ds.leaves.size() > kMaxLeaves)

@@ -36,12 +36,14 @@ def allreduce_sum_i64(values):
 
 
 def global_table_stats(local_keys, local_sizes, local_doc_count, local_total_len):
-    """-> (global posting size per LOCAL gram id, global BM25 doc_count, global total_len).
+    """-> (global posting size per LOCAL gram id, global BM25 doc_count, global total_len, {gram: global size} over
+    the union of all shards' dictionaries).
 
     Shards may hold different gram dictionaries; sizes are aligned by gram bytes."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
-        return np.asarray(local_sizes, dtype=np.int64), int(local_doc_count), int(local_total_len)
+        sizes = np.asarray(local_sizes, dtype=np.int64)
+        return sizes, int(local_doc_count), int(local_total_len), dict(zip(local_keys, sizes.tolist()))
     gathered = [None] * world
     dist.all_gather_object(gathered, list(local_keys))
     union = sorted(set(k for ks in gathered for k in ks))
@@ -52,7 +54,7 @@ def global_table_stats(local_keys, local_sizes, local_doc_count, local_total_len
     vec[-2], vec[-1] = local_doc_count, local_total_len
     tot = allreduce_sum_i64(vec)
     sizes = np.asarray([tot[pos[k]] for k in local_keys], dtype=np.int64)
-    return sizes, int(tot[-2]), int(tot[-1])
+    return sizes, int(tot[-2]), int(tot[-1]), {k: int(tot[i]) for k, i in pos.items()}
 
 
 class ShardedTable:
@@ -68,8 +70,11 @@ class ShardedTable:
         c = self.index.columns
         keys = [c.gram(g) for g in range(c.n_grams)]
         sizes = np.diff(c.offsets.astype(np.int64))
-        gsizes, n, total_len = global_table_stats(keys, sizes, c.bm25_doc_count, c.bm25_total_len)
+        gsizes, n, total_len, gdict = global_table_stats(keys, sizes, c.bm25_doc_count, c.bm25_total_len)
         self.index._global_sizes = gsizes
+        # a gram another shard holds but this one lacks is an empty operand here, not an unknown term: every rank then
+        # compiles the same batch layout (same queries on the device, same text-level terms in the df buffer)
+        self.index._global_dict = gdict
         self.index.total_docs = n
         self.index.avg_doc_length = (total_len / n) if n else 0.0
         self.keys, self.global_sizes = keys, gsizes
@@ -93,12 +98,38 @@ class ShardedTable:
                                 torch.empty(n * self.world, dtype=torch.int32, device=dev))
         return self._blobs[key]
 
+    def _df_tensor(self, batch, ptr, n):
+        """The batch's device df array (u64; counts stay far below 2^63) as an int64 torch tensor, without a copy."""
+        key = ("df", id(batch))
+        if key not in self._blobs:
+            dev = self.index.device_index.device
+
+            class _Arr:  # __cuda_array_interface__ view of library-owned memory
+                __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+            self._blobs[key] = torch.as_tensor(_Arr(), device=torch.device("cuda", dev))
+        return self._blobs[key]
+
     def run(self, batch):
         """Executes `batch` on this shard, exchanges per-shard top-k and merges: afterwards batch.fetch*() returns
         the table-wide page and total on every rank."""
         stream = torch.cuda.current_stream().cuda_stream
+        exchange = self.world > 1 or self.force_exchange
+        if exchange and batch.n:
+            ptr, n_tt = batch.df_buffer()
+            if n_tt:
+                # text-level terms: df is the table-wide count (PopulateTermDocumentFrequency over every shard's
+                # candidates), so the per-shard counts are summed before any rank takes idf
+                batch.count_df(stream)
+                df = self._df_tensor(batch, ptr, n_tt)
+                if dist.get_backend() == "nccl":
+                    dist.all_reduce(df, op=dist.ReduceOp.SUM)
+                else:
+                    h = df.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    df.copy_(h)
         batch.execute(stream)
-        if self.world == 1 and not self.force_exchange:
+        if not exchange:
             return
         b64, b32, g64, g32 = self._buffers(batch)
         batch.export_topk(b64.data_ptr(), b32.data_ptr(), stream)

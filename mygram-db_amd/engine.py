@@ -367,9 +367,13 @@ class Index:
         self.avg_doc_length = self.columns.avg_doc_length() if avg_doc_length is None else avg_doc_length
         # df source: posting sizes of the WHOLE table (a shard passes the global sizes so idf is identical everywhere)
         self._global_sizes = global_posting_sizes
+        self._global_dict = None  # sharded tables: {gram bytes: table-wide posting size} over every shard's dictionary
 
     # ---- dictionary -------------------------------------------------------------------------------------------
     def posting_size(self, gram):
+        if self._global_dict is not None:
+            g = gram.encode("utf-8") if isinstance(gram, str) else bytes(gram)
+            return int(self._global_dict.get(g, 0))
         gid = self.columns.lookup(gram)
         if gid is None:
             return 0
@@ -506,7 +510,8 @@ class Index:
             ps = self.posting_size(g)
             if ps > 0:
                 size = ps if size is None else min(size, ps)
-                ti.gram_ids.append(self.columns.lookup(g))
+                gid = self.columns.lookup(g)  # None: another shard has the gram, this one holds no posting for it
+                ti.gram_ids.append(_capi.GRAM_ABSENT if gid is None else gid)
             else:
                 size = 0
                 break

@@ -36,8 +36,20 @@ def queries_for(keys, sizes, n=24, limit=10):
     return out
 
 
-def oracle_whole():
-    corpus = mg.Corpus.synthetic(N_DOCS, seed=11)
+def table_texts():
+    """The synthetic corpus plus a few grams that exist in ONE half of the doc range only (the synthetic vocabulary
+    puts every letter bigram into every shard)."""
+    base = mg.Corpus.synthetic(N_DOCS, seed=11)
+    texts = [base.text(i) for i in range(N_DOCS)]
+    for i in (100, 2_000, 2_001, 15_000):
+        texts[i] = texts[i] + b" k9k"
+    for i in (25_000, 31_000, 39_999):
+        texts[i] = texts[i] + b" 7j7 the"
+    return texts
+
+
+def oracle_whole(texts):
+    corpus = mg.Corpus.from_texts(texts)
     cols = mg.Columns(corpus, 1, 2, 0, True)
     oidx = O.Index.from_csr(2, 0, True, cols.key_bytes, cols.key_off, cols.offsets, cols.docids)
     ostore = O.DocumentStore.from_arrays(corpus.text_bytes, corpus.text_off)
@@ -50,8 +62,9 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     before, mine = mdist.shard_range(N_DOCS, rank, world)
     assert sum(mdist.shard_range(N_DOCS, r, world)[1] for r in range(world)) == N_DOCS
-    shard_corpus = mg.Corpus.synthetic(mine, seed=11, global_first=before)
-    corpus, cols, oidx, ostore = oracle_whole()
+    texts = table_texts()
+    shard_corpus = mg.Corpus.from_texts(texts[before:before + mine])
+    corpus, cols, oidx, ostore = oracle_whole(texts)
     keys_w = [cols.gram(g) for g in range(cols.n_grams)]
     sizes_w = np.diff(cols.offsets.astype(np.int64))
 
@@ -59,9 +72,11 @@ def main():
         scols = mg.Columns(shard_corpus, 1 + before, 2, 0, True)
         keys = [scols.gram(g) for g in range(scols.n_grams)]
         sizes = np.diff(scols.offsets.astype(np.int64))
-        gsizes, n, total_len = mdist.global_table_stats(keys, sizes, scols.bm25_doc_count, scols.bm25_total_len)
+        gsizes, n, total_len, gdict = mdist.global_table_stats(keys, sizes, scols.bm25_doc_count,
+                                                               scols.bm25_total_len)
         whole = dict(zip(keys_w, sizes_w.tolist()))
         assert [whole[k] for k in keys] == gsizes.tolist()
+        assert gdict == whole  # union of the shards' dictionaries with table-wide sizes
         assert (n, total_len) == (cols.bm25_doc_count, cols.bm25_total_len)
         # per-shard oracle top-k with GLOBAL statistics, gathered and merged == unsharded oracle ranking
         sidx = O.Index.from_csr(2, 0, True, scols.key_bytes, scols.key_off, scols.offsets, scols.docids)
@@ -91,6 +106,30 @@ def main():
         table = mdist.ShardedTable(shard_corpus, first_doc_id=1 + before, device=0)
         assert table.index.total_docs == cols.bm25_doc_count
         qs = queries_for(keys_w, sizes_w)
+        # grams that only ONE shard holds: the other shard must still run the query (as an empty operand) so that
+        # both ranks exchange blobs of the same layout
+        half = 1 + mdist.shard_range(N_DOCS, 1, world)[0]
+        one_sided = []
+        for g in range(cols.n_grams):
+            ids = cols.docids[int(cols.offsets[g]):int(cols.offsets[g + 1])]
+            if len(ids) and (ids.max() < half or ids.min() >= half):
+                one_sided.append(cols.gram(g).decode())
+        assert one_sided
+        common = [k.decode() for k, sz in zip(keys_w, sizes_w) if sz > N_DOCS // 4 and b" " not in k][:3]
+        assert {"k9", "7j"} <= set(one_sided)
+        for i, g in enumerate(one_sided[:8]):
+            qs.append(mg.engine.Query([g, common[i % len(common)]], sort_score=True, limit=10))
+            qs.append(mg.engine.Query([g], sort_score=True, limit=5))
+        # text-level terms (N1): df is summed over the shards before idf is taken
+        words = sorted({w for i in range(0, N_DOCS, 997) for w in corpus.text(i).decode().split(" ") if len(w) >= 3})
+        rng = np.random.default_rng(8)
+        for i in range(8):
+            terms = [str(w) for w in rng.choice(words, size=2, replace=False)]
+            if i % 2:
+                terms.append(common[0])
+            qs.append(mg.engine.Query(terms, sort_score=True, limit=10, offset=i % 3))
+        qs.append(mg.engine.Query(["k9k"], sort_score=True, limit=10))         # text-level, one shard only
+        qs.append(mg.engine.Query(["7j7", "the"], sort_score=True, limit=10))  # ... mixed with a term every shard has
         batch = table.prepare(qs)
         for _ in range(2):  # a prepared batch can be run repeatedly
             table.run(batch)
