@@ -288,6 +288,12 @@ int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, cons
 int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids,
                         const double* idfs, uint32_t n_terms, double avg_doc_length, double k1, double b,
                         double* scores_out);
+/* BM25Scorer::ScoreDocuments for terms of any length: tf counted in the doc text as the reference does
+ * (CountTermOccurrences, bm25_scorer.cpp:27-45). Terms are normalized bytes, term t = term_bytes[term_off[t] ..
+ * term_off[t+1]). Needs mgx_index_attach_text. */
+int mgx_score_documents_text(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint8_t* term_bytes,
+                             const uint32_t* term_off, const double* idfs, uint32_t n_terms, double avg_doc_length,
+                             double k1, double b, double* scores_out);
 /* ResultSorter::SortByScore. */
 int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* scores, uint64_t n, int descending,
                       uint32_t limit, uint32_t offset, uint32_t** out_docs, uint64_t* out_n);

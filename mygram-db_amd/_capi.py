@@ -18,7 +18,7 @@ EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
     "mgx_columns_build", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
-    "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer",
+    "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
@@ -133,6 +133,7 @@ def load():
     L.mgx_threshold.argtypes = [vp, vp, u32, u32, pp32, p64]
     L.mgx_retain.argtypes = [vp, vp, u64, vp, u32, pp32, p64]
     L.mgx_score_documents.argtypes = [vp, vp, u64, vp, vp, u32, f64, f64, f64, vp]
+    L.mgx_score_documents_text.argtypes = [vp, vp, u64, vp, vp, vp, u32, f64, f64, f64, vp]
     L.mgx_sort_by_score.argtypes = [vp, vp, vp, u64, i32, u32, u32, pp32, p64]
     L.mgxt_corpus_generate.argtypes = [u64, u64, u64, i32, C.POINTER(vp)]
     L.mgxt_corpus_view.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]

@@ -1654,6 +1654,38 @@ int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_c
   }
 }
 
+int mgx_score_documents_text(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint8_t* term_bytes,
+                             const uint32_t* term_off, const double* idfs, uint32_t n_terms, double avg_doc_length,
+                             double k1, double b, double* scores_out) {
+  if (!idx || (n_cand && (!candidates || !scores_out)) || (n_terms && (!term_off || !idfs)))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_score_documents_text: null argument");
+  if (!idx->can_score) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "index was created without tf/doc_len columns");
+  if (!idx->dev.text) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_score_documents_text: no text attached");
+  for (uint32_t i = 0; i < n_terms; ++i)
+    if (term_off[i + 1] < term_off[i]) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "term offsets must ascend");
+  if (n_terms && term_off[n_terms] > term_off[0] && !term_bytes)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_score_documents_text: null term bytes");
+  if (n_cand == 0) return MGX_OK;
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    DevBuf d_c, d_t, d_o, d_i, d_s;
+    MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
+    MGX_HIP(mgx::Upload(d_t, term_bytes, n_terms ? term_off[n_terms] : 0, 16));
+    MGX_HIP(mgx::Upload(d_o, term_off, n_terms + 1));
+    MGX_HIP(mgx::Upload(d_i, idfs, n_terms));
+    MGX_HIP(d_s.Alloc(n_cand * 8));
+    MGX_LAUNCH(mgx::LaunchScoreCandidatesText(idx->dev, d_c.as<uint32_t>(), n_cand, d_t.as<uint8_t>(),
+                                              d_o.as<uint32_t>(), d_i.as<double>(), n_terms, k1, b, avg_doc_length,
+                                              d_s.as<double>(), idx->stream));
+    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_score_documents_text: ") + e.what());
+  }
+}
+
 int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* scores, uint64_t n, int descending,
                       uint32_t limit, uint32_t offset, uint32_t** out_docs, uint64_t* out_n) {
   if (out_docs) *out_docs = nullptr;

@@ -1314,6 +1314,37 @@ __global__ void score_candidates_kernel(DevIndex ix, const uint32_t* __restrict_
   scores[i] = score;
 }
 
+// BM25Scorer::ScoreDocuments as the reference runs it — every term's tf counted in the doc text (bm25_scorer.cpp:71-91)
+// — for terms of any length. One thread per candidate.
+__global__ void score_candidates_text_kernel(DevIndex ix, const uint32_t* __restrict__ cand, uint64_t n_cand,
+                                             const uint8_t* __restrict__ term_bytes,
+                                             const uint32_t* __restrict__ term_off, const double* __restrict__ idfs,
+                                             uint32_t n_terms, double k1, double b, double one_minus_b,
+                                             double k1_plus_1, double avgdl_clamped, double* __restrict__ scores) {
+  const uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_cand) return;
+  const uint32_t d = cand[i];
+  double score = 0.0;
+  if (d >= ix.first_doc_id && static_cast<uint64_t>(d) - ix.first_doc_id < ix.n_docs) {
+    const uint32_t slot = d - ix.first_doc_id;
+    const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
+    if (t1 > t0) {  // empty / missing text => 0.0
+      const double dl = static_cast<double>(ix.doc_len[slot]);
+      const double length_norm = one_minus_b + b * dl / avgdl_clamped;
+      for (uint32_t t = 0; t < n_terms; ++t) {
+        const double tf = static_cast<double>(text_count_occurrences(
+            ix.text + t0, static_cast<uint32_t>(t1 - t0), term_bytes + term_off[t], term_off[t + 1] - term_off[t], false));
+        if (tf > 0.0) {
+          const double numerator = tf * k1_plus_1;
+          const double denominator = tf + k1 * length_norm;
+          score += idfs[t] * numerator / denominator;
+        }
+      }
+    }
+  }
+  scores[i] = score;
+}
+
 // (key, docid') pairs for ResultSorter::SortByScore on arbitrary inputs, and the trivial one-list "merge" input.
 __global__ void make_sort_keys_kernel(const uint32_t* __restrict__ docs, const double* __restrict__ scores,
                                       uint64_t n, int descending, uint64_t* __restrict__ keys,
@@ -1496,6 +1527,17 @@ int LaunchScoreCandidates(const DevIndex& ix, const uint32_t* cand, uint64_t n_c
   const double avg = avgdl > 1.0 ? avgdl : 1.0;
   hipLaunchKernelGGL(score_candidates_kernel, dim3(static_cast<uint32_t>((n_cand + 255) / 256)), dim3(256), 0, s, ix,
                      cand, n_cand, grams, idfs, n_terms, k1, b, 1.0 - b, k1 + 1.0, avg, scores);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchScoreCandidatesText(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint8_t* term_bytes,
+                              const uint32_t* term_off, const double* idfs, uint32_t n_terms, double k1, double b,
+                              double avgdl, double* scores, hipStream_t s) {
+  if (n_cand == 0) return 0;
+  const double avg = avgdl > 1.0 ? avgdl : 1.0;
+  hipLaunchKernelGGL(score_candidates_text_kernel, dim3(static_cast<uint32_t>((n_cand + 255) / 256)), dim3(256), 0, s,
+                     ix, cand, n_cand, term_bytes, term_off, idfs, n_terms, k1, b, 1.0 - b, k1 + 1.0, avg, scores);
   MGX_KCHECK();
   return 0;
 }

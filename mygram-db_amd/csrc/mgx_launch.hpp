@@ -34,6 +34,9 @@ int LaunchRetain(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, cons
 int LaunchScoreCandidates(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint32_t* grams,
                           const double* idfs, uint32_t n_terms, double k1, double b, double avgdl, double* scores,
                           hipStream_t s);
+int LaunchScoreCandidatesText(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint8_t* term_bytes,
+                              const uint32_t* term_off, const double* idfs, uint32_t n_terms, double k1, double b,
+                              double avgdl, double* scores, hipStream_t s);
 int LaunchSortByScore(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint32_t lo,
                       uint32_t hi, uint64_t* keys_tmp, uint32_t* dprime_tmp, uint32_t* out, hipStream_t s);
 

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <deque>
 #include <map>
 #include <mutex>
 
@@ -224,7 +225,11 @@ std::string Index::Finalize() const {
   if (mgx_index_create(&d, &impl_->dev) != MGX_OK) {
     impl_->last_error = mgx_last_error();
     impl_->dev = nullptr;
+    return impl_->last_error;
   }
+  // the shim's Index is also the DocumentStore of the texts it was given: BM25 terms longer than one n-gram are
+  // counted in the text on the device
+  if (mgx_index_attach_text(impl_->dev, bytes.data(), off.data()) != MGX_OK) impl_->last_error = mgx_last_error();
   return impl_->last_error;
 }
 
@@ -396,21 +401,34 @@ Expected<std::vector<ScoredDoc>, Error> BM25Scorer::ScoreDocuments(const std::ve
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
   std::vector<uint32_t> ids;
   std::vector<double> idfs;
+  bool all_single_gram = true;
   for (size_t i = 0; i < search_terms.size(); ++i) {
     uint32_t id = 0xFFFFFFFFu;  // a term no document contains: tf = 0 everywhere
-    const auto grams = GenerateQueryNgrams(search_terms[i], index.GetNgramSize(), im->query_kanji,
-                                           index.GetCrossBoundaryNgrams());
-    if (grams.size() > 1)
-      return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
-                                      "BM25 on the device needs search terms that are one n-gram long (SURVEY.md 8f N1)"));
+    auto grams = GenerateQueryNgrams(search_terms[i], index.GetNgramSize(), im->query_kanji,
+                                     index.GetCrossBoundaryNgrams());
+    DeduplicateSorted(grams);
+    if (grams.size() != 1 || grams[0] != search_terms[i]) all_single_gram = false;
     im->Lookup(search_terms[i], &id) || (id = 0xFFFFFFFFu);
     ids.push_back(id);
     idfs.push_back(ComputeIDF(total_docs, term_doc_freqs[i]));
   }
   std::vector<double> scores(candidates.size(), 0.0);
-  const int rc = mgx_score_documents(im->dev, candidates.data(), candidates.size(), ids.data(), idfs.data(),
-                                     static_cast<uint32_t>(ids.size()), avg_doc_length, params.k1, params.b,
-                                     scores.data());
+  int rc;
+  if (all_single_gram) {  // every term is one n-gram: its tf column holds CountTermOccurrences already
+    rc = mgx_score_documents(im->dev, candidates.data(), candidates.size(), ids.data(), idfs.data(),
+                             static_cast<uint32_t>(ids.size()), avg_doc_length, params.k1, params.b, scores.data());
+  } else {  // bm25_scorer.cpp:71-91 literally: every term counted in the text
+    std::vector<uint8_t> bytes;
+    std::vector<uint32_t> off(search_terms.size() + 1, 0);
+    for (size_t i = 0; i < search_terms.size(); ++i) {
+      bytes.insert(bytes.end(), search_terms[i].begin(), search_terms[i].end());
+      off[i + 1] = static_cast<uint32_t>(bytes.size());
+    }
+    bytes.resize(bytes.size() + 16);
+    rc = mgx_score_documents_text(im->dev, candidates.data(), candidates.size(), bytes.data(), off.data(),
+                                  idfs.data(), static_cast<uint32_t>(search_terms.size()), avg_doc_length, params.k1,
+                                  params.b, scores.data());
+  }
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   std::vector<ScoredDoc> out;
   out.reserve(candidates.size());
@@ -457,6 +475,7 @@ struct TermInfo {  // search_pipeline.h:44-55
   size_t n_grams = 0;
   uint64_t estimated_size = 0;  // UINT64_MAX = no n-grams
   uint64_t df = 0;
+  bool is_gram = false;  // the term is exactly one n-gram
   std::string normalized;
 };
 }  // namespace
@@ -476,6 +495,7 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   std::vector<std::vector<mgx_term>> term_store, not_store;
   std::vector<std::vector<std::vector<uint32_t>>> id_store;
   std::vector<std::vector<mgx_filter>> filter_store;
+  std::deque<std::string> text_store;  // normalized text-level terms (addresses stay valid as the deque grows)
 
   auto make_info = [&](const std::string& raw) {  // GenerateTermInfos, search_pipeline.cpp:569-603
     TermInfo ti;
@@ -497,7 +517,10 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
       }
     }
     ti.estimated_size = mn;
-    ti.df = (grams.size() == 1 && mn != UINT64_MAX) ? mn : 0;  // one-gram term: df = |posting list|
+    // a term that IS its one n-gram: df = |posting list|, tf = the gram's tf column; any other term is counted in the
+    // text on the device (PopulateTermDocumentFrequency / CountTermOccurrences)
+    ti.is_gram = grams.size() == 1 && grams[0] == ti.normalized;
+    ti.df = (ti.is_gram && mn != UINT64_MAX) ? mn : 0;
     return ti;
   };
 
@@ -529,12 +552,18 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
     auto& ids = id_store.back();
     ids.reserve(q.terms.size() + q.not_terms.size());
     for (const auto& ti : tis) {
-      if (q.sort_by_score && ti.n_grams != 1)
-        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
-                                        "SORT _score on the device needs one-n-gram terms (SURVEY.md 8f N1)"));
       ids.push_back(ti.gram_ids);
-      term_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0,
-                                           q.sort_by_score ? index::BM25Scorer::ComputeIDF(total_docs, ti.df) : 0.0});
+      mgx_term mt{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0};
+      if (q.sort_by_score) {
+        if (ti.is_gram) {
+          mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
+        } else {
+          text_store.push_back(ti.normalized);
+          mt.text = reinterpret_cast<const uint8_t*>(text_store.back().data());
+          mt.text_len = static_cast<uint32_t>(text_store.back().size());
+        }
+      }
+      term_store.back().push_back(mt);
     }
     for (const auto& t : q.not_terms) {  // ApplyNotFilter :871-932
       TermInfo ti = make_info(t);
@@ -542,7 +571,7 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
         return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)"));
       if (ti.estimated_size == 0) continue;  // an unknown gram: the NOT term matches nothing
       ids.push_back(ti.gram_ids);
-      not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0});
+      not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
     }
     for (const auto& f : q.filters) filter_store.back().push_back(mgx_filter{f.first, f.second ? 1u : 0u});
     mgx_query m{};

@@ -471,10 +471,25 @@ class Index:
 
     # ---- BM25Scorer / ResultSorter ----------------------------------------------------------------------------
     def score_documents(self, candidates, terms, dfs, total_docs, avg_doc_length, k1=1.2, b=0.75):
-        """BM25Scorer::ScoreDocuments (bm25_scorer.cpp:47-99) for terms that are exactly one n-gram long."""
+        """BM25Scorer::ScoreDocuments (bm25_scorer.cpp:47-99): tf columns when every term is exactly one n-gram, the
+        doc text otherwise."""
         if len(terms) != len(dfs):
             raise _capi.MgxError(2, "BM25 search_terms and term_doc_freqs must have identical lengths")
         cand = np.ascontiguousarray(candidates, dtype=np.uint32)
+        tis = [self.term_info(t) for t in terms]
+        if any(len(ti.grams) != 1 or ti.grams[0] != ti.normalized.encode("utf-8") for ti in tis):
+            # some term is not one n-gram: count every term in the doc text, like the reference
+            self.ensure_text()
+            tb = [ti.normalized.encode("utf-8") for ti in tis]
+            off = np.zeros(len(tb) + 1, dtype=np.uint32)
+            off[1:] = np.cumsum([len(x) for x in tb])
+            data = np.frombuffer(b"".join(tb) + b"\0" * 16, dtype=np.uint8).copy()
+            idfs = np.asarray([compute_idf(total_docs, d) for d in dfs], dtype=np.float64)
+            out = np.zeros(max(len(cand), 1), dtype=np.float64)
+            check(load().mgx_score_documents_text(self.device_index._h, cand.ctypes.data, len(cand), data.ctypes.data,
+                                                  off.ctypes.data, idfs.ctypes.data, len(tb), float(avg_doc_length),
+                                                  float(k1), float(b), out.ctypes.data))
+            return out[: len(cand)]
         gids = []
         for t in terms:
             gid = self.columns.lookup(t)

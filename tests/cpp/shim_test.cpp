@@ -165,6 +165,49 @@ int main() {
       std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
     }
   }
+  {  // the same worked example on the default bigram index: "alpha" spans four n-grams, so tf comes from the text
+     // (CountTermOccurrences, bm25_scorer.cpp:27-45) — identical scores
+    Index index(2);
+    index.AddDocument(1, "alpha");
+    index.AddDocument(2, "alpha alpha alpha");
+    index.AddDocument(3, "alp pha lph ha");  // every bigram of "alpha", not the term: tf 0 -> score 0
+    auto scored = BM25Scorer::ScoreDocuments({1, 2, 3, 77}, {"alpha"}, {2}, index, 2, 11.0, BM25Params{1.2, 0.75});
+    EXPECT(scored.has_value());
+    if (scored) {
+      EXPECT(std::fabs((*scored)[0].score - 0.2346905145964735) < 1e-12);
+      EXPECT(std::fabs((*scored)[1].score - 0.25652219037288959) < 1e-12);
+      EXPECT((*scored)[2].score == 0.0 && (*scored)[3].score == 0.0);
+    } else {
+      std::printf("ScoreDocuments error: %s\n", scored.error().message().c_str());
+    }
+  }
+  {  // SORT _score through the batched entry with a multi-gram term: df by text scan of the term's candidates
+     // (search_pipeline.cpp:542-565), tf by CountTermOccurrences, ranking by SortByScore
+    using namespace mygramdb::search_pipeline;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning learning techniques");
+    index.AddDocument(3, "old article about cats");
+    index.AddDocument(4, "lea ear arn rni nin ing");  // n-gram candidate without the term
+    std::vector<BatchQuery> qs(1);
+    qs[0].terms = {"learning"};
+    qs[0].sort_by_score = true;
+    qs[0].limit = 10;
+    qs[0].order = SortOrder::DESC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      const double n = 4.0, df = 2.0, avgdl = (23.0 + 33.0 + 22.0 + 23.0) / 4.0;
+      const double idf = std::log((n - df + 0.5) / (df + 0.5) + 1.0);
+      auto bm = [&](double tf, double dl) { return idf * (tf * (1.2 + 1.0)) / (tf + 1.2 * (1.0 - 0.75 + 0.75 * dl / avgdl)); };
+      EXPECT((*r)[0].total == 3);  // verify_text off: doc 4 stays, with score 0
+      EXPECT((*r)[0].results == (V{2, 1, 4}));
+      EXPECT((*r)[0].scores.size() == 3 && (*r)[0].scores[0] == bm(2.0, 33.0) && (*r)[0].scores[1] == bm(1.0, 23.0) &&
+             (*r)[0].scores[2] == 0.0);
+    } else {
+      std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
+    }
+  }
   std::printf("shim_test: %d checks, %d failed\n", g_checked, g_failed);
   return g_failed == 0 ? 0 : 1;
 }

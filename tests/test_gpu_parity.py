@@ -192,11 +192,13 @@ def test_fuzzy_threshold_terms(pair60k):
         assert got.docs.tolist() == want.tolist(), w
 
 
-def test_bm25_golden_vectors_on_device():
+@pytest.mark.parametrize("ngram", [5, 2], ids=["tf-column", "text-level"])
+def test_bm25_golden_vectors_on_device(ngram):
     bm = G.load("bm25.json")
     for v in bm["score_properties"]:
         first, texts = densify([(d, t) for d, t in v["docs"]])
-        idx = mg.Index(texts=texts, first_doc_id=first, ngram_size=5)  # "hello"/"alpha": one 5-gram per term
+        # ngram 5: "hello"/"alpha" are one 5-gram each (tf column); ngram 2: they span four bigrams (tf from the text)
+        idx = mg.Index(texts=texts, first_doc_id=first, ngram_size=ngram)
         if v["assert"] == "raises":
             with pytest.raises(mg._capi.MgxError):
                 idx.score_documents(v["candidates"], v["terms"], v["dfs"], v["N"], v["avgdl"], v["k1"], v["b"])
