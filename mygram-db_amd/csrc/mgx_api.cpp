@@ -690,7 +690,8 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       out->score.push_back(st);
     }
   } else if (in.sort == MGX_SORT_DOCID) {
-    out->mode = kModeBitmap;
+    // a bounded page in docid order needs no materialised result bitmap: count pass + page pass
+    out->mode = (in.limit != 0 && in.limit <= kMaxDocPage) ? kModeDocPage : kModeBitmap;
   } else {
     return Fail(MGX_ERR_INVALID_ARGUMENT, "unknown sort");
   }
@@ -720,6 +721,9 @@ struct mgx_batch {
     mgx::DevBatch dev_wave{};
     DevBuf d_items_wave, d_tables;
     uint32_t n_items_wave = 0;
+    // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
+    mgx::DevBatch dev_page_wave{}, dev_page_block{};
+    DevBuf d_pq_wave, d_pq_block;
     DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident, d_items, d_list_begin;
     uint32_t n_items = 0;
     std::vector<unsigned long long> h_counters;
@@ -748,6 +752,13 @@ struct mgx_batch {
   bool merged_shards = false;
   // bitmap group outputs
   DevBuf d_rbits, d_tile_cnt, d_tile_start, d_totals, d_take, d_out_off, d_reverse, d_out;
+  // docid-page group (kModeDocPage): per-tile counts / rank offsets, and one packed result block
+  // [counters n*8 u64 | totals n u64 | page docs n*stride u32] mirrored in pinned host memory
+  Group page;
+  DevBuf d_ptile_cnt, d_ptile_start, d_page_out;
+  void* h_page_out = nullptr;
+  size_t po_totals = 0, po_docs = 0, po_bytes = 0;
+  uint32_t doc_page_stride = 0;
   // host results
   std::vector<mgx_query_result> h_results;
   std::vector<uint32_t> h_docs;
@@ -764,7 +775,7 @@ struct mgx_batch {
 namespace mgx {
 
 static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const std::vector<QuerySpec>& specs) {
-  const bool score_mode = mode == kModeScore, df_mode = mode == kModeTextDf;
+  const bool score_mode = mode == kModeScore, df_mode = mode == kModeTextDf, page_mode = mode == kModeDocPage;
   const uint32_t n = static_cast<uint32_t>(g.qids.size());
   if (n == 0) return MGX_OK;
   std::vector<DevQuery> dq(n);
@@ -838,6 +849,21 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
     if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
+  if (page_mode) {
+    // flat programs count on the wave kernel (registers only, two tiles in flight per wave)
+    const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
+    uint32_t wl = 1, wi = 1;
+    bool has_list = false;
+    for (uint32_t i = 0; i < n; ++i) {
+      const QuerySpec& s = specs[g.qids[i]];
+      if (!(allow && s.wave_ok)) continue;
+      on_wave[i] = 1;
+      for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;
+      wl = std::max<uint32_t>(wl, dq[i].n_leaves);
+      wi = std::max<uint32_t>(wi, dq[i].n_instr);
+    }
+    g.wplan = WavePlan{wl, 0, wi, 0, 0, has_list ? 1u : 0u, 0};
+  }
   if (g.plan.bytes > 160 * 1024)
     return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
   MGX_HIP(Upload(g.d_queries, dq.data(), dq.size()));
@@ -856,6 +882,18 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     b->so_bytes = b->so_n + static_cast<size_t>(n) * 4;
     MGX_HIP(b->d_score_out.Alloc(b->so_bytes));
     MGX_HIP(hipHostMalloc(&b->h_score_out, b->so_bytes, hipHostMallocDefault));
+  } else if (page_mode) {
+    uint32_t max_limit = 1;
+    for (const DevQuery& q : dq) max_limit = std::max(max_limit, q.limit);
+    b->doc_page_stride = max_limit;
+    b->po_totals = static_cast<size_t>(n) * 8 * 8;
+    b->po_docs = b->po_totals + static_cast<size_t>(n) * 8;
+    b->po_bytes = b->po_docs + static_cast<size_t>(n) * max_limit * 4;
+    MGX_HIP(b->d_page_out.Alloc(b->po_bytes));
+    MGX_HIP(hipHostMalloc(&b->h_page_out, b->po_bytes, hipHostMallocDefault));
+    const size_t tiles = b->idx->dev.n_tiles;
+    MGX_HIP(b->d_ptile_cnt.Alloc(static_cast<size_t>(n) * tiles * 4));
+    MGX_HIP(b->d_ptile_start.Alloc(static_cast<size_t>(n) * tiles * 8));
   } else {
     MGX_HIP(g.d_counters.Alloc(static_cast<size_t>(n) * 9 * sizeof(unsigned long long)));
   }
@@ -945,7 +983,16 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   d.text_terms = b->d_text_terms.as<DevTextTerm>();
   d.text_idf = b->d_text_idf.as<double>();
   d.n_queries = n;
-  d.counters = score_mode ? b->sc_counters() : g.d_counters.as<unsigned long long>();
+  d.counters = score_mode  ? b->sc_counters()
+               : page_mode ? b->d_page_out.as<unsigned long long>()
+                           : g.d_counters.as<unsigned long long>();
+  if (page_mode) {
+    d.tile_cnt = b->d_ptile_cnt.as<uint32_t>();
+    d.tile_start = b->d_ptile_start.as<uint64_t>();
+    d.totals = reinterpret_cast<const uint64_t*>(static_cast<const char*>(b->d_page_out.p) + b->po_totals);
+    d.page_docs = reinterpret_cast<uint32_t*>(static_cast<char*>(b->d_page_out.p) + b->po_docs);
+    d.page_stride = b->doc_page_stride;
+  }
   d.bounds = score_mode ? d.counters + static_cast<size_t>(n) * 8 : nullptr;
   d.debug_skip = std::getenv("MGX_DEBUG_SKIP") ? static_cast<uint32_t>(atoi(std::getenv("MGX_DEBUG_SKIP"))) : 0u;
   if (score_mode) {
@@ -967,7 +1014,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     d.cand_keys = b->d_cand_keys.as<uint64_t>();
     d.cand_docs = b->d_cand_docs.as<uint32_t>();
     d.cand_n = b->d_cand_n.as<uint32_t>();
-  } else if (!df_mode) {
+  } else if (!df_mode && !page_mode) {
     const size_t tiles = b->idx->dev.n_tiles;
     MGX_HIP(b->d_rbits.Alloc(static_cast<size_t>(n) * tiles * kWordsPerTile * 8));
     MGX_HIP(b->d_tile_cnt.Alloc(static_cast<size_t>(n) * tiles * 4));
@@ -1013,6 +1060,18 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   g.dev_wave = d;
   g.dev_wave.items = g.d_items_wave.as<DevItem>();
   g.dev_wave.n_items = g.n_items_wave;
+  if (page_mode) {
+    std::vector<DevItem> pw, pb;
+    for (uint32_t i = 0; i < n; ++i) (on_wave[i] ? pw : pb).push_back(DevItem{i, 0, 0, 0});
+    MGX_HIP(Upload(g.d_pq_wave, pw.data(), pw.size()));
+    MGX_HIP(Upload(g.d_pq_block, pb.data(), pb.size()));
+    g.dev_page_wave = d;
+    g.dev_page_wave.items = g.d_pq_wave.as<DevItem>();
+    g.dev_page_wave.n_items = static_cast<uint32_t>(pw.size());
+    g.dev_page_block = d;
+    g.dev_page_block.items = g.d_pq_block.as<DevItem>();
+    g.dev_page_block.n_items = static_cast<uint32_t>(pb.size());
+  }
   return MGX_OK;
 }
 
@@ -1021,8 +1080,10 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
   b->idx = idx;
   b->n_queries = static_cast<uint32_t>(specs.size());
   b->specs = std::move(specs);
-  for (uint32_t i = 0; i < b->n_queries; ++i)
-    (b->specs[i].mode == kModeScore ? b->score : b->bitmap).qids.push_back(i);
+  for (uint32_t i = 0; i < b->n_queries; ++i) {
+    const uint32_t m = b->specs[i].mode;
+    (m == kModeScore ? b->score : m == kModeDocPage ? b->page : b->bitmap).qids.push_back(i);
+  }
   MGX_HIP(hipSetDevice(idx->device));
   // text-level scored terms: number them across the batch, pool their bytes, and give each one a df query
   {
@@ -1070,6 +1131,8 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
   rc = UploadGroup(b.get(), b->bitmap, kModeBitmap, b->specs);
   if (rc) return rc;
   rc = UploadGroup(b.get(), b->textdf, kModeTextDf, b->df_specs);
+  if (rc) return rc;
+  rc = UploadGroup(b.get(), b->page, kModeDocPage, b->specs);
   if (rc) return rc;
   b->h_results.assign(b->n_queries, mgx_query_result{});
   *out = b.release();
@@ -1168,6 +1231,24 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     MGX_LAUNCH(LaunchScanTiles(g.dev.tile_cnt, static_cast<uint32_t>(g.qids.size()), idx->dev.n_tiles,
                                b->d_tile_start.as<uint64_t>(), b->d_totals.as<uint64_t>(), s));
   }
+  if (!b->page.qids.empty()) {
+    mgx_batch::Group& g = b->page;
+    const uint32_t n = static_cast<uint32_t>(g.qids.size());
+    MGX_HIP(hipMemsetAsync(b->d_page_out.p, 0, b->po_docs, s));  // counters + totals
+    if (b->timing && !timed) {
+      MGX_HIP(hipEventRecord(ev0, s));
+    }
+    MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, s));
+    MGX_LAUNCH(LaunchTileEval(kModeDocCount, idx->dev, g.dev, g.plan, s));
+    if (b->timing && !timed) {
+      MGX_HIP(hipEventRecord(ev1, s));
+      timed = true;
+    }
+    MGX_LAUNCH(LaunchScanTiles(g.dev.tile_cnt, n, idx->dev.n_tiles, b->d_ptile_start.as<uint64_t>(),
+                               const_cast<uint64_t*>(g.dev.totals), s));
+    MGX_LAUNCH(LaunchWavePage(idx->dev, g.dev_page_wave, g.wplan, s));
+    MGX_LAUNCH(LaunchTileEval(kModeDocPage, idx->dev, g.dev_page_block, g.plan, s));
+  }
   if (b->timing) {
     if (timed) {
       b->events.emplace_back(ev0, ev1);
@@ -1185,13 +1266,13 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   mgx_index* idx = b->idx;
   MGX_HIP(hipSetDevice(idx->device));
   hipStream_t s = b->last_stream;
-  b->h_docs.clear();
-  b->h_scores.clear();
   // ---- score group: one async copy of the packed result block, then the only synchronisation of the step ----
   const uint32_t* page_n = nullptr;
   const uint32_t* page_docs = nullptr;
   const double* page_scores = nullptr;
   const unsigned long long* override_tot = nullptr;
+  if (!b->page.qids.empty())
+    MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
     const size_t n = g.qids.size();
@@ -1239,34 +1320,55 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
       MGX_HIP(hipStreamSynchronize(s));
     }
   }
+  const uint32_t* dp_docs = nullptr;
+  if (!b->page.qids.empty()) {
+    const char* h = static_cast<const char*>(b->h_page_out);
+    const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(h);
+    for (size_t i = 0; i < b->page.qids.size() * 8; ++i) b->page.h_counters[i] = hc[i];
+    dp_docs = reinterpret_cast<const uint32_t*>(h + b->po_docs);
+  }
   // ---- assemble in batch order ----
   std::vector<uint32_t> pos_in_group(b->n_queries, 0);
   for (size_t i = 0; i < b->score.qids.size(); ++i) pos_in_group[b->score.qids[i]] = static_cast<uint32_t>(i);
   for (size_t i = 0; i < b->bitmap.qids.size(); ++i) pos_in_group[b->bitmap.qids[i]] = static_cast<uint32_t>(i);
+  for (size_t i = 0; i < b->page.qids.size(); ++i) pos_in_group[b->page.qids[i]] = static_cast<uint32_t>(i);
+  // two passes: sizes first, then bulk copies (a page-mode batch returns ~10^6 doc ids per fetch)
+  uint64_t n_out = 0;
   for (uint32_t qi = 0; qi < b->n_queries; ++qi) {
     mgx_query_result& r = b->h_results[qi];
     const uint32_t gi = pos_in_group[qi];
-    const bool sc = b->specs[qi].mode == kModeScore;
-    const unsigned long long* c = (sc ? b->score : b->bitmap).h_counters.data() + static_cast<size_t>(gi) * 8;
+    const bool sc = b->specs[qi].mode == kModeScore, pg = b->specs[qi].mode == kModeDocPage;
+    const unsigned long long* c =
+        (sc ? b->score : pg ? b->page : b->bitmap).h_counters.data() + static_cast<size_t>(gi) * 8;
     r.total_candidates = c[0];
     r.after_intersection = c[1];
     r.after_not = c[2];
     r.after_filters = c[3];
     r.total = c[4];
-    r.docs_begin = static_cast<uint32_t>(b->h_docs.size());
-    if (sc) {
-      if (b->merged_shards) r.total = override_tot[gi];
-      r.n_docs = page_n[gi];
-      for (uint32_t k = 0; k < r.n_docs; ++k) {
-        b->h_docs.push_back(page_docs[static_cast<size_t>(gi) * b->page_stride + k]);
-        b->h_scores.push_back(page_scores[static_cast<size_t>(gi) * b->page_stride + k]);
-      }
+    if (sc && b->merged_shards) r.total = override_tot[gi];
+    r.n_docs = sc   ? page_n[gi]
+               : pg ? static_cast<uint32_t>(std::min<uint64_t>(r.total, b->specs[qi].limit))
+                    : static_cast<uint32_t>(take[gi]);
+    r.docs_begin = static_cast<uint32_t>(n_out);
+    n_out += r.n_docs;
+  }
+  if (n_out > 0xFFFFFFFFull) return Fail(MGX_ERR_OUT_OF_RANGE, "batch result exceeds 2^32 doc ids");
+  b->h_docs.resize(n_out);
+  b->h_scores.assign(n_out, 0.0);
+  for (uint32_t qi = 0; qi < b->n_queries; ++qi) {
+    const mgx_query_result& r = b->h_results[qi];
+    if (r.n_docs == 0) continue;
+    const uint32_t gi = pos_in_group[qi];
+    const uint32_t mode = b->specs[qi].mode;
+    uint32_t* dst = b->h_docs.data() + r.docs_begin;
+    if (mode == kModeScore) {
+      std::memcpy(dst, page_docs + static_cast<size_t>(gi) * b->page_stride, r.n_docs * sizeof(uint32_t));
+      std::memcpy(b->h_scores.data() + r.docs_begin, page_scores + static_cast<size_t>(gi) * b->page_stride,
+                  r.n_docs * sizeof(double));
+    } else if (mode == kModeDocPage) {
+      std::memcpy(dst, dp_docs + static_cast<size_t>(gi) * b->doc_page_stride, r.n_docs * sizeof(uint32_t));
     } else {
-      r.n_docs = static_cast<uint32_t>(take[gi]);
-      for (uint64_t k = 0; k < take[gi]; ++k) {
-        b->h_docs.push_back(bm_docs[out_off[gi] + k]);
-        b->h_scores.push_back(0.0);
-      }
+      std::memcpy(dst, bm_docs.data() + out_off[gi], r.n_docs * sizeof(uint32_t));
     }
   }
   out->n_queries = b->n_queries;
@@ -1343,7 +1445,7 @@ int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n)
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride,
                           void* hip_stream) {
   if (!batch || !stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null argument");
-  if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
+  if (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty())
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: every query must be MGX_SORT_SCORE");
   *stride = batch->top_stride;
   if (!blob64 && !blob32) return MGX_OK;  // size query
@@ -1366,7 +1468,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                            void* hip_stream) {
   if (!batch || !blob64 || !blob32 || n_shards == 0)
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: null argument");
-  if (!batch->bitmap.qids.empty() || batch->score.qids.empty())
+  if (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty())
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: every query must be MGX_SORT_SCORE");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
@@ -1438,6 +1540,7 @@ void mgx_batch_destroy(mgx_batch* batch) {
   if (batch->fork_ev) (void)hipEventDestroy(batch->fork_ev);
   if (batch->join_ev) (void)hipEventDestroy(batch->join_ev);
   if (batch->h_score_out) (void)hipHostFree(batch->h_score_out);
+  if (batch->h_page_out) (void)hipHostFree(batch->h_page_out);
   delete batch;
 }
 

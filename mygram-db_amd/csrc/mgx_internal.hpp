@@ -81,7 +81,11 @@ enum QueryMode : uint32_t {
   kModeScore = 0,   // fused BM25 + per-workgroup top-k
   kModeBitmap = 1,  // result bitmaps + per-tile counts to HBM (expanded to docids afterwards)
   kModeTextDf = 2,  // df of one text-level term: candidates of its gram AND whose text contains it (counter slot 5)
+  // docid-ordered page (no SORT _score, 0 < limit <= kMaxDocPage) without materialising result bitmaps:
+  kModeDocCount = 3,  // pass 1: per-tile match counts only (scan_tiles_kernel turns them into rank offsets)
+  kModeDocPage = 4,   // pass 2: re-evaluates only the tiles that hold ranks of the page and writes the page's docids
 };
+constexpr uint32_t kMaxDocPage = 16384;
 
 struct DevQuery {
   uint32_t leaf_begin, n_leaves;
@@ -154,6 +158,11 @@ struct DevBatch {
   // bitmap mode
   uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]
   uint32_t* tile_cnt;    // [n_bitmap_queries][n_tiles]
+  // docid-page mode
+  const uint64_t* tile_start;  // [n][n_tiles] matches before each tile (scan of tile_cnt)
+  const uint64_t* totals;      // [n]
+  uint32_t* page_docs;         // [n][page_stride]
+  uint32_t page_stride;
 };
 
 // LDS bytes the tile kernel needs for a launch whose queries have at most these shapes.

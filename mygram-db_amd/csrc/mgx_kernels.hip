@@ -301,7 +301,7 @@ __device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __rest
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const LdsOffsets lo_ = carve(plan, MODE != kModeBitmap);
+  const LdsOffsets lo_ = carve(plan, MODE == kModeScore || MODE == kModeTextDf);
   uint64_t* const bm64 = reinterpret_cast<uint64_t*>(smem + lo_.bm);
   uint64_t* const stack = reinterpret_cast<uint64_t*>(smem + lo_.stack);
   uint64_t* const seg_lo = reinterpret_cast<uint64_t*>(smem + lo_.seg_lo);
@@ -316,10 +316,31 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   const uint32_t tid = threadIdx.x;
   // items are ordered by doc range first: neighbouring workgroups walk the same tiles for different queries, so
   // shared lists / doc_len hit in L2
-  const DevItem it = bt.items[blockIdx.x];
+  // the page pass has one workgroup per query and finds its own tile range; every other mode walks a host-made item
+  DevItem it = bt.items[blockIdx.x];  // (page pass: only .query is meaningful)
   const uint32_t qi = it.query;
   const DevQuery q = bt.queries[qi];
-  if (q.mode != MODE) return;
+  if (q.mode != MODE && !(MODE == kModeDocCount && q.mode == kModeDocPage)) return;
+  if (MODE == kModeDocPage) {
+    // tiles that hold ranks [lo, hi) of the matches in doc order: tile_start is non-decreasing, so two binary searches
+    const uint64_t total = bt.totals[q.out_slot];
+    const uint64_t take = total < q.limit ? total : q.limit;
+    if (take == 0) return;
+    const uint64_t lo = q.descending ? total - take : 0, hi = q.descending ? total : take;
+    const uint64_t* ts = bt.tile_start + static_cast<uint64_t>(q.out_slot) * ix.n_tiles;
+    uint32_t a = 0, b = ix.n_tiles;  // last tile whose start rank is <= lo
+    while (b - a > 1) {
+      const uint32_t mid = (a + b) >> 1;
+      if (ts[mid] <= lo) a = mid; else b = mid;
+    }
+    uint32_t c = a, d = ix.n_tiles;  // first tile past `a` whose start rank is >= hi
+    while (c < d) {
+      const uint32_t mid = (c + d) >> 1;
+      if (ts[mid] >= hi) d = mid; else c = mid + 1;
+    }
+    it.tile_begin = a;
+    it.n_tiles = max(c, a + 1) - a;
+  }
 
   const uint32_t n_leaves = q.n_leaves;
   for (uint32_t i = tid; i < n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
@@ -349,9 +370,48 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   __syncthreads();
 
-  for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
+  // Page pass: only tiles with matches are visited. A sparse query's page spans hundreds of tiles, almost all empty;
+  // their counts are read 256 at a time into four ballot masks instead of one dependent load per tile.
+  uint64_t* const pmask = reinterpret_cast<uint64_t*>(misc);
+  uint32_t loaded_chunk = 0xFFFFFFFFu;
+  auto next_tile = [&](uint32_t from) -> uint32_t {  // first tile >= from to visit (workgroup-uniform)
+    if (MODE != kModeDocPage) return from;
+    while (from < tile_end) {
+      const uint32_t ck = (from - tile_begin) >> 8;
+      if (ck != loaded_chunk) {
+        __syncthreads();
+        const uint32_t t = tile_begin + ck * 256 + tid;
+        const uint32_t c = t < tile_end ? bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + t] : 0u;
+        const uint64_t m = __ballot(c != 0);
+        if (lane_id() == 0) pmask[wave_id()] = m;
+        __syncthreads();
+        loaded_chunk = ck;
+      }
+      const uint32_t rel = (from - tile_begin) & 255u;
+      for (uint32_t w = rel >> 6; w < 4; ++w) {
+        uint64_t m = pmask[w];
+        if (w == (rel >> 6)) m &= ~0ull << (rel & 63u);
+        if (m) return tile_begin + ck * 256 + w * 64 + static_cast<uint32_t>(__builtin_ctzll(m));
+      }
+      from = tile_begin + (ck + 1) * 256;
+    }
+    return tile_end;
+  };
+  for (uint32_t tile = next_tile(tile_begin); tile < tile_end; tile = next_tile(tile + 1)) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     if (MODE == kModeScore) wave_topk_refresh_gbound(tk);
+    // page pass: ranks [page_lo, page_hi) of the query's matches in doc order are wanted (ascending: the first `limit`,
+    // descending: the last `limit`); a tile whose rank range misses the page is skipped before any operand is read
+    uint64_t page_lo = 0, page_hi = 0, page_total = 0, tile_rank0 = 0;
+    if (MODE == kModeDocPage) {
+      page_total = bt.totals[q.out_slot];
+      const uint64_t take = page_total < q.limit ? page_total : q.limit;
+      page_lo = q.descending ? page_total - take : 0;
+      page_hi = q.descending ? page_total : take;
+      tile_rank0 = bt.tile_start[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile];
+      const uint32_t c = bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile];
+      if (c == 0 || tile_rank0 >= page_hi || tile_rank0 + c <= page_lo) continue;  // workgroup-uniform
+    }
 
     // ---- A. operand setup: segment bounds, and bitmaps that need no scatter -----------------------------------
     if (tid < n_leaves) {
@@ -470,9 +530,31 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     const uint32_t my_cnt = __popcll(acc);
     cnt_res += my_cnt;
 
-    if (MODE == kModeBitmap) {
-      const uint64_t obase = (static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile) * kWordsPerTile;
-      bt.rbits[obase + tid] = acc;
+    if (MODE == kModeDocPage) {
+      const uint32_t inc = wave_incl_scan(my_cnt);
+      if (lane_id() == 63) scan_tot[wave_id()] = inc;
+      __syncthreads();
+      uint32_t off = 0;
+      for (int w = 0; w < wave_id(); ++w) off += scan_tot[w];
+      uint64_t rank = tile_rank0 + off + inc - my_cnt;
+      uint64_t bits = acc;
+      uint32_t* out = bt.page_docs + static_cast<uint64_t>(q.out_slot) * bt.page_stride;
+      while (bits) {
+        const uint32_t bpos = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (rank >= page_lo && rank < page_hi)
+          out[q.descending ? page_total - 1 - rank : rank] =
+              static_cast<uint32_t>(tile_first) + static_cast<uint32_t>(tid) * 64 + bpos;
+        ++rank;
+      }
+      __syncthreads();  // scan_tot and the operand bitmaps are rewritten by the next tile
+      continue;
+    }
+    if (MODE == kModeBitmap || MODE == kModeDocCount) {
+      if (MODE == kModeBitmap) {
+        const uint64_t obase = (static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile) * kWordsPerTile;
+        bt.rbits[obase + tid] = acc;
+      }
       // per-tile count
       uint32_t s = wave_incl_scan(my_cnt);
       if (lane_id() == 63) scan_tot[wave_id()] = s;
@@ -596,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   }
 
   // ---- funnel counters: one atomic per wave per slot -----------------------------------------------------------
-  {
+  if (MODE != kModeDocPage) {  // (the page pass re-evaluates tiles pass 1 has already counted)
     uint32_t v[6] = {cnt0, cnt1, cnt2, cnt3, cnt_res, cnt_df};
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -1094,6 +1176,212 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wave-autonomous count pass of docid-ordered pages (kModeDocPage queries with flat programs)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// Pass 1 of a docid page only needs the number of matches per tile (and the funnel counters): the program runs in
+// registers on 4 words per lane exactly as in wave_score_kernel's operand phase, nothing is written but one u32 per
+// tile. Without sorted-list operands a wave keeps TWO tiles in flight (every operand's loads for both tiles are issued
+// before either is combined), which is what hides the load latency at this register budget.
+
+// This lane's four words of operand `lf` for `tile` (zeros when !active, a wave-uniform flag). Without kLists only
+// bitmap-form and range operands occur, and nothing but the loads themselves stands between two calls.
+template <bool kLists>
+__device__ __forceinline__ void wave_operand_words(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
+                                                   uint32_t tile, bool active, uint64_t* scratch, uint64_t (&w)[4]) {
+  const uint32_t lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = 0;
+  if (!active) return;
+  if (kLists) {
+    uint32_t seg_rel;
+    wave_fetch_operand(ix, bt, lf, tile, static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs,
+                       scratch, w, &seg_rel);
+  } else if (lf.kind == kLeafRange) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + (static_cast<uint64_t>(lane) * 4 + k) * 64;
+      const uint64_t ra = lf.a > s0 ? lf.a - s0 : 0, rb = lf.b > s0 ? lf.b - s0 : 0;
+      const uint64_t hi_mask = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
+      const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
+      w[k] = hi_mask & ~lo_mask;
+    }
+  } else {  // gram or filter bitmap
+    const uint64_t* rowp = lf.kind == kLeafGramBitmap
+                               ? ix.gram_bitmaps + tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + lane * 4
+                               : ix.filter_bitmaps + tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + lane * 4;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(rowp);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + 2);
+    w[0] = (static_cast<uint64_t>(v0.y) << 32) | v0.x;
+    w[1] = (static_cast<uint64_t>(v0.w) << 32) | v0.z;
+    w[2] = (static_cast<uint64_t>(v1.y) << 32) | v1.x;
+    w[3] = (static_cast<uint64_t>(v1.w) << 32) | v1.z;
+  }
+}
+
+template <bool kLists>
+__global__ __launch_bounds__(kBlock) void wave_count_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))));
+  uint64_t* const scratch_all = reinterpret_cast<uint64_t*>(
+      smem + align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))) + align8(plan.max_instr * 4));
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  uint64_t* const scratch = scratch_all + (kLists ? static_cast<size_t>(wave) * kWordsPerTile : 0);
+  constexpr int kT = kLists ? 1 : 2;  // tiles in flight per wave
+  constexpr int kWaves = kBlock / 64;
+
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query;
+  const DevQuery q = bt.queries[qi];
+  for (uint32_t i = tid; i < q.n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
+  __syncthreads();
+
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  const uint32_t tile_begin = it.tile_begin;
+  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
+  for (uint32_t t0 = tile_begin + wave * kT; t0 < tile_end; t0 += kWaves * kT) {
+    uint64_t acc[kT][4];
+#pragma unroll
+    for (int u = 0; u < kT; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[u][k] = 0;
+    for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+      const uint32_t ins = prog[pc];
+      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+      if (op == kOpCount) {
+        uint32_t pcnt = 0;
+#pragma unroll
+        for (int u = 0; u < kT; ++u)
+          pcnt += __popcll(acc[u][0]) + __popcll(acc[u][1]) + __popcll(acc[u][2]) + __popcll(acc[u][3]);
+        cnt0 += (arg & 1u) ? pcnt : 0;
+        cnt1 += (arg & 2u) ? pcnt : 0;
+        cnt2 += (arg & 4u) ? pcnt : 0;
+        cnt3 += (arg & 8u) ? pcnt : 0;
+        continue;
+      }
+      const DevLeaf lf = leaf[arg];
+      uint64_t w[kT][4];
+#pragma unroll
+      for (int u = 0; u < kT; ++u) wave_operand_words<kLists>(ix, bt, lf, t0 + u, t0 + u < tile_end, scratch, w[u]);
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (op == kOpLoad) acc[u][k] = w[u][k];
+          else if (op == kOpAnd) acc[u][k] &= w[u][k];
+          else if (op == kOpOr) acc[u][k] |= w[u][k];
+          else if (op == kOpAndNot) acc[u][k] &= ~w[u][k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kT; ++u) {
+      const uint32_t tile = t0 + u;
+      if (tile < tile_end) {  // wave-uniform
+        uint32_t c = __popcll(acc[u][0]) + __popcll(acc[u][1]) + __popcll(acc[u][2]) + __popcll(acc[u][3]);
+        cnt_res += c;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+        if (lane == 0) bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile] = c;
+      }
+    }
+  }
+  {
+    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t x = v[s];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
+    }
+  }
+}
+
+// Pass 2 of a docid page for flat programs: one workgroup per query, its four waves take the page's non-empty tiles in
+// turn (tile counts are read 256 at a time into ballot masks, every wave for itself: no barrier in the kernel after the
+// program is staged), re-evaluate them in registers and write the doc ids at their rank positions.
+template <bool kLists>
+__global__ __launch_bounds__(kBlock) void wave_page_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))));
+  uint64_t* const scratch_all = reinterpret_cast<uint64_t*>(
+      smem + align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))) + align8(plan.max_instr * 4));
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  uint64_t* const scratch = scratch_all + (kLists ? static_cast<size_t>(wave) * kWordsPerTile : 0);
+  constexpr uint32_t kWaves = kBlock / 64;
+
+  const uint32_t qi = bt.items[blockIdx.x].query;
+  const DevQuery q = bt.queries[qi];
+  const uint64_t total = bt.totals[q.out_slot];
+  const uint64_t take = total < q.limit ? total : q.limit;
+  if (take == 0) return;
+  const uint64_t lo = q.descending ? total - take : 0, hi = q.descending ? total : take;
+  const uint64_t* ts = bt.tile_start + static_cast<uint64_t>(q.out_slot) * ix.n_tiles;
+  const uint32_t* tc = bt.tile_cnt + static_cast<uint64_t>(q.out_slot) * ix.n_tiles;
+  uint32_t a = 0, b = ix.n_tiles;  // last tile whose start rank is <= lo
+  while (b - a > 1) {
+    const uint32_t mid = (a + b) >> 1;
+    if (ts[mid] <= lo) a = mid; else b = mid;
+  }
+  uint32_t c = a, d = ix.n_tiles;  // first tile past `a` whose start rank is >= hi
+  while (c < d) {
+    const uint32_t mid = (c + d) >> 1;
+    if (ts[mid] >= hi) d = mid; else c = mid + 1;
+  }
+  const uint32_t tile_begin = a, tile_end = max(c, a + 1);
+  for (uint32_t i = tid; i < q.n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
+  __syncthreads();
+
+  uint32_t* const out = bt.page_docs + static_cast<uint64_t>(q.out_slot) * bt.page_stride;
+  uint32_t seen = 0;  // non-empty tiles passed so far; this wave takes those with seen % kWaves == wave
+  for (uint32_t base = tile_begin; base < tile_end; base += 256) {
+#pragma unroll 1
+    for (uint32_t sub = 0; sub < 4; ++sub) {
+      const uint32_t t = base + sub * 64 + lane;
+      uint64_t m = __ballot(t < tile_end && tc[t] != 0);
+      while (m) {  // wave-uniform
+        const uint32_t tile = base + sub * 64 + static_cast<uint32_t>(__builtin_ctzll(m));
+        m &= m - 1;
+        if ((seen++ % kWaves) != wave) continue;
+        uint64_t acc[4] = {0, 0, 0, 0};
+        for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+          const uint32_t ins = prog[pc];
+          const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+          if (op == kOpCount) continue;
+          uint64_t w[4];
+          wave_operand_words<kLists>(ix, bt, leaf[arg], tile, true, scratch, w);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (op == kOpLoad) acc[k] = w[k];
+            else if (op == kOpAnd) acc[k] &= w[k];
+            else if (op == kOpOr) acc[k] |= w[k];
+            else if (op == kOpAndNot) acc[k] &= ~w[k];
+          }
+        }
+        const uint32_t mine = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+        uint64_t rank = ts[tile] + (wave_incl_scan(mine) - mine);
+        const uint32_t doc0 = ix.first_doc_id + tile * kTileDocs + lane * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint64_t bits = acc[k];
+          while (bits) {
+            const uint32_t bpos = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (rank >= lo && rank < hi) out[q.descending ? total - 1 - rank : rank] = doc0 + k * 64 + bpos;
+            ++rank;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // merge of sorted candidate lists (per-workgroup lists of one shard, or per-shard lists of one query)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -1422,15 +1710,48 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  auto* kernel = mode == kModeScore    ? &tile_eval_kernel<kModeScore>
-                 : mode == kModeBitmap ? &tile_eval_kernel<kModeBitmap>
-                                       : &tile_eval_kernel<kModeTextDf>;
+  auto* kernel = mode == kModeScore      ? &tile_eval_kernel<kModeScore>
+                 : mode == kModeBitmap   ? &tile_eval_kernel<kModeBitmap>
+                 : mode == kModeDocCount ? &tile_eval_kernel<kModeDocCount>
+                 : mode == kModeDocPage  ? &tile_eval_kernel<kModeDocPage>
+                                         : &tile_eval_kernel<kModeTextDf>;
   if (plan.bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
   hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan);
+  MGX_KCHECK();
+  return 0;
+}
+
+uint32_t WaveCountLdsBytes(const WavePlan& plan) {
+  return align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))) + align8(plan.max_instr * 4) +
+         (plan.has_list ? (kBlock / 64) * kWordsPerTile * 8 : 0);
+}
+
+int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
+  const uint64_t grid = bt.n_items;
+  if (grid == 0) return 0;
+  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  const uint32_t lds = WaveCountLdsBytes(plan);
+  if (plan.has_list)
+    hipLaunchKernelGGL(wave_count_kernel<true>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
+  else
+    hipLaunchKernelGGL(wave_count_kernel<false>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
+  const uint64_t grid = bt.n_items;
+  if (grid == 0) return 0;
+  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  const uint32_t lds = WaveCountLdsBytes(plan);
+  if (plan.has_list)
+    hipLaunchKernelGGL(wave_page_kernel<true>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
+  else
+    hipLaunchKernelGGL(wave_page_kernel<false>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }

@@ -15,6 +15,8 @@ int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* d
                     uint32_t first_doc_id, uint16_t* out, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
+int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
+int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
 
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,

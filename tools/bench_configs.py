@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs that are parity-test shapes, not the bench line
+(cut to one GPU's share). Prints one JSON line per config. Not used by the driver.
+
+    python tools/bench_configs.py cfg5 [--docs 12500000] [--batch 8192] [--steps 10]
+    python tools/bench_configs.py cfg3 [--docs 1000000]  [--batch 4096] [--steps 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+
+def cfg5(mg, args):
+    """Zipf-by-rank 5-term AND + FILTER category = x, docid DESC page of 100 (no SORT _score)."""
+    corpus = mg.Corpus.synthetic(args.docs, seed=42)
+    idx = mg.Index(corpus=corpus, ngram_size=2)
+    c = idx.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    grams = sorted((g for g in range(c.n_grams) if b" " not in c.gram(g)), key=lambda g: -sizes[g])
+    rng = np.random.default_rng(5)
+    cat = rng.integers(0, 5, size=c.n_docs, dtype=np.int64)
+    fids = [idx.device_index.add_filter_bitmap(np.nonzero(cat == v)[0].astype(np.uint32) + 1) for v in range(5)]
+    w = 1.0 / np.arange(1, len(grams) + 1)
+    w /= w.sum()
+    qs = []
+    for _ in range(args.batch):
+        pick = rng.choice(len(grams), size=5, replace=False, p=w)
+        qs.append(mg.engine.Query([c.gram(grams[i]).decode() for i in pick], filters=[(fids[int(rng.integers(0, 5))], False)],
+                                  limit=100, descending=True))
+    return idx, qs, {"workload": "cfg5 share: %d docs, bigram, batch %d x 5-term AND (Zipf by rank) + category filter, "
+                                 "docid DESC limit 100" % (args.docs, args.batch)}
+
+
+def cfg3(mg, args):
+    """CJK trigram index; 50% AND of 2-4 multi-gram terms, 20% (a OR b) AND c, 20% a AND NOT b, 10% FUZZY 1."""
+    rng = np.random.default_rng(3)
+    ideo = [chr(0x4E00 + i) for i in range(3000)]
+    kana = [chr(0x3042 + i) for i in range(80)]
+    wi = 1.0 / np.arange(1, 3001)
+    alphabet = np.asarray(ideo + kana)
+    p = np.concatenate([wi / wi.sum() * 0.9, np.full(80, 0.1 / 80)])
+    lens = rng.integers(16, 49, size=args.docs)
+    flat = rng.choice(len(alphabet), size=int(lens.sum()), p=p)
+    texts, at = [], 0
+    for n in lens:
+        texts.append("".join(alphabet[flat[at:at + n]]))
+        at += n
+    idx = mg.Index(texts=texts, ngram_size=3, kanji_ngram_size=3)
+
+    def term():
+        d = texts[int(rng.integers(0, len(texts)))]
+        n = int(rng.integers(3, 7))
+        s = int(rng.integers(0, max(1, len(d) - n)))
+        return d[s:s + n]
+
+    qs = []
+    for i in range(args.batch):
+        r = i % 10
+        if r < 5:
+            qs.append(mg.engine.Query([term() for _ in range(int(rng.integers(2, 5)))], limit=100))
+        elif r < 7:
+            a, b, cc = term(), term(), term()
+            qs.append(mg.engine.Query(expr=("and", ("or", a, b), cc), limit=100))
+        elif r < 9:
+            qs.append(mg.engine.Query([term()], [term()], limit=100))
+        else:
+            qs.append(mg.engine.Query([term()], fuzzy=1, limit=100))
+    return idx, qs, {"workload": "cfg3 share: %d CJK docs (3000 ideographs Zipf + 80 kana, 16-48 cp), trigram, batch %d "
+                                 "mixed AND/OR/NOT/FUZZY, docid DESC limit 100" % (args.docs, args.batch)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=["cfg3", "cfg5"])
+    ap.add_argument("--docs", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000}[args.config]
+    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192}[args.config]
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    mg = entry.load_package()
+    t0 = time.perf_counter()
+    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5}[args.config](mg, args)
+    batch = idx.prepare(qs)
+    setup = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        batch.execute()
+        batch.fetch_raw()
+    batch.kernel_time_ms()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.execute()
+        batch.fetch_raw()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms, k_n = batch.kernel_time_ms()
+    res = batch.fetch()
+    cfg.update({"index_bytes_hbm": idx.device_index.memory_bytes(), "grams": idx.columns.n_grams,
+                "postings": idx.columns.n_postings, "setup_s": setup,
+                "mean_total": float(np.mean([r.total for r in res])), "device_queries": batch.n})
+    print(json.dumps({"metric": "queries/sec", "value": len(qs) * args.steps / dt, "unit": "queries/s",
+                      "ms_per_step": 1e3 * dt / args.steps, "tile_kernel_ms": k_ms, "steps": args.steps, "config": cfg}))
+
+
+if __name__ == "__main__":
+    main()
