@@ -25,6 +25,15 @@ namespace mgx {
 // ---------------------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// A value every lane of the wave holds identically, moved to scalar registers: loads through LDS or vector memory
+// leave wave-uniform values in VGPRs, and the scoring kernel has none to spare.
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // LDS operations of one wave complete in issue order; this only has to stop the compiler from moving LDS accesses
@@ -239,8 +248,8 @@ __device__ void wave_topk_truncate(WaveTopK& t) {
   }
   wave_lds_sync();
   if (t.have >= t.needed) {
-    t.bound_key = t.keys[t.needed - 1];
-    t.bound_doc = t.docs[t.needed - 1];
+    t.bound_key = wave_uniform(t.keys[t.needed - 1]);
+    t.bound_doc = wave_uniform(t.docs[t.needed - 1]);
     if (t.gbound_ptr && t.bound_key > t.gbound) {
       if (lane == 0) atomicMax(t.gbound_ptr, static_cast<unsigned long long>(t.bound_key));
       t.gbound = t.bound_key;
@@ -250,7 +259,8 @@ __device__ void wave_topk_truncate(WaveTopK& t) {
 
 __device__ __forceinline__ void wave_topk_refresh_gbound(WaveTopK& t) {
   if (t.gbound_ptr) {
-    const uint64_t g = __hip_atomic_load(t.gbound_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t g = wave_uniform(static_cast<uint64_t>(
+        __hip_atomic_load(t.gbound_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     if (g > t.gbound) t.gbound = g;
   }
 }
@@ -939,7 +949,8 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   for (int i = 0; i < kWaveScoreSlots; ++i) {
     sbits[i] = ix.gram_bitmaps;
     if (static_cast<uint32_t>(i) < q.n_score)
-      sbits[i] = ix.gram_bitmaps + leaf[bt.score_terms[q.score_begin + i].leaf].b * ix.gb_row_stride;
+      sbits[i] = ix.gram_bitmaps +
+                 wave_uniform(leaf[bt.score_terms[q.score_begin + i].leaf].b) * ix.gb_row_stride;
   }
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
@@ -990,7 +1001,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
         for (int i = 0; i < kWaveScoreSlots; ++i) {
           if (lf.score_slot == static_cast<uint32_t>(i)) {
             srel[i] = rel;
-            tf_tile[i] = tf_base[i] + seg_rel;
+            tf_tile[i] = wave_uniform(tf_base[i] + seg_rel);
           }
         }
       }

@@ -77,22 +77,40 @@ def cfg3(mg, args):
                                  "mixed AND/OR/NOT/FUZZY, docid DESC limit 100" % (args.docs, args.batch)}
 
 
+def cfg2doc(mg, args):
+    """The bench.py batch (3 bigrams sampled by df) in docid order: what the operand phase alone costs."""
+    corpus = mg.Corpus.synthetic(args.docs, seed=42)
+    idx = mg.Index(corpus=corpus, ngram_size=2)
+    c = idx.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    cand = [g for g in range(c.n_grams) if b" " not in c.gram(g)]
+    w = sizes[cand].astype(np.float64)
+    w /= w.sum()
+    rng = np.random.default_rng(42)
+    qs = []
+    for _ in range(args.batch):
+        pick = rng.choice(len(cand), size=3, replace=False, p=w)
+        qs.append(mg.engine.Query([c.gram(cand[i]).decode() for i in pick], limit=10, descending=True))
+    return idx, qs, {"workload": "bench.py batch in docid order: %d docs, batch %d x 3-term AND, docid DESC limit 10"
+                                 % (args.docs, args.batch)}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["cfg3", "cfg5"])
+    ap.add_argument("config", choices=["cfg3", "cfg5", "cfg2doc"])
     ap.add_argument("--docs", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000}[args.config]
-    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192}[args.config]
+    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000}[args.config]
+    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024}[args.config]
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X")
     mg = entry.load_package()
     t0 = time.perf_counter()
-    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5}[args.config](mg, args)
+    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5, "cfg2doc": cfg2doc}[args.config](mg, args)
     batch = idx.prepare(qs)
     setup = time.perf_counter() - t0
     for _ in range(args.warmup):
