@@ -43,7 +43,7 @@ constexpr uint32_t kNoSlot = 0xFFu;
 constexpr int kWaveScoreSlots = 3;   // scored terms the wave kernel handles
 constexpr int kWaveBlock = 512;      // threads per workgroup of the wave kernel (8 autonomous waves share one BM25 table)
 constexpr int kWavesPerBlock = kWaveBlock / 64;
-constexpr uint32_t kTableTf = 8;     // BM25 contribution tables cover tf 1..8 ...
+constexpr uint32_t kTableTf = 6;     // BM25 contribution tables cover tf 1..6 ...
 constexpr uint32_t kTableDlMax = 256;  // ... and doc lengths below min(max_doc_len+1, 256)
 
 // ---- tile program: an accumulator machine over 64-bit bitmap words -------------------------------------------

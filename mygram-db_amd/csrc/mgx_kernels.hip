@@ -769,6 +769,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 //   * every wave keeps its own running top-k (WaveTopK) pruned by the query-wide bound; the lists are merged at the end.
 
 constexpr uint32_t kWaveMatchBuf = 256;  // matches buffered per wave between enumeration and scoring
+constexpr int kStepWords = 2;            // owned words enumerated and scored together (a tile is 4 / kStepWords steps)
+constexpr uint32_t kStripWords = 192 * kStepWords;  // u32 per parked operand: 64 x 2W half-words + 64 x W packed prefixes
 constexpr int kScoreUnroll = 2;          // matches in flight per lane in phase C
 
 struct WaveOffsets {
@@ -784,7 +786,7 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
   at = (at + 15u) & ~15u;
   o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
   o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
-  o.park = at;     at += kWavesPerBlock * p.max_score * 64 * 12;  // per scored operand: 64 x u64 word + 64 x packed u32 prefix
+  o.park = at;     at += kWavesPerBlock * p.max_score * kStripWords * 4;
   o.mbuf = at;     at += kWavesPerBlock * kWaveMatchBuf * 2;
   o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
   o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
@@ -905,7 +907,8 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
   uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
   uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
   // parked strips of this wave: operand i -> 128 x u32 half-words, then 64 x u32 packed prefixes (lo | hi << 16)
-  uint32_t* const park = reinterpret_cast<uint32_t*>(smem + wo.park) + static_cast<size_t>(wave) * plan.max_score * 192;
+  uint32_t* const park =
+      reinterpret_cast<uint32_t*>(smem + wo.park) + static_cast<size_t>(wave) * plan.max_score * kStripWords;
 
   const DevItem it = bt.items[blockIdx.x];
   const uint32_t qi = it.query;
@@ -1009,49 +1012,68 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
     cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
     if (bt.debug_skip & 2u) continue;
 
-    // ---- four steps, one per owned word index k ----------------------------------------------------------------------
+    // ---- 4 / kStepWords steps, each over kStepWords of the lane's owned words -----------------------------------------
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // word k of every scored operand again (8 B per lane; the lines were streamed by phase A a moment ago): holding
-      // 4 words x 3 operands in registers across the whole tile costs more (spills) than these L1/L2 hits
-      uint2 swk[kWaveScoreSlots];
+    for (int h = 0; h < 4 / kStepWords; ++h) {
+      // the step's words of every scored operand again (8 B per lane and word; the lines were streamed by phase A a
+      // moment ago): holding 4 words x 3 operands in registers across the whole tile costs more than these L1/L2 hits
+      uint2 swk[kWaveScoreSlots][kStepWords];
+      uint64_t any = 0;
+#pragma unroll
+      for (int wi = 0; wi < kStepWords; ++wi) any |= acc[h * kStepWords + wi];
 #pragma unroll
       for (int i = 0; i < kWaveScoreSlots; ++i) {
-        swk[i] = make_uint2(0, 0);
-        if (static_cast<uint32_t>(i) < q.n_score)  // wave-uniform
-          swk[i] = *reinterpret_cast<const uint2*>(sbits[i] + tile * ix.gb_tile_stride + lane * 4 + k);
-      }
-      if (__ballot(acc[k] != 0) == 0) {  // wave-uniform: no match in this step; only advance the prefixes
 #pragma unroll
-        for (int i = 0; i < kWaveScoreSlots; ++i) srel[i] += __popc(swk[i].x) + __popc(swk[i].y);
+        for (int wi = 0; wi < kStepWords; ++wi) {
+          swk[i][wi] = make_uint2(0, 0);
+          if (static_cast<uint32_t>(i) < q.n_score)  // wave-uniform
+            swk[i][wi] = *reinterpret_cast<const uint2*>(sbits[i] + tile * ix.gb_tile_stride + lane * 4 +
+                                                         h * kStepWords + wi);
+        }
+      }
+      if (__ballot(any != 0) == 0) {  // wave-uniform: no match in this step; only advance the prefixes
+#pragma unroll
+        for (int i = 0; i < kWaveScoreSlots; ++i)
+#pragma unroll
+          for (int wi = 0; wi < kStepWords; ++wi) srel[i] += __popc(swk[i][wi].x) + __popc(swk[i][wi].y);
         continue;
       }
-      // park word k of every scored operand with the postings that precede its low / high half inside the tile
+      // park the step's words of every scored operand with the postings that precede each 32-bit half inside the tile
 #pragma unroll
       for (int i = 0; i < kWaveScoreSlots; ++i) {
         if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-          const uint32_t lo = swk[i].x, hi = swk[i].y;
-          uint32_t* strip = park + i * 192;
-          strip[lane * 2] = lo;
-          strip[lane * 2 + 1] = hi;
-          const uint32_t plo = srel[i], phi = srel[i] + __popc(lo);
-          strip[128 + lane] = plo | (phi << 16);
-          srel[i] = phi + __popc(hi);
+          uint32_t* strip = park + i * kStripWords;
+#pragma unroll
+          for (int wi = 0; wi < kStepWords; ++wi) {
+            const uint32_t lo = swk[i][wi].x, hi = swk[i][wi].y;
+            strip[lane * (2 * kStepWords) + 2 * wi] = lo;
+            strip[lane * (2 * kStepWords) + 2 * wi + 1] = hi;
+            const uint32_t plo = srel[i], phi = srel[i] + __popc(lo);
+            strip[128 * kStepWords + lane * kStepWords + wi] = plo | (phi << 16);
+            srel[i] = phi + __popc(hi);
+          }
         }
       }
-      // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc[k] (a lane resumes where it stopped), C scores.
+      // Rounds of at most kWaveMatchBuf matches: B consumes bits of the step's words (a lane resumes where it
+      // stopped), C scores.
       for (;;) {
-        uint32_t n_left;
-        const uint32_t my_first = wave_excl_scan_total(__popcll(acc[k]), &n_left);
+        uint32_t n_left, mine = 0;
+#pragma unroll
+        for (int wi = 0; wi < kStepWords; ++wi) mine += __popcll(acc[h * kStepWords + wi]);
+        const uint32_t my_first = wave_excl_scan_total(mine, &n_left);
         if (n_left == 0) break;  // wave-uniform
-        // ---- phase B: (owner lane, bit) of this lane's next matches into the wave's match buffer --------------------
+        // ---- phase B: (owner lane, word, bit) of this lane's next matches into the wave's match buffer --------------
         {
           uint32_t r = my_first;
-          while (acc[k] != 0 && r < kWaveMatchBuf) {
-            const uint32_t bit = __builtin_ctzll(acc[k]);
-            acc[k] &= acc[k] - 1;
-            mbuf[r] = static_cast<uint16_t>((lane << 6) | bit);
-            ++r;
+#pragma unroll
+          for (int wi = 0; wi < kStepWords; ++wi) {
+            uint64_t& aw = acc[h * kStepWords + wi];
+            while (aw != 0 && r < kWaveMatchBuf) {
+              const uint32_t bit = __builtin_ctzll(aw);
+              aw &= aw - 1;
+              mbuf[r] = static_cast<uint16_t>((lane << 7) | (wi << 6) | bit);
+              ++r;
+            }
           }
         }
         wave_lds_sync();
@@ -1075,16 +1097,16 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
               valid[m] = j < nm;
               if (valid[m]) {
                 const uint32_t e = mbuf[j];
-                const uint32_t owner = e >> 6, bit = e & 63u;
-                const uint32_t hw = owner * 2 + (bit >> 5), mask = 1u << (bit & 31u);
-                slot[m] = tile * kTileDocs + owner * 256 + k * 64 + bit;
+                const uint32_t owner = e >> 7, wi = (e >> 6) & 1u, bit = e & 63u;
+                const uint32_t hw = owner * (2 * kStepWords) + wi * 2 + (bit >> 5), mask = 1u << (bit & 31u);
+                slot[m] = tile * kTileDocs + owner * 256 + (h * kStepWords + wi) * 64 + bit;
 #pragma unroll
                 for (int i = 0; i < kWaveScoreSlots; ++i) {
                   if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-                    const uint32_t* strip = park + i * 192;
+                    const uint32_t* strip = park + i * kStripWords;
                     const uint32_t wbits = strip[hw];
                     if (wbits & mask) {
-                      const uint32_t pp = strip[128 + owner];
+                      const uint32_t pp = strip[128 * kStepWords + owner * kStepWords + wi];
                       const uint32_t rank = ((bit >> 5) ? pp >> 16 : pp & 0xFFFFu) + __popc(wbits & (mask - 1u));
                       // the loaded values are first looked at after every gather of the iteration has been issued
                       if (i == 0) tfv[m][0] = ix.tfdl[tf_tile[0] + rank];
