@@ -312,3 +312,30 @@ def test_text_level_spans_many_tiles():
     qs = [Query([str(w) for w in rng.choice(words, size=2, replace=False)], sort_score=True, limit=10)
           for _ in range(6)]
     p.check(qs)
+
+
+# ---- docid-ordered pages (no SORT _score): count pass + page pass, no result bitmap ------------------------------------
+
+def test_docid_pages_dense_and_sparse(score_kernel):
+    # the reference's default order: primary key DESC with a limit (result_sorter.cpp:502-510). Dense queries have their
+    # page inside one tile; sparse ones (rare grams, multi-gram words) spread it over hundreds of mostly empty tiles.
+    corpus = mg.Corpus.synthetic(1_200_000, seed=7)
+    p = Pair(corpus=corpus)
+    c, sizes, grams = _letter_grams(p)
+    words = _words(p, 300, 5)
+    rng = np.random.default_rng(21)
+    qs = []
+    for it in range(10):
+        qs.append(Query([c.gram(int(g)).decode() for g in rng.choice(grams[:30], size=2, replace=False)],
+                        limit=int(rng.choice([1, 10, 100, 1000])), descending=bool(it % 2)))
+    for it in range(10):
+        qs.append(Query([c.gram(int(g)).decode() for g in rng.choice(grams[450:], size=2, replace=False)],
+                        limit=int(rng.choice([3, 50, 500])), descending=bool(it % 2)))
+    for it in range(8):
+        qs.append(Query([str(w) for w in rng.choice(words, size=2, replace=False)], limit=20, descending=bool(it % 2)))
+    qs.append(Query([c.gram(int(grams[0])).decode()], limit=16384, descending=True))    # largest page of the page path
+    qs.append(Query([c.gram(int(grams[0])).decode()], limit=16385, descending=False))   # one more: materialising path
+    qs.append(Query([c.gram(int(grams[600])).decode(), c.gram(int(grams[5])).decode()], limit=0))  # everything
+    qs.append(Query(["th"], ["he"], limit=7, descending=True))
+    qs.append(Query(expr=("and", ("or", "th", "qu"), ("not", "he")), limit=15))
+    p.check(qs)
