@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <deque>
+#include <functional>
 #include <map>
 #include <mutex>
 
@@ -150,6 +151,8 @@ struct Index::Impl {
   mutable mgx_columns_view view{};
   mutable bool finalized = false;
   mutable std::string last_error;
+  mutable bool has_gaps = false;       // ids inside [first, last] that were never added
+  mutable uint32_t exists_bitmap = 0;  // filter bitmap of the ids that were (only when has_gaps)
 
   ~Impl() {
     if (dev) mgx_index_destroy(dev);
@@ -212,6 +215,10 @@ std::string Index::Finalize() const {
     }
   }
   bytes.resize(bytes.size() + 16);
+  std::vector<DocId> existing;
+  impl_->has_gaps = impl_->pending.size() != n && !impl_->pending.empty();
+  if (impl_->has_gaps)
+    for (const auto& kv : impl_->pending) existing.push_back(kv.first);
   impl_->pending.clear();
   mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, ngram_size_, kanji_ngram_size_, cross_boundary_ ? 1 : 0, 0};
   if (mgx_columns_build(&bp, bytes.data(), off.data(), first, n, &impl_->cols) != MGX_OK) {
@@ -230,6 +237,10 @@ std::string Index::Finalize() const {
   // the shim's Index is also the DocumentStore of the texts it was given: BM25 terms longer than one n-gram are
   // counted in the text on the device
   if (mgx_index_attach_text(impl_->dev, bytes.data(), off.data()) != MGX_OK) impl_->last_error = mgx_last_error();
+  // DocumentStore::GetAllDocIds (the NOT universe of boolean expressions) is the set of ids that were added
+  if (impl_->has_gaps &&
+      mgx_index_add_filter_bitmap(impl_->dev, existing.data(), existing.size(), &impl_->exists_bitmap) != MGX_OK)
+    impl_->last_error = mgx_last_error();
   return impl_->last_error;
 }
 
@@ -524,8 +535,86 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
     return ti;
   };
 
+  std::vector<std::vector<mgx_expr_token>> expr_store;
   for (size_t qi = 0; qi < queries.size(); ++qi) {
     const BatchQuery& q = queries[qi];
+    if (q.ast) {
+      // ---- boolean expression: distinct TERM leaves in first-use order, tree in postfix ---------------------------
+      if (!q.terms.empty() || q.sort_by_score)
+        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
+                                        "an expression query takes its terms from the tree and is not scored"));
+      std::vector<std::string> leaves;
+      std::vector<TermInfo> tis;
+      std::vector<mgx_expr_token> toks;
+      bool bad = false;
+      std::function<void(const query::QueryNode&)> walk = [&](const query::QueryNode& nd) {
+        if (nd.type == query::NodeType::TERM) {
+          size_t k = 0;
+          while (k < leaves.size() && leaves[k] != nd.term) ++k;
+          if (k == leaves.size()) {
+            leaves.push_back(nd.term);
+            tis.push_back(make_info(nd.term));
+          }
+          // a term with an unknown gram (or none at all) is an empty doc set inside the tree
+          const bool empty = tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX;
+          toks.push_back(empty ? mgx_expr_token{MGX_EXPR_EMPTY, 0} : mgx_expr_token{MGX_EXPR_TERM, static_cast<uint32_t>(k)});
+          return;
+        }
+        if (nd.children.empty() || (nd.type == query::NodeType::NOT && nd.children.size() != 1)) {
+          bad = true;
+          return;
+        }
+        for (const auto& c : nd.children) walk(*c);
+        const uint32_t op = nd.type == query::NodeType::AND ? MGX_EXPR_AND
+                            : nd.type == query::NodeType::OR ? MGX_EXPR_OR
+                                                             : MGX_EXPR_NOT;
+        toks.push_back(mgx_expr_token{op, static_cast<uint32_t>(nd.children.size())});
+      };
+      walk(*q.ast);
+      if (bad || leaves.empty() || leaves.size() > MGX_MAX_TERMS)
+        return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "malformed expression tree"));
+      id_store.emplace_back();
+      term_store.emplace_back();
+      not_store.emplace_back();
+      filter_store.emplace_back();
+      auto& ids = id_store.back();
+      ids.reserve(leaves.size() + q.not_terms.size());
+      for (auto& ti : tis) {
+        if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids = {0};  // placeholder of an EMPTY leaf
+        ids.push_back(ti.gram_ids);
+        term_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
+      }
+      for (const auto& t : q.not_terms) {
+        TermInfo ti = make_info(t);
+        if (ti.n_grams == 0)
+          return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)"));
+        if (ti.estimated_size == 0) continue;
+        ids.push_back(ti.gram_ids);
+        not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
+      }
+      for (const auto& f : q.filters) filter_store.back().push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+      if (im->has_gaps) filter_store.back().push_back(mgx_filter{im->exists_bitmap, 0u});  // NOT universe = added ids
+      expr_store.push_back(std::move(toks));
+      mgx_query m{};
+      m.terms = term_store.back().data();
+      m.n_terms = static_cast<uint32_t>(term_store.back().size());
+      m.not_terms = not_store.back().data();
+      m.n_not_terms = static_cast<uint32_t>(not_store.back().size());
+      m.filters = filter_store.back().data();
+      m.n_filters = static_cast<uint32_t>(filter_store.back().size());
+      m.sort = MGX_SORT_DOCID;
+      m.limit = q.limit;
+      m.reverse = q.order == query::SortOrder::DESC ? 1 : 0;
+      m.k1 = q.bm25.k1;
+      m.b = q.bm25.b;
+      m.total_docs = total_docs;
+      m.avg_doc_length = avgdl;
+      m.expr = expr_store.back().data();
+      m.n_expr = static_cast<uint32_t>(expr_store.back().size());
+      mq.push_back(m);
+      device_slot.push_back(qi);
+      continue;
+    }
     if (q.terms.empty() || q.terms.size() > MGX_MAX_TERMS || q.not_terms.size() > MGX_MAX_TERMS)
       return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "query needs 1..64 terms"));
     std::vector<TermInfo> tis;

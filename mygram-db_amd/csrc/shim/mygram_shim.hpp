@@ -181,6 +181,16 @@ namespace mygramdb::query {
 using DocId = storage::DocId;
 enum class SortOrder : uint8_t { ASC, DESC };  // src/query/query_parser.h
 
+// query::QueryNode (src/query/query_ast.h:52-83): the boolean expression tree QueryASTParser produces.
+enum class NodeType : uint8_t { AND, OR, NOT, TERM };
+struct QueryNode {
+  NodeType type;
+  std::string term;  // TERM only
+  std::vector<std::unique_ptr<QueryNode>> children;
+  explicit QueryNode(std::string term_value) : type(NodeType::TERM), term(std::move(term_value)) {}
+  explicit QueryNode(NodeType node_type) : type(node_type) {}
+};
+
 class ResultSorter {
  public:
   // src/query/result_sorter.h:75-76. Runs on the device of `index` (any finalised index: only its stream is used).
@@ -198,6 +208,10 @@ using DocId = storage::DocId;
 // The parts of query::Query (src/query/query_parser.h:207-243) the hot path consumes.
 struct BatchQuery {
   std::vector<std::string> terms;      // search_text + and_terms (raw; normalised here)
+  // ExecuteWithBooleanAst (src/server/search_pipeline.cpp:1408-1578): when set, the positive part of the query is this
+  // tree (TERM = the term's doc set, NOT = every document of the index minus the child) and `terms` must be empty;
+  // NOT terms and filters still apply to its result. SORT _score is not combined with an expression here.
+  std::shared_ptr<const query::QueryNode> ast;
   std::vector<std::string> not_terms;
   std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
   bool sort_by_score = false;          // SORT _score

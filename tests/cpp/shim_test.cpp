@@ -208,6 +208,48 @@ int main() {
       std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
     }
   }
+  {  // boolean expressions through the batched entry (EvaluateBooleanAstExpanded, search_pipeline.cpp:327-378):
+     // NOT = DocumentStore::GetAllDocIds minus the child, so ids that were never added must not appear
+    using namespace mygramdb::search_pipeline;
+    using mygramdb::query::NodeType;
+    using mygramdb::query::QueryNode;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning techniques");
+    index.AddDocument(3, "old article about cats");
+    index.AddDocument(7, "learning cats");  // ids 4..6 do not exist
+    auto term = [](const char* t) { return std::make_unique<QueryNode>(std::string(t)); };
+    auto node = [](NodeType t, std::vector<std::unique_ptr<QueryNode>> kids) {
+      auto n = std::make_unique<QueryNode>(t);
+      n->children = std::move(kids);
+      return n;
+    };
+    auto kids = [](std::unique_ptr<QueryNode> a, std::unique_ptr<QueryNode> b = nullptr) {
+      std::vector<std::unique_ptr<QueryNode>> v;
+      v.push_back(std::move(a));
+      if (b) v.push_back(std::move(b));
+      return v;
+    };
+    std::vector<BatchQuery> qs(4);
+    // (machine OR deep) AND NOT techniques
+    qs[0].ast = node(NodeType::AND, kids(node(NodeType::OR, kids(term("machine"), term("deep"))),
+                                         node(NodeType::NOT, kids(term("techniques")))));
+    qs[1].ast = node(NodeType::NOT, kids(term("machine")));                       // every existing doc but 1
+    qs[2].ast = node(NodeType::OR, kids(term("cats"), term("zzzzzz")));           // unknown term = empty set in the tree
+    qs[3].ast = node(NodeType::AND, kids(term("learning"), node(NodeType::NOT, kids(term("cats")))));
+    qs[3].not_terms = {"deep"};
+    for (auto& q : qs) q.order = SortOrder::ASC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      EXPECT((*r)[0].results == (V{1}));
+      EXPECT((*r)[1].results == (V{2, 3, 7}) && (*r)[1].total == 3);
+      EXPECT((*r)[2].results == (V{3, 7}));
+      EXPECT((*r)[3].results == (V{1}));
+    } else {
+      std::printf("ExecuteBatch(ast) error: %s\n", r.error().message().c_str());
+    }
+  }
   std::printf("shim_test: %d checks, %d failed\n", g_checked, g_failed);
   return g_failed == 0 ? 0 : 1;
 }
