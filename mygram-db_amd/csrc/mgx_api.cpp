@@ -339,7 +339,8 @@ int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint6
   MGX_HIP(hipSetDevice(idx->device));
   std::vector<uint64_t> rel(n + 1);
   for (uint64_t i = 0; i <= n; ++i) rel[i] = text_off[i] - text_off[0];
-  MGX_HIP(mgx::Upload(idx->d_text, text_bytes ? text_bytes + text_off[0] : nullptr, total, 16));
+  // (the text scan reads aligned 16-byte chunks up to 48 bytes past a doc's end)
+  MGX_HIP(mgx::Upload(idx->d_text, text_bytes ? text_bytes + text_off[0] : nullptr, total, 128));
   MGX_HIP(mgx::Upload(idx->d_text_off, rel.data(), rel.size()));
   idx->dev.text = idx->d_text.as<uint8_t>();
   idx->dev.text_off = idx->d_text_off.as<uint64_t>();

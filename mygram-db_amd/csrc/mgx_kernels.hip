@@ -84,7 +84,7 @@ __device__ __forceinline__ bool better(uint64_t ka, uint32_t da, uint64_t kb, ui
 // ---------------------------------------------------------------------------------------------------------------
 
 struct LdsOffsets {
-  uint32_t bm, stack, pref, prog, seg_lo, seg_hi, leaf, scan_tot, match, tk_keys, tk_docs, misc, total;
+  uint32_t bm, stack, pref, prog, seg_lo, seg_hi, leaf, scan_tot, match, tk_keys, tk_docs, misc, tpat, total;
 };
 
 __host__ __device__ inline uint32_t align8(uint32_t x) { return (x + 7u) & ~7u; }
@@ -110,6 +110,8 @@ __host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
     o.tk_keys = at;  at += 4 * 2 * p.max_cap * 8;
     o.tk_docs = at;  at += 4 * 2 * p.max_cap * 4;
   }
+  o.tpat = at;
+  if (score_mode) at += p.max_score * 32;  // one TextPattern per scored term
   o.total = at;
   return o;
 }
@@ -286,24 +288,76 @@ __device__ __forceinline__ void wave_topk_offer(WaveTopK& t, bool valid, uint64_
   t.pend += ns;
 }
 
-// BM25Scorer::CountTermOccurrences (bm25_scorer.cpp:27-45): non-overlapping occurrences of `pat` in `text`, found
-// left to right; with first_only the scan stops at the first one (std::string::find != npos, search_pipeline.cpp:556-563).
-__device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __restrict__ text, uint32_t len,
-                                                           const uint8_t* __restrict__ pat, uint32_t plen,
-                                                           bool first_only) {
-  if (len == 0 || plen == 0 || plen > len) return 0;
-  const uint8_t p0 = pat[0];
-  uint32_t count = 0, pos = 0;
-  while (pos + plen <= len) {
-    bool hit = text[pos] == p0;
-    for (uint32_t k = 1; hit && k < plen; ++k) hit = text[pos + k] == pat[k];
-    if (hit) {
-      ++count;
-      if (first_only) break;
-      pos += plen;
+// BM25Scorer::CountTermOccurrences (bm25_scorer.cpp:27-45): non-overlapping occurrences of the pattern in one doc's
+// text, found left to right; with first_only the scan stops at the first one (std::string::find != npos,
+// search_pipeline.cpp:556-563).
+//
+// The doc text is streamed in aligned 16-byte chunks (the next chunk is in flight while the current one is scanned);
+// for each of the 16 byte positions of a chunk an 8-byte window is cut out of the chunk registers with compile-time
+// shifts and compared with the pattern's first 8 bytes (masked when the pattern is shorter). Positions that pass are
+// taken in order under the non-overlap rule; only patterns longer than 8 bytes verify their tail byte by byte.
+struct TextPattern {
+  const uint8_t* bytes;   // the whole pattern
+  uint32_t len;
+  uint32_t lo, hi;        // its first 8 bytes, little-endian, zero beyond len
+  uint32_t mlo, mhi;      // byte mask of those 8 bytes
+};
+
+__device__ __forceinline__ TextPattern text_pattern(const uint8_t* __restrict__ pat, uint32_t plen) {
+  TextPattern p{pat, plen, 0, 0, 0, 0};
+  for (uint32_t k = 0; k < 8 && k < plen; ++k) {
+    const uint32_t v = pat[k];
+    if (k < 4) {
+      p.lo |= v << (8 * k);
+      p.mlo |= 0xFFu << (8 * k);
     } else {
-      ++pos;
+      p.hi |= v << (8 * (k - 4));
+      p.mhi |= 0xFFu << (8 * (k - 4));
     }
+  }
+  return p;
+}
+
+__device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __restrict__ text_base, uint64_t t0,
+                                                           uint64_t t1, const TextPattern& pt, bool first_only) {
+  const uint32_t plen = pt.len;
+  if (t1 <= t0 || plen == 0 || plen > t1 - t0) return 0;
+  const uint64_t last_start = t1 - plen;  // last byte offset an occurrence can start at
+  uint64_t base = t0 & ~static_cast<uint64_t>(15);
+  uint64_t next_ok = t0;
+  uint32_t count = 0;
+  uint4 c0 = *reinterpret_cast<const uint4*>(text_base + base);
+  uint4 c1 = *reinterpret_cast<const uint4*>(text_base + base + 16);
+  for (;;) {
+    // the chunk after next is requested now and used two iterations later (the text buffer is padded for it)
+    const uint4 c2 = *reinterpret_cast<const uint4*>(text_base + base + 32);
+    const uint32_t d[7] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z};
+    uint32_t cand = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int i = p >> 2, sh = p & 3;
+      const uint32_t wlo = sh ? __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh) : d[i];
+      const uint32_t whi = sh ? __builtin_amdgcn_alignbyte(d[i + 2], d[i + 1], sh) : d[i + 1];
+      const uint32_t diff = ((wlo ^ pt.lo) & pt.mlo) | ((whi ^ pt.hi) & pt.mhi);
+      cand |= diff == 0 ? (1u << p) : 0u;
+    }
+    while (cand) {
+      const uint32_t p = __builtin_ctz(cand);
+      cand &= cand - 1;
+      const uint64_t pos = base + p;
+      if (pos < next_ok || pos > last_start) continue;
+      bool hit = true;
+      for (uint32_t k = 8; hit && k < plen; ++k) hit = text_base[pos + k] == pt.bytes[k];  // rare: long pattern
+      if (hit) {
+        ++count;
+        if (first_only) return count;
+        next_ok = pos + plen;
+      }
+    }
+    base += 16;
+    if (base > last_start) break;
+    c0 = c1;
+    c1 = c2;
   }
   return count;
 }
@@ -375,6 +429,17 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   }
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0, cnt_df = 0;
   const uint32_t n_score = MODE == kModeScore ? q.n_score : 0u;
+  TextPattern df_pattern{nullptr, 0, 0, 0, 0, 0};
+  if (MODE == kModeTextDf) df_pattern = text_pattern(bt.patterns + q.pat_off, q.pat_len);
+  static_assert(sizeof(TextPattern) == 32, "LDS plan reserves 32 bytes per text pattern");
+  TextPattern* const tpat = reinterpret_cast<TextPattern*>(smem + lo_.tpat);
+  if (MODE == kModeScore && tid < n_score) {
+    const DevScoreTerm st = bt.score_terms[q.score_begin + tid];
+    if (st.leaf == kNoLeaf) {
+      const DevTextTerm tt = bt.text_terms[st.text_term];
+      tpat[tid] = text_pattern(bt.patterns + tt.pat_off, tt.pat_len);
+    }
+  }
 
   const uint32_t tile_begin = it.tile_begin;
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
@@ -640,8 +705,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
           if (valid) {
             const uint32_t slot = tile * kTileDocs + matchbuf[j];
             const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
-            cnt_df += text_count_occurrences(ix.text + t0, static_cast<uint32_t>(t1 - t0), bt.patterns + q.pat_off,
-                                             q.pat_len, true);
+            cnt_df += text_count_occurrences(ix.text, t0, t1, df_pattern, true);
           }
           continue;
         }
@@ -660,10 +724,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
             const DevScoreTerm st = bt.score_terms[q.score_begin + i];
             double tf = 0.0, idf = st.idf;
             if (st.leaf == kNoLeaf) {
-              const DevTextTerm tt = bt.text_terms[st.text_term];
               const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
-              tf = static_cast<double>(text_count_occurrences(ix.text + t0, static_cast<uint32_t>(t1 - t0),
-                                                              bt.patterns + tt.pat_off, tt.pat_len, false));
+              tf = static_cast<double>(text_count_occurrences(ix.text, t0, t1, tpat[i], false));
               idf = bt.text_idf[st.text_term];
             } else {
               const uint64_t wbits = bm64[st.leaf * kBlock + word];
@@ -1656,7 +1718,7 @@ __global__ void score_candidates_text_kernel(DevIndex ix, const uint32_t* __rest
       const double length_norm = one_minus_b + b * dl / avgdl_clamped;
       for (uint32_t t = 0; t < n_terms; ++t) {
         const double tf = static_cast<double>(text_count_occurrences(
-            ix.text + t0, static_cast<uint32_t>(t1 - t0), term_bytes + term_off[t], term_off[t + 1] - term_off[t], false));
+            ix.text, t0, t1, text_pattern(term_bytes + term_off[t], term_off[t + 1] - term_off[t]), false));
         if (tf > 0.0) {
           const double numerator = tf * k1_plus_1;
           const double denominator = tf + k1 * length_norm;

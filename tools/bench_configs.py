@@ -95,22 +95,36 @@ def cfg2doc(mg, args):
                                  % (args.docs, args.batch)}
 
 
+def text2(mg, args):
+    """Text-level BM25: 2 whole words per query (each several bigrams long), SORT _score top-10; per
+    execute: df pass (text scan of every term's candidates) + scoring with tf from the text."""
+    corpus = mg.Corpus.synthetic(args.docs, seed=42)
+    idx = mg.Index(corpus=corpus, ngram_size=2)
+    rng = np.random.default_rng(9)
+    words = sorted({w for i in range(0, args.docs, max(1, args.docs // 4000)) for w in corpus.text(i).decode().split(" ")
+                    if len(w) >= 3})
+    qs = [mg.engine.Query([str(w) for w in rng.choice(words, size=2, replace=False)], sort_score=True, limit=10)
+          for _ in range(args.batch)]
+    return idx, qs, {"workload": "text-level BM25: %d docs, bigram, batch %d x 2 whole-word terms, top-10" %
+                                 (args.docs, args.batch), "vocabulary_sample": len(words)}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["cfg3", "cfg5", "cfg2doc"])
+    ap.add_argument("config", choices=["cfg3", "cfg5", "cfg2doc", "text2"])
     ap.add_argument("--docs", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000}[args.config]
-    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024}[args.config]
+    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000, "text2": 2_000_000}[args.config]
+    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024, "text2": 1024}[args.config]
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X")
     mg = entry.load_package()
     t0 = time.perf_counter()
-    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5, "cfg2doc": cfg2doc}[args.config](mg, args)
+    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5, "cfg2doc": cfg2doc, "text2": text2}[args.config](mg, args)
     batch = idx.prepare(qs)
     setup = time.perf_counter() - t0
     for _ in range(args.warmup):
