@@ -916,6 +916,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
       tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
+      // the workgroup kernel walks its tiles one after the other (~4 us each): short items keep the few queries it
+      // serves from becoming the tail of the step
+      if (score_mode && !on_wave[i]) tiles = 8;
       list_begin[i] = static_cast<uint32_t>(items.size());
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), 0};

@@ -1519,20 +1519,48 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   const uint32_t page_hi = q.limit == 0 ? merged : min(q.offset + q.limit, merged);
 
   const uint64_t total_slots = static_cast<uint64_t>(n_lists) * q.needed;
+  // Small merges (the usual page: ~12 lists x 10 entries) are staged in LDS first: ranking an entry is a chain of
+  // dependent probes into every other list, which costs a memory latency each when the lists stay in HBM.
+  constexpr uint32_t kStage = 4096;
+  __shared__ uint64_t s_keys[kStage];
+  __shared__ uint32_t s_docs[kStage];
+  __shared__ uint32_t s_cnt[kStage];
+  const bool staged = total_slots <= kStage;
+  if (staged) {
+    for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) s_cnt[j] = min(cnt[MGX_C(j)], q.needed);
+    for (uint32_t e = threadIdx.x; e < total_slots; e += kBlock) {
+      const uint32_t j = e / q.needed, i = e % q.needed;
+      const bool live = i < cnt[MGX_C(j)];
+      s_keys[e] = live ? keys[MGX_K(j) + i] : 0;
+      s_docs[e] = live ? docs[MGX_K(j) + i] : 0;
+    }
+    __syncthreads();
+  }
   for (uint64_t e = threadIdx.x; e < total_slots; e += kBlock) {
     const uint32_t j = static_cast<uint32_t>(e / q.needed), i = static_cast<uint32_t>(e % q.needed);
-    if (i >= cnt[MGX_C(j)]) continue;
-    const uint64_t k = keys[MGX_K(j) + i];
-    const uint32_t d = docs[MGX_K(j) + i];
+    if (i >= (staged ? s_cnt[j] : cnt[MGX_C(j)])) continue;
+    const uint64_t k = staged ? s_keys[e] : keys[MGX_K(j) + i];
+    const uint32_t d = staged ? s_docs[e] : docs[MGX_K(j) + i];
     uint32_t rank = i;
     for (uint32_t j2 = 0; j2 < n_lists && rank < q.needed; ++j2) {
       if (j2 == j) continue;
-      const uint64_t* kk = keys + MGX_K(j2);
-      const uint32_t* dd = docs + MGX_K(j2);
-      uint32_t lo = 0, hi = min(cnt[MGX_C(j2)], q.needed);
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+      uint32_t lo = 0;
+      if (staged) {
+        const uint64_t* kk = s_keys + j2 * q.needed;
+        const uint32_t* dd = s_docs + j2 * q.needed;
+        uint32_t hi = s_cnt[j2];
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
+      } else {
+        const uint64_t* kk = keys + MGX_K(j2);
+        const uint32_t* dd = docs + MGX_K(j2);
+        uint32_t hi = min(cnt[MGX_C(j2)], q.needed);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
       }
       rank += lo;
     }
