@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   const uint64_t total_slots = static_cast<uint64_t>(n_lists) * q.needed;
   // Small merges (the usual page: ~12 lists x 10 entries) are staged in LDS first: ranking an entry is a chain of
   // dependent probes into every other list, which costs a memory latency each when the lists stay in HBM.
-  constexpr uint32_t kStage = 4096;
+  constexpr uint32_t kStage = 2048;
   __shared__ uint64_t s_keys[kStage];
   __shared__ uint32_t s_docs[kStage];
   __shared__ uint32_t s_cnt[kStage];
@@ -1536,10 +1536,65 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
     }
     __syncthreads();
   }
+  // A list that is full holds `needed` entries at or above its last key, so nothing below the largest such key can
+  // reach the merged top: most entries of a many-list merge are dropped here without being ranked.
+  __shared__ unsigned long long s_thr;
+  if (threadIdx.x == 0) s_thr = 0;
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) {
+    const uint32_t c = staged ? s_cnt[j] : min(cnt[MGX_C(j)], q.needed);
+    if (c >= q.needed && q.needed > 0) {
+      const uint64_t k = staged ? s_keys[j * q.needed + q.needed - 1] : keys[MGX_K(j) + q.needed - 1];
+      atomicMax(&s_thr, static_cast<unsigned long long>(k));
+    }
+  }
+  __syncthreads();
+  const uint64_t thr = s_thr;
+  // Everything below thr is worse than every entry at or above it, so the survivors can be ranked among themselves:
+  // they are compacted and each counts the survivors that beat it (a few dozen LDS reads instead of a binary search in
+  // every other list, which is what made merges of ~70 lists slow).
+  constexpr uint32_t kSurv = 1024;
+  __shared__ uint64_t s_sk[kSurv];
+  __shared__ uint32_t s_sd[kSurv];
+  __shared__ uint32_t s_nsurv;
+  if (threadIdx.x == 0) s_nsurv = 0;
+  __syncthreads();
   for (uint64_t e = threadIdx.x; e < total_slots; e += kBlock) {
     const uint32_t j = static_cast<uint32_t>(e / q.needed), i = static_cast<uint32_t>(e % q.needed);
     if (i >= (staged ? s_cnt[j] : cnt[MGX_C(j)])) continue;
     const uint64_t k = staged ? s_keys[e] : keys[MGX_K(j) + i];
+    if (k < thr) continue;
+    const uint32_t at = atomicAdd(&s_nsurv, 1u);
+    if (at < kSurv) {
+      s_sk[at] = k;
+      s_sd[at] = staged ? s_docs[e] : docs[MGX_K(j) + i];
+    }
+  }
+  __syncthreads();
+  const uint32_t n_surv = s_nsurv;
+  if (n_surv <= kSurv) {
+    for (uint32_t t = threadIdx.x; t < n_surv; t += kBlock) {
+      const uint64_t k = s_sk[t];
+      const uint32_t d = s_sd[t];
+      uint32_t rank = 0;
+      for (uint32_t u = 0; u < n_surv; ++u) rank += better(s_sk[u], s_sd[u], k, d) ? 1u : 0u;
+      if (rank < q.needed) {
+        if (top_keys) {
+          top_keys[static_cast<uint64_t>(slot) * top_stride + rank] = k;
+          top_docs[static_cast<uint64_t>(slot) * top_stride + rank] = d;
+        }
+        if (page_docs && rank >= page_lo && rank < page_hi) {
+          page_docs[static_cast<uint64_t>(slot) * page_stride + rank - page_lo] = q.descending ? d : ~d;
+          page_scores[static_cast<uint64_t>(slot) * page_stride + rank - page_lo] = key_score(k, q.descending != 0);
+        }
+      }
+    }
+  } else
+  for (uint64_t e = threadIdx.x; e < total_slots; e += kBlock) {
+    const uint32_t j = static_cast<uint32_t>(e / q.needed), i = static_cast<uint32_t>(e % q.needed);
+    if (i >= (staged ? s_cnt[j] : cnt[MGX_C(j)])) continue;
+    const uint64_t k = staged ? s_keys[e] : keys[MGX_K(j) + i];
+    if (k < thr) continue;
     const uint32_t d = staged ? s_docs[e] : docs[MGX_K(j) + i];
     uint32_t rank = i;
     for (uint32_t j2 = 0; j2 < n_lists && rank < q.needed; ++j2) {
