@@ -109,6 +109,7 @@ struct mgx_index {
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
+  DevBuf d_dl8, d_tfnib;
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -261,6 +262,22 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
                                        /*row_stride=*/mgx::kWordsPerTile, idx->d_gram_bitmaps.as<uint64_t>(),
                                        idx->stream));
     MGX_HIP(hipStreamSynchronize(idx->stream));
+    if (idx->can_score) {
+      // tf of the dense grams by doc slot (4 bits per doc); rows padded off power-of-two strides
+      const uint64_t stride = static_cast<uint64_t>(n_tiles) * (mgx::kTileDocs / 2) + 4352;
+      MGX_HIP(idx->d_tfnib.Alloc(bm_grams.size() * stride + 256));
+      MGX_HIP(hipMemsetAsync(idx->d_tfnib.p, 0, idx->d_tfnib.bytes, idx->stream));
+      MGX_LAUNCH(mgx::LaunchBuildTfNib(idx->d_docids.as<uint32_t>(), idx->d_tf.as<uint8_t>(), d_lo.as<uint64_t>(),
+                                       d_hi.as<uint64_t>(), static_cast<uint32_t>(bm_grams.size()), d->first_doc_id,
+                                       stride, idx->d_tfnib.as<uint8_t>(), idx->stream));
+      MGX_HIP(hipStreamSynchronize(idx->stream));
+      idx->dev.nib_row_stride = stride;
+    }
+  }
+  if (idx->can_score) {
+    std::vector<uint8_t> dl8(n_docs);
+    for (uint64_t i = 0; i < n_docs; ++i) dl8[i] = static_cast<uint8_t>(std::min<uint32_t>(d->doc_len[i], 255u));
+    MGX_HIP(mgx::Upload(idx->d_dl8, dl8.data(), n_docs, 16));
   }
 
   mgx::DevIndex& v = idx->dev;
@@ -269,6 +286,8 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.tf = idx->d_tf.as<uint8_t>();
   v.tfdl = idx->d_tfdl.as<uint16_t>();
   v.doc_len = idx->d_doc_len.as<uint32_t>();
+  v.dl8 = idx->d_dl8.as<uint8_t>();
+  v.tfnib = idx->d_tfnib.as<uint8_t>();
   v.skip_row = idx->d_skip_row.as<uint32_t>();
   v.tile_off = idx->d_tile_off.as<uint32_t>();
   v.gram_bitmaps = idx->d_gram_bitmaps.as<uint64_t>();
@@ -323,7 +342,7 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_tfdl.bytes + idx->d_doc_len.bytes +
          idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes +
-         idx->d_text.bytes + idx->d_text_off.bytes;
+         idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes;
   return MGX_OK;
 }
 
@@ -717,6 +736,7 @@ struct mgx_batch {
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
     mgx::WavePlan wplan{};
+    bool use_nib = false;  // the wave share scores from doc-slot tf nibbles (nib_score_kernel)
     // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
     // separately, over disjoint item lists, into the same candidate arrays
     mgx::DevBatch dev_wave{};
@@ -847,7 +867,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       wi = std::max<uint32_t>(wi, dq[i].n_instr);
       wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
+    static const bool kUseNib = !(std::getenv("MGX_SCORE_KERNEL") && std::string(std::getenv("MGX_SCORE_KERNEL")) == "rank");
+    g.use_nib = kUseNib && b->idx->dev.tfnib != nullptr;
+    g.wplan = g.use_nib ? PlanNib(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list)
+                        : PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
     if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
   if (page_mode) {
@@ -1203,10 +1226,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
       MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH((g.use_nib ? LaunchNibScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH((g.use_nib ? LaunchNibScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {

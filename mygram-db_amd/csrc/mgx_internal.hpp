@@ -108,6 +108,9 @@ struct DevIndex {
   const uint8_t* tf;
   const uint16_t* tfdl;       // [P] tf | min(doc_len,255) << 8 of the posting's doc: one gather gives a term's tf and the doc length
   const uint32_t* doc_len;
+  const uint8_t* dl8;         // [n_docs] min(doc_len, 255)
+  const uint8_t* tfnib;       // [bitmap rows][nib_row_stride] min(tf,15) by doc slot, two docs per byte (0 = absent)
+  uint64_t nib_row_stride;    // bytes
   const uint32_t* skip_row;   // [G] row in tile_off, or kNoRow
   const uint32_t* tile_off;   // [rows][n_tiles+1]
   // bitmap word (tile, row, w) lives at base[tile*tile_stride + row*row_stride + w]. Gram bitmaps are TILE-major
@@ -180,6 +183,8 @@ struct WavePlan {
   uint32_t has_list;      // some operand needs the per-wave scatter bitmap
   uint32_t bytes;
 };
+WavePlan PlanNib(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
+                 bool has_list);
 WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
                   bool has_list);
 

@@ -158,6 +158,23 @@ __global__ void build_bitmap_kernel(const uint32_t* __restrict__ docids, const u
   }
 }
 
+// tf of the dense grams by DOC SLOT, 4 bits per doc: nib[row][slot/2] holds min(tf, 15) of slot in its low (even slot)
+// or high (odd slot) nibble, 0 where the doc lacks the gram. The scoring kernel reads a match's tf from its slot
+// directly — no rank, hence no prefix popcounts and no parked operand words.
+__global__ void build_tfnib_kernel(const uint32_t* __restrict__ docids, const uint8_t* __restrict__ tf,
+                                   const uint64_t* __restrict__ row_lo, const uint64_t* __restrict__ row_hi,
+                                   uint32_t first_doc_id, uint64_t row_stride_bytes, uint8_t* __restrict__ nib) {
+  const uint32_t row = blockIdx.y;
+  const uint64_t lo = row_lo[row], hi = row_hi[row];
+  uint32_t* out = reinterpret_cast<uint32_t*>(nib + static_cast<uint64_t>(row) * row_stride_bytes);
+  for (uint64_t p = lo + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < hi;
+       p += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    const uint32_t slot = docids[p] - first_doc_id;
+    const uint32_t v = tf[p] < 15 ? tf[p] : 15u;
+    atomicOr(&out[slot >> 3], v << ((slot & 7u) * 4u));
+  }
+}
+
 // tfdl[p] = tf[p] | min(doc_len[slot(p)], 255) << 8
 __global__ void build_tfdl_kernel(const uint32_t* __restrict__ docids, const uint8_t* __restrict__ tf,
                                   const uint32_t* __restrict__ doc_len, uint64_t n_postings, uint32_t first_doc_id,
@@ -1271,6 +1288,298 @@ __global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// scoring kernel over doc-slot tf nibbles (no ranks)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// Same contract as wave_score_kernel, different data path for the scoring phase: a match's tf under scored term i is
+// the nibble tfnib[row_i][slot/2] and its doc length is dl8[slot], both addressed by the doc slot alone. So nothing of
+// the rank machinery is needed (no prefix popcounts in the operand phase, no parked operand words, no per-step
+// re-fetch): a tile is  A. program on 4 words per lane  B. all matches of the tile into the match buffer
+// C. one match per lane: T+1 byte gathers, table lookups, top-k offer. Nibble 15 (tf >= 15) and dl8 255 take an exact
+// slow path (binary search of the posting segment / the u32 doc_len), both rare.
+
+struct NibOffsets {
+  uint32_t leaf, prog, misc, table, scratch, mbuf, tk_keys, tk_docs, total;
+};
+constexpr uint32_t kNibMatchBuf = 512;  // matches of one tile buffered per wave and round
+
+__host__ __device__ inline NibOffsets carve_nib(const WavePlan& p) {
+  NibOffsets o;
+  uint32_t at = 0;
+  o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
+  o.prog = at;     at += align8(p.max_instr * 4);
+  o.misc = at;     at += 128;
+  at = (at + 15u) & ~15u;
+  o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
+  o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
+  o.mbuf = at;     at += kWavesPerBlock * kNibMatchBuf * 2;
+  o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
+  o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
+  o.total = at;
+  return o;
+}
+
+WavePlan PlanNib(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
+                 bool has_list) {
+  WavePlan p{max_leaves ? max_leaves : 1, max_score, max_instr ? max_instr : 1, max_cap, 0, has_list ? 1u : 0u, 0};
+  p.table_dl = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
+  p.bytes = carve_nib(p).total;
+  return p;
+}
+
+// exact tf of gram `g` in the doc at `slot` (the nibble saturated): binary search of the tile's posting segment
+__device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot) {
+  const uint32_t tile = slot >> kTileShift;
+  const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+  const uint64_t l0 = ix.offsets[g];
+  const uint64_t lo = l0 + r[tile], hi = l0 + r[tile + 1];
+  const uint32_t d = ix.first_doc_id + slot;
+  const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
+  return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
+}
+
+__global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const NibOffsets no = carve_nib(plan);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + no.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + no.prog);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + no.misc);
+  double* const table = reinterpret_cast<double*>(smem + no.table);
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + no.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
+  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + no.mbuf) + static_cast<size_t>(wave) * kNibMatchBuf;
+
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query;
+  const DevQuery q = bt.queries[qi];
+  const uint32_t tdl = plan.table_dl;
+  for (uint32_t i = tid; i < q.n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
+  {
+    const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
+    const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
+    double2* dst = reinterpret_cast<double2*>(table);
+    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
+  }
+  WaveTopK tk;
+  tk.cap = q.cap;
+  tk.needed = q.needed;
+  tk.keys = reinterpret_cast<uint64_t*>(smem + no.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + no.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.have = 0;
+  tk.pend = 0;
+  tk.bound_key = 0;
+  tk.bound_doc = 0;
+  tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
+  tk.gbound = 0;
+  for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
+    tk.keys[i] = 0;
+    tk.docs[i] = 0;
+  }
+  // per scored term (LDS, misc[16..]): gram id, skip row (exact-tf path), bitmap row (nibble row)
+  uint32_t* const sterm = misc + 16;
+  if (tid < q.n_score) {
+    const DevLeaf lf = bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf];
+    sterm[tid * 3] = lf.a;
+    sterm[tid * 3 + 1] = lf.row;
+    sterm[tid * 3 + 2] = lf.b;
+  }
+  __syncthreads();
+  const uint8_t* nib[kWaveScoreSlots];
+#pragma unroll
+  for (int i = 0; i < kWaveScoreSlots; ++i) {
+    nib[i] = ix.tfnib;
+    if (static_cast<uint32_t>(i) < q.n_score)
+      nib[i] = ix.tfnib + static_cast<uint64_t>(wave_uniform(sterm[i * 3 + 2])) * ix.nib_row_stride;
+  }
+
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  const uint32_t tile_begin = it.tile_begin;
+  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
+  const bool desc = q.descending != 0;
+
+  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kWavesPerBlock) {
+    const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
+    wave_topk_refresh_gbound(tk);
+    // ---- A. the program on this lane's four words ------------------------------------------------------------------
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+      const uint32_t ins = prog[pc];
+      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+      if (op == kOpCount) {
+        const uint32_t pcnt = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+        cnt0 += (arg & 1u) ? pcnt : 0;
+        cnt1 += (arg & 2u) ? pcnt : 0;
+        cnt2 += (arg & 4u) ? pcnt : 0;
+        cnt3 += (arg & 8u) ? pcnt : 0;
+        continue;
+      }
+      DevLeaf lf = leaf[arg];
+      lf.score_slot = kNoSlot;  // (no rank base needed here)
+      uint64_t w[4];
+      uint32_t seg_rel;
+      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (op == kOpLoad) acc[k] = w[k];
+        else if (op == kOpAnd) acc[k] &= w[k];
+        else if (op == kOpOr) acc[k] |= w[k];
+        else if (op == kOpAndNot) acc[k] &= ~w[k];
+      }
+    }
+    cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+    if (bt.debug_skip & 2u) continue;
+
+    // Rounds of at most kNibMatchBuf matches: B consumes bits of acc (a lane resumes where it stopped), C scores.
+    for (;;) {
+      uint32_t n_left;
+      const uint32_t mine = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
+      const uint32_t my_first = wave_excl_scan_total(mine, &n_left);
+      if (n_left == 0) break;  // wave-uniform
+      // ---- B. (owner lane, word, bit) of this lane's next matches ---------------------------------------------------
+      {
+        uint32_t r = my_first;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          while (acc[k] != 0 && r < kNibMatchBuf) {
+            const uint32_t bit = __builtin_ctzll(acc[k]);
+            acc[k] &= acc[k] - 1;
+            mbuf[r] = static_cast<uint16_t>((lane << 8) | (k << 6) | bit);  // = the doc's slot inside the tile
+            ++r;
+          }
+        }
+      }
+      wave_lds_sync();
+      const uint32_t nm = min(kNibMatchBuf, n_left);
+      // ---- C. one match per lane, kScoreUnroll in flight -------------------------------------------------------------
+      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
+        bool valid[kScoreUnroll];
+        uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
+        uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+          valid[m] = false;
+          slot[m] = 0;
+          dli[m] = 0;
+#pragma unroll
+          for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
+          if (j0 + m * 64 < nm) {  // wave-uniform
+            const uint32_t j = j0 + m * 64 + lane;
+            valid[m] = j < nm;
+            if (valid[m]) {
+              slot[m] = tile * kTileDocs + mbuf[j];
+              // every gather of the iteration is issued before any of them is looked at
+#pragma unroll
+              for (int i = 0; i < kWaveScoreSlots; ++i)
+                if (static_cast<uint32_t>(i) < q.n_score) tfv[m][i] = nib[i][slot[m] >> 1];
+              dli[m] = ix.dl8[slot[m]];
+            }
+          }
+        }
+        bool slow = false;
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+          if (j0 + m * 64 < nm) {  // wave-uniform
+            const uint32_t sh = (slot[m] & 1u) * 4u;
+#pragma unroll
+            for (int i = 0; i < kWaveScoreSlots; ++i) {
+              tfv[m][i] = (tfv[m][i] >> sh) & 15u;
+              slow = slow || tfv[m][i] == 15u;
+            }
+            slow = slow || (valid[m] && dli[m] == 255u);
+          }
+        }
+        if (__ballot(slow) != 0) {  // wave-uniform, rare: saturated nibble or doc length
+#pragma unroll
+          for (int m = 0; m < kScoreUnroll; ++m) {
+            if (valid[m]) {
+#pragma unroll
+              for (int i = 0; i < kWaveScoreSlots; ++i)
+                if (tfv[m][i] == 15u) tfv[m][i] = exact_tf(ix, sterm[i * 3], sterm[i * 3 + 1], slot[m]);
+              if (dli[m] == 255u) dli[m] = ix.doc_len[slot[m]];
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < kScoreUnroll; ++m) {
+          if (j0 + m * 64 < nm) {  // wave-uniform
+            double score = 0.0;
+#pragma unroll
+            for (int i = 0; i < kWaveScoreSlots; ++i) {
+              if (tfv[m][i] != 0) {
+                if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
+                  score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
+                } else {  // bm25_scorer.cpp:80-84, same operation order as the table
+                  const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
+                  const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
+                  const double numerator = tf * q.k1_plus_1;
+                  const double denominator = tf + q.k1 * length_norm;
+                  score += bt.score_terms[q.score_begin + i].idf * numerator / denominator;
+                }
+              }
+            }
+            const uint32_t doc = ix.first_doc_id + slot[m];
+            wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+  }
+
+  {
+    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t x = v[s];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
+    }
+  }
+
+  // ---- merge the waves' lists into this workgroup's best `needed`, best first, to HBM ---------------------------------
+  wave_topk_truncate(tk);
+  if (lane == 0) misc[wave] = tk.have;
+  __syncthreads();
+  {
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + no.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + no.tk_docs);
+    const uint32_t cap = q.cap;
+    uint32_t have[kWavesPerBlock];
+    uint32_t total = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+      have[w] = min(misc[w], q.needed);
+      total += have[w];
+    }
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
+    for (uint32_t e = tid; e < kWavesPerBlock * cap; e += kWaveBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= have[w]) continue;
+      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+      uint32_t rank = i;
+      for (uint32_t w2 = 0; w2 < kWavesPerBlock; ++w2) {
+        if (w2 == w) continue;
+        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+        uint32_t lo = 0, hi = have[w2];
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < q.needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = d;
+      }
+    }
+    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wave-autonomous count pass of docid-ordered pages (kModeDocPage queries with flat programs)
 // ---------------------------------------------------------------------------------------------------------------
 //
@@ -1870,6 +2179,17 @@ int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* d
   return 0;
 }
 
+int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* row_lo, const uint64_t* row_hi,
+                     uint32_t n_rows, uint32_t first_doc_id, uint64_t row_stride_bytes, uint8_t* nib, hipStream_t s) {
+  for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
+    const uint32_t nr = n_rows - r0 < 32768 ? n_rows - r0 : 32768;
+    hipLaunchKernelGGL(build_tfnib_kernel, dim3(64, nr), dim3(256), 0, s, docids, tf, row_lo + r0, row_hi + r0,
+                       first_doc_id, row_stride_bytes, nib + static_cast<uint64_t>(r0) * row_stride_bytes);
+    MGX_KCHECK();
+  }
+  return 0;
+}
+
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
                        uint32_t first_doc_id, uint32_t first_row, uint64_t tile_stride, uint64_t row_stride,
                        uint64_t* bitmaps, hipStream_t s) {
@@ -1930,6 +2250,20 @@ int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan,
     hipLaunchKernelGGL(wave_page_kernel<true>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
   else
     hipLaunchKernelGGL(wave_page_kernel<false>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchNibScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
+  const uint64_t grid = bt.n_items;
+  if (grid == 0) return 0;
+  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
+  if (plan.bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nib_score_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(nib_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
