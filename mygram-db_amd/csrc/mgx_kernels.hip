@@ -1302,6 +1302,15 @@ struct NibOffsets {
   uint32_t leaf, prog, misc, table, scratch, mbuf, tk_keys, tk_docs, total;
 };
 constexpr uint32_t kNibMatchBuf = 512;  // matches of one tile buffered per wave and round
+#ifndef MGX_NIB_WAVES
+#define MGX_NIB_WAVES 8
+#endif
+#ifndef MGX_NIB_UNROLL
+#define MGX_NIB_UNROLL 2
+#endif
+constexpr int kNibWaves = MGX_NIB_WAVES;     // autonomous waves per workgroup (they share the BM25 table)
+constexpr int kNibBlock = kNibWaves * 64;
+constexpr int kNibUnroll = MGX_NIB_UNROLL;   // matches in flight per lane in the scoring phase
 
 __host__ __device__ inline NibOffsets carve_nib(const WavePlan& p) {
   NibOffsets o;
@@ -1311,10 +1320,10 @@ __host__ __device__ inline NibOffsets carve_nib(const WavePlan& p) {
   o.misc = at;     at += 128;
   at = (at + 15u) & ~15u;
   o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
-  o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
-  o.mbuf = at;     at += kWavesPerBlock * kNibMatchBuf * 2;
-  o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
-  o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
+  o.scratch = at;  at += p.has_list ? kNibWaves * kWordsPerTile * 8 : 0;
+  o.mbuf = at;     at += kNibWaves * kNibMatchBuf * 2;
+  o.tk_keys = at;  at += kNibWaves * 2 * p.max_cap * 8;
+  o.tk_docs = at;  at += kNibWaves * 2 * p.max_cap * 4;
   o.total = at;
   return o;
 }
@@ -1338,7 +1347,7 @@ __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uin
   return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
 }
 
-__global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+__global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const NibOffsets no = carve_nib(plan);
   DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + no.leaf);
@@ -1353,13 +1362,13 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
   const uint32_t qi = it.query;
   const DevQuery q = bt.queries[qi];
   const uint32_t tdl = plan.table_dl;
-  for (uint32_t i = tid; i < q.n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
-  for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
+  for (uint32_t i = tid; i < q.n_leaves; i += kNibBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kNibBlock) prog[i] = bt.prog[q.prog_begin + i];
   {
     const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
     const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
     double2* dst = reinterpret_cast<double2*>(table);
-    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
+    for (uint32_t e = tid; e < n_pairs; e += kNibBlock) dst[e] = src[e];
   }
   WaveTopK tk;
   tk.cap = q.cap;
@@ -1398,7 +1407,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   const bool desc = q.descending != 0;
 
-  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kWavesPerBlock) {
+  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kNibWaves) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     wave_topk_refresh_gbound(tk);
     // ---- A. the program on this lane's four words ------------------------------------------------------------------
@@ -1451,13 +1460,13 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
       }
       wave_lds_sync();
       const uint32_t nm = min(kNibMatchBuf, n_left);
-      // ---- C. one match per lane, kScoreUnroll in flight -------------------------------------------------------------
-      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
-        bool valid[kScoreUnroll];
-        uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
-        uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
+      // ---- C. one match per lane, kNibUnroll in flight -------------------------------------------------------------
+      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kNibUnroll) {
+        bool valid[kNibUnroll];
+        uint32_t slot[kNibUnroll], dli[kNibUnroll];
+        uint32_t tfv[kNibUnroll][kWaveScoreSlots];
 #pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
+        for (int m = 0; m < kNibUnroll; ++m) {
           valid[m] = false;
           slot[m] = 0;
           dli[m] = 0;
@@ -1478,7 +1487,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
         }
         bool slow = false;
 #pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
+        for (int m = 0; m < kNibUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
             const uint32_t sh = (slot[m] & 1u) * 4u;
 #pragma unroll
@@ -1491,7 +1500,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
         }
         if (__ballot(slow) != 0) {  // wave-uniform, rare: saturated nibble or doc length
 #pragma unroll
-          for (int m = 0; m < kScoreUnroll; ++m) {
+          for (int m = 0; m < kNibUnroll; ++m) {
             if (valid[m]) {
 #pragma unroll
               for (int i = 0; i < kWaveScoreSlots; ++i)
@@ -1501,7 +1510,7 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
           }
         }
 #pragma unroll
-        for (int m = 0; m < kScoreUnroll; ++m) {
+        for (int m = 0; m < kNibUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
             double score = 0.0;
 #pragma unroll
@@ -1546,20 +1555,20 @@ __global__ __launch_bounds__(kWaveBlock, 4) void nib_score_kernel(DevIndex ix, D
     const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + no.tk_keys);
     const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + no.tk_docs);
     const uint32_t cap = q.cap;
-    uint32_t have[kWavesPerBlock];
+    uint32_t have[kNibWaves];
     uint32_t total = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) {
+    for (int w = 0; w < kNibWaves; ++w) {
       have[w] = min(misc[w], q.needed);
       total += have[w];
     }
     const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
-    for (uint32_t e = tid; e < kWavesPerBlock * cap; e += kWaveBlock) {
+    for (uint32_t e = tid; e < kNibWaves * cap; e += kNibBlock) {
       const uint32_t w = e / cap, i = e % cap;
       if (i >= have[w]) continue;
       const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
       const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
       uint32_t rank = i;
-      for (uint32_t w2 = 0; w2 < kWavesPerBlock; ++w2) {
+      for (uint32_t w2 = 0; w2 < kNibWaves; ++w2) {
         if (w2 == w) continue;
         const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
         const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
@@ -2263,7 +2272,7 @@ int LaunchNibScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(nib_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
+  hipLaunchKernelGGL(nib_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kNibBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
