@@ -5,7 +5,7 @@ CSRC := mygram-db_amd/csrc
 LIB := mygram-db_amd/libmygram_gpu.so
 # -ffp-contract=off: BM25 arithmetic must round exactly like the reference's fp64 expression (no fused multiply-add)
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Iinclude
-HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS) $(EXTRA_DEFS)
+HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
 OBJS := $(CSRC)/mgx_kernels.o $(CSRC)/mgx_api.o $(CSRC)/mgx_columns.o $(CSRC)/mgx_tools.o
 

@@ -107,7 +107,7 @@ struct mgx_index {
   hipStream_t side_stream = nullptr;  // the few queries the wave kernel cannot take run here, beside the main launch
   std::mutex mu;  // serialises the single-operator entry points and filter registration
   mgx::DevIndex dev{};
-  DevBuf d_offsets, d_docids, d_tf, d_tfdl, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
+  DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
   DevBuf d_dl8, d_tfnib;
   std::vector<uint64_t> h_offsets;
@@ -212,10 +212,6 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
     MGX_HIP(mgx::Upload(idx->d_tf, d->tf, P, 4));
     MGX_HIP(mgx::Upload(idx->d_doc_len, d->doc_len, n_docs));
     for (uint64_t i = 0; i < n_docs; ++i) max_doc_len = std::max(max_doc_len, d->doc_len[i]);
-    MGX_HIP(idx->d_tfdl.Alloc((P + 4) * sizeof(uint16_t)));
-    MGX_LAUNCH(mgx::LaunchBuildTfDl(idx->d_docids.as<uint32_t>(), idx->d_tf.as<uint8_t>(),
-                                    idx->d_doc_len.as<uint32_t>(), P, d->first_doc_id, idx->d_tfdl.as<uint16_t>(),
-                                    idx->stream));
   }
 
   // which grams get a skip row / a dense bitmap
@@ -284,7 +280,6 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.offsets = idx->d_offsets.as<uint64_t>();
   v.docids = idx->d_docids.as<uint32_t>();
   v.tf = idx->d_tf.as<uint8_t>();
-  v.tfdl = idx->d_tfdl.as<uint16_t>();
   v.doc_len = idx->d_doc_len.as<uint32_t>();
   v.dl8 = idx->d_dl8.as<uint8_t>();
   v.tfnib = idx->d_tfnib.as<uint8_t>();
@@ -340,7 +335,7 @@ int mgx_posting_size(const mgx_index* idx, uint32_t gram_id, uint64_t* out) {
 int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (out) *out = 0;
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
-  *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_tfdl.bytes + idx->d_doc_len.bytes +
+  *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
          idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes +
          idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes;
   return MGX_OK;
@@ -736,7 +731,6 @@ struct mgx_batch {
     mgx::DevBatch dev{};
     mgx::LdsPlan plan{};
     mgx::WavePlan wplan{};
-    bool use_nib = false;  // the wave share scores from doc-slot tf nibbles (nib_score_kernel)
     // score mode: queries the wave kernel can run (flat program, dense scored operands) and the rest are launched
     // separately, over disjoint item lists, into the same candidate arrays
     mgx::DevBatch dev_wave{};
@@ -867,10 +861,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       wi = std::max<uint32_t>(wi, dq[i].n_instr);
       wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    static const bool kUseNib = !(std::getenv("MGX_SCORE_KERNEL") && std::string(std::getenv("MGX_SCORE_KERNEL")) == "rank");
-    g.use_nib = kUseNib && b->idx->dev.tfnib != nullptr;
-    g.wplan = g.use_nib ? PlanNib(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list)
-                        : PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
+    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
     if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
   if (page_mode) {
@@ -1226,10 +1217,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
       MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
-      MGX_LAUNCH((g.use_nib ? LaunchNibScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
-      MGX_LAUNCH((g.use_nib ? LaunchNibScore : LaunchWaveScore)(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {

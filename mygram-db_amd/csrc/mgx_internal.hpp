@@ -106,7 +106,6 @@ struct DevIndex {
   const uint64_t* offsets;
   const uint32_t* docids;
   const uint8_t* tf;
-  const uint16_t* tfdl;       // [P] tf | min(doc_len,255) << 8 of the posting's doc: one gather gives a term's tf and the doc length
   const uint32_t* doc_len;
   const uint8_t* dl8;         // [n_docs] min(doc_len, 255)
   const uint8_t* tfnib;       // [bitmap rows][nib_row_stride] min(tf,15) by doc slot, two docs per byte (0 = absent)
@@ -183,8 +182,6 @@ struct WavePlan {
   uint32_t has_list;      // some operand needs the per-wave scatter bitmap
   uint32_t bytes;
 };
-WavePlan PlanNib(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
-                 bool has_list);
 WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
                   bool has_list);
 

@@ -175,16 +175,6 @@ __global__ void build_tfnib_kernel(const uint32_t* __restrict__ docids, const ui
   }
 }
 
-// tfdl[p] = tf[p] | min(doc_len[slot(p)], 255) << 8
-__global__ void build_tfdl_kernel(const uint32_t* __restrict__ docids, const uint8_t* __restrict__ tf,
-                                  const uint32_t* __restrict__ doc_len, uint64_t n_postings, uint32_t first_doc_id,
-                                  uint16_t* __restrict__ out) {
-  const uint64_t p = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (p >= n_postings) return;
-  const uint32_t dl = doc_len[docids[p] - first_doc_id];
-  out[p] = static_cast<uint16_t>(tf[p] | ((dl < 255u ? dl : 255u) << 8));
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // tile kernel
 // ---------------------------------------------------------------------------------------------------------------
@@ -826,34 +816,30 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 // ---------------------------------------------------------------------------------------------------------------
 //
 // Same work as tile_eval_kernel<kModeScore> for "flat" programs (LOAD/AND/OR/ANDNOT/COUNT only) whose scored terms
-// (at most kWaveScoreSlots) all have the precomputed dense-bitmap form. Built for occupancy: the kernel is bound by
-// memory latency, not bandwidth, so what counts is how many tiles a CU has in flight.
+// (at most kWaveScoreSlots) all have the dense form (bitmap row + doc-slot tf nibbles). Built for occupancy: the
+// kernel is bound by memory latency and issue slots, not bandwidth, so what counts is how many tiles a CU has in flight.
 //   * a workgroup is 8 waves that share nothing but the query's BM25 table; each WAVE owns whole 16384-doc tiles
 //     (tile = tile_begin + wave, +8, ...) and never meets a workgroup barrier inside the tile loop;
-//   * phase A: a lane owns 4 consecutive 64-bit words (256 doc slots) of every operand (two 16-byte loads per
-//     bitmap-form operand; sorted lists go through a 2 KiB per-wave LDS bitmap) and evaluates the program in registers;
-//     the words of scored operands stay in registers with the wave-prefix popcount of the lane's first doc slot;
-//   * the tile is then scored in four steps, one per owned word index k: every lane parks word k of each scored
-//     operand in a 512-byte per-wave LDS strip together with the number of the operand's postings that precede its
-//     two 32-bit halves inside the tile (wave-prefix + in-lane popcounts);
-//   * phase B: every lane appends the matches of its word k (12-bit: owner lane, bit) to the wave's match buffer;
-//   * phase C: the step's matches are scored one per lane, kScoreUnroll per lane in flight. The posting index of a
-//     match in a scored term's tf column is tile_off + parked prefix + popcount(parked bits below), so it costs two
-//     LDS reads and exactly ONE gather per scored term: the first term's gather reads the packed (tf, doc_len)
-//     posting column, the others the tf column. The vector L1 handles about one lane-request per clock, so gathers
-//     per match — not bytes — are what this phase is bound by; then one LDS table read per term;
+//   * A: a lane owns 4 consecutive 64-bit words (256 doc slots) of every operand (two 16-byte loads per bitmap-form
+//     operand; sorted lists go through a 2 KiB per-wave LDS bitmap) and evaluates the program in registers;
+//   * B: every lane appends its matches (14-bit slot inside the tile) to the wave's match buffer;
+//   * C: matches are scored one per lane, kScoreUnroll per lane in flight. A match's tf under scored term i is the
+//     nibble tfnib[row_i][slot/2] and its doc length dl8[slot] — both addressed by the doc slot alone, so there are no
+//     ranks, no prefix popcounts and no parked operand words: T+1 byte gathers, then one LDS table read per term.
+//     Nibble 15 (tf >= 15) and dl8 255 take an exact slow path (binary search of the posting segment / the u32
+//     doc_len), both rare;
 //   * BM25 term contributions idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) are tabulated once per workgroup in LDS for
-//     tf <= 8 and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84); anything outside
-//     the table is computed directly;
+//     tf <= kTableTf and dl < table_dl with the reference's exact operation order (bm25_scorer.cpp:80-84); anything
+//     outside the table is computed directly;
 //   * every wave keeps its own running top-k (WaveTopK) pruned by the query-wide bound; the lists are merged at the end.
+// 80 VGPRs (12 B spill), ~42 KB LDS: 3 workgroups = 24 waves per CU. (An earlier version located tf through the
+// posting rank — prefix popcounts, operand words parked in LDS, per-step re-fetch — and was 1.4x slower.)
 
-constexpr uint32_t kWaveMatchBuf = 256;  // matches buffered per wave between enumeration and scoring
-constexpr int kStepWords = 2;            // owned words enumerated and scored together (a tile is 4 / kStepWords steps)
-constexpr uint32_t kStripWords = 192 * kStepWords;  // u32 per parked operand: 64 x 2W half-words + 64 x W packed prefixes
 constexpr int kScoreUnroll = 2;          // matches in flight per lane in phase C
+constexpr uint32_t kWaveMatchBuf = 512;  // matches of one tile buffered per wave and round
 
 struct WaveOffsets {
-  uint32_t prog, leaf, table, scratch, park, mbuf, tk_keys, tk_docs, misc, total;
+  uint32_t leaf, prog, misc, table, scratch, mbuf, tk_keys, tk_docs, total;
 };
 
 __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
@@ -861,11 +847,10 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
   uint32_t at = 0;
   o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
   o.prog = at;     at += align8(p.max_instr * 4);
-  o.misc = at;     at += 64;
+  o.misc = at;     at += 128;
   at = (at + 15u) & ~15u;
   o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
   o.scratch = at;  at += p.has_list ? kWavesPerBlock * kWordsPerTile * 8 : 0;
-  o.park = at;     at += kWavesPerBlock * p.max_score * kStripWords * 4;
   o.mbuf = at;     at += kWavesPerBlock * kWaveMatchBuf * 2;
   o.tk_keys = at;  at += kWavesPerBlock * 2 * p.max_cap * 8;
   o.tk_docs = at;  at += kWavesPerBlock * 2 * p.max_cap * 4;
@@ -973,369 +958,6 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
   }
 }
 
-// (A variant compiled without the sorted-list operand path allocates registers worse and runs 14 % slower on the
-// all-bitmap benchmark batch — measured — so there is one kernel.)
-__global__ __launch_bounds__(kWaveBlock, 4) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const WaveOffsets wo = carve_wave(plan);
-  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + wo.leaf);
-  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + wo.prog);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + wo.misc);
-  double* const table = reinterpret_cast<double*>(smem + wo.table);
-  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
-  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
-  // parked strips of this wave: operand i -> 128 x u32 half-words, then 64 x u32 packed prefixes (lo | hi << 16)
-  uint32_t* const park =
-      reinterpret_cast<uint32_t*>(smem + wo.park) + static_cast<size_t>(wave) * plan.max_score * kStripWords;
-
-  const DevItem it = bt.items[blockIdx.x];
-  const uint32_t qi = it.query;
-  const DevQuery q = bt.queries[qi];
-  const uint32_t n_leaves = q.n_leaves;
-  const uint32_t tdl = plan.table_dl;
-  for (uint32_t i = tid; i < n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
-  for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
-  // BM25 contribution tables table[(i*kTableTf + tf-1)*tdl + dl]: built on the host when the batch was prepared (same
-  // fp64 operation order as bm25_scorer.cpp:80-84), copied here with 16-byte loads
-  {
-    const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
-    const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
-    double2* dst = reinterpret_cast<double2*>(table);
-    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
-  }
-
-  WaveTopK tk;
-  tk.cap = q.cap;
-  tk.needed = q.needed;
-  tk.keys = reinterpret_cast<uint64_t*>(smem + wo.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
-  tk.docs = reinterpret_cast<uint32_t*>(smem + wo.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
-  tk.have = 0;
-  tk.pend = 0;
-  tk.bound_key = 0;
-  tk.bound_doc = 0;
-  tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
-  tk.gbound = 0;
-  for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
-    tk.keys[i] = 0;
-    tk.docs[i] = 0;
-  }
-  __syncthreads();
-
-  // per scored term: where its tf column starts (kept in LDS: it is needed once per tile, registers are scarce)
-  uint64_t* const tf_base = reinterpret_cast<uint64_t*>(misc + 8);
-  if (tid < q.n_score) tf_base[tid] = ix.offsets[bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf].a];
-  __syncthreads();
-  const uint64_t* sbits[kWaveScoreSlots];  // bitmap row base of every scored operand (all in dense form here)
-#pragma unroll
-  for (int i = 0; i < kWaveScoreSlots; ++i) {
-    sbits[i] = ix.gram_bitmaps;
-    if (static_cast<uint32_t>(i) < q.n_score)
-      sbits[i] = ix.gram_bitmaps +
-                 wave_uniform(leaf[bt.score_terms[q.score_begin + i].leaf].b) * ix.gb_row_stride;
-  }
-
-  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
-  const uint32_t tile_begin = it.tile_begin;
-  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
-  const bool desc = q.descending != 0;
-
-  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kWavesPerBlock) {
-    const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
-    wave_topk_refresh_gbound(tk);
-    uint64_t acc[4] = {0, 0, 0, 0};
-
-    // ---- phase A: program ------------------------------------------------------------------------------------------
-    uint32_t srel[kWaveScoreSlots];   // postings of the scored operand inside this tile before this lane's words
-    uint64_t tf_tile[kWaveScoreSlots];  // tf column position of the tile's first posting
-#pragma unroll
-    for (int i = 0; i < kWaveScoreSlots; ++i) {
-      srel[i] = 0;
-      tf_tile[i] = 0;
-    }
-    for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
-      const uint32_t ins = prog[pc];
-      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
-      if (op == kOpCount) {
-        const uint32_t pcnt = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
-        cnt0 += (arg & 1u) ? pcnt : 0;
-        cnt1 += (arg & 2u) ? pcnt : 0;
-        cnt2 += (arg & 4u) ? pcnt : 0;
-        cnt3 += (arg & 8u) ? pcnt : 0;
-        continue;
-      }
-      const DevLeaf lf = leaf[arg];
-      uint64_t w[4];
-      uint32_t seg_rel;
-      wave_fetch_operand(ix, bt, lf, tile, tile_first, scratch, w, &seg_rel);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (op == kOpLoad) acc[k] = w[k];
-        else if (op == kOpAnd) acc[k] &= w[k];
-        else if (op == kOpOr) acc[k] |= w[k];
-        else if (op == kOpAndNot) acc[k] &= ~w[k];
-      }
-      if (lf.score_slot != kNoSlot) {
-        uint32_t tot;
-        const uint32_t rel =
-            wave_excl_scan_total(__popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]), &tot);
-#pragma unroll
-        for (int i = 0; i < kWaveScoreSlots; ++i) {
-          if (lf.score_slot == static_cast<uint32_t>(i)) {
-            srel[i] = rel;
-            tf_tile[i] = wave_uniform(tf_base[i] + seg_rel);
-          }
-        }
-      }
-    }
-    cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
-    if (bt.debug_skip & 2u) continue;
-
-    // ---- 4 / kStepWords steps, each over kStepWords of the lane's owned words -----------------------------------------
-#pragma unroll
-    for (int h = 0; h < 4 / kStepWords; ++h) {
-      // the step's words of every scored operand again (8 B per lane and word; the lines were streamed by phase A a
-      // moment ago): holding 4 words x 3 operands in registers across the whole tile costs more than these L1/L2 hits
-      uint2 swk[kWaveScoreSlots][kStepWords];
-      uint64_t any = 0;
-#pragma unroll
-      for (int wi = 0; wi < kStepWords; ++wi) any |= acc[h * kStepWords + wi];
-#pragma unroll
-      for (int i = 0; i < kWaveScoreSlots; ++i) {
-#pragma unroll
-        for (int wi = 0; wi < kStepWords; ++wi) {
-          swk[i][wi] = make_uint2(0, 0);
-          if (static_cast<uint32_t>(i) < q.n_score)  // wave-uniform
-            swk[i][wi] = *reinterpret_cast<const uint2*>(sbits[i] + tile * ix.gb_tile_stride + lane * 4 +
-                                                         h * kStepWords + wi);
-        }
-      }
-      if (__ballot(any != 0) == 0) {  // wave-uniform: no match in this step; only advance the prefixes
-#pragma unroll
-        for (int i = 0; i < kWaveScoreSlots; ++i)
-#pragma unroll
-          for (int wi = 0; wi < kStepWords; ++wi) srel[i] += __popc(swk[i][wi].x) + __popc(swk[i][wi].y);
-        continue;
-      }
-      // park the step's words of every scored operand with the postings that precede each 32-bit half inside the tile
-#pragma unroll
-      for (int i = 0; i < kWaveScoreSlots; ++i) {
-        if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-          uint32_t* strip = park + i * kStripWords;
-#pragma unroll
-          for (int wi = 0; wi < kStepWords; ++wi) {
-            const uint32_t lo = swk[i][wi].x, hi = swk[i][wi].y;
-            strip[lane * (2 * kStepWords) + 2 * wi] = lo;
-            strip[lane * (2 * kStepWords) + 2 * wi + 1] = hi;
-            const uint32_t plo = srel[i], phi = srel[i] + __popc(lo);
-            strip[128 * kStepWords + lane * kStepWords + wi] = plo | (phi << 16);
-            srel[i] = phi + __popc(hi);
-          }
-        }
-      }
-      // Rounds of at most kWaveMatchBuf matches: B consumes bits of the step's words (a lane resumes where it
-      // stopped), C scores.
-      for (;;) {
-        uint32_t n_left, mine = 0;
-#pragma unroll
-        for (int wi = 0; wi < kStepWords; ++wi) mine += __popcll(acc[h * kStepWords + wi]);
-        const uint32_t my_first = wave_excl_scan_total(mine, &n_left);
-        if (n_left == 0) break;  // wave-uniform
-        // ---- phase B: (owner lane, word, bit) of this lane's next matches into the wave's match buffer --------------
-        {
-          uint32_t r = my_first;
-#pragma unroll
-          for (int wi = 0; wi < kStepWords; ++wi) {
-            uint64_t& aw = acc[h * kStepWords + wi];
-            while (aw != 0 && r < kWaveMatchBuf) {
-              const uint32_t bit = __builtin_ctzll(aw);
-              aw &= aw - 1;
-              mbuf[r] = static_cast<uint16_t>((lane << 7) | (wi << 6) | bit);
-              ++r;
-            }
-          }
-        }
-        wave_lds_sync();
-        const uint32_t nm = min(kWaveMatchBuf, n_left);
-        // ---- phase C: score them, one match per lane, kScoreUnroll in flight ----------------------------------------
-        for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
-          bool valid[kScoreUnroll];
-          uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
-          uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
-          // all gathers of the iteration first: (tf, doc_len) of the first scored term's posting, tf of the others
-#pragma unroll
-          for (int m = 0; m < kScoreUnroll; ++m) {
-            valid[m] = false;
-            slot[m] = 0;
-            dli[m] = 0;
-#pragma unroll
-            for (int i = 0; i < kWaveScoreSlots; ++i) tfv[m][i] = 0;
-            tfv[m][0] = 0xFF00u;  // (tf 0, "doc length not known yet")
-            if (j0 + m * 64 < nm) {  // wave-uniform
-              const uint32_t j = j0 + m * 64 + lane;
-              valid[m] = j < nm;
-              if (valid[m]) {
-                const uint32_t e = mbuf[j];
-                const uint32_t owner = e >> 7, wi = (e >> 6) & 1u, bit = e & 63u;
-                const uint32_t hw = owner * (2 * kStepWords) + wi * 2 + (bit >> 5), mask = 1u << (bit & 31u);
-                slot[m] = tile * kTileDocs + owner * 256 + (h * kStepWords + wi) * 64 + bit;
-#pragma unroll
-                for (int i = 0; i < kWaveScoreSlots; ++i) {
-                  if (static_cast<uint32_t>(i) < q.n_score) {  // wave-uniform
-                    const uint32_t* strip = park + i * kStripWords;
-                    const uint32_t wbits = strip[hw];
-                    if (wbits & mask) {
-                      const uint32_t pp = strip[128 * kStepWords + owner * kStepWords + wi];
-                      const uint32_t rank = ((bit >> 5) ? pp >> 16 : pp & 0xFFFFu) + __popc(wbits & (mask - 1u));
-                      // the loaded values are first looked at after every gather of the iteration has been issued
-                      if (i == 0) tfv[m][0] = ix.tfdl[tf_tile[0] + rank];
-                      else tfv[m][i] = ix.tf[tf_tile[i] + rank];
-                    }
-                  }
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int m = 0; m < kScoreUnroll; ++m) {
-            if (j0 + m * 64 < nm) {  // wave-uniform
-              dli[m] = tfv[m][0] >> 8;
-              tfv[m][0] &= 0xFFu;
-              // saturated, or the doc lacks the first term
-              if (valid[m] && dli[m] == 255u) dli[m] = ix.doc_len[slot[m]];
-            }
-          }
-          // contributions and top-k
-#pragma unroll
-          for (int m = 0; m < kScoreUnroll; ++m) {
-            if (j0 + m * 64 < nm) {  // wave-uniform
-              double score = 0.0;
-#pragma unroll
-              for (int i = 0; i < kWaveScoreSlots; ++i) {
-                if (tfv[m][i] != 0) {
-                  if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
-                    score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
-                  } else {  // bm25_scorer.cpp:80-84, same operation order as the table
-                    const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
-                    const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
-                    const double numerator = tf * q.k1_plus_1;
-                    const double denominator = tf + q.k1 * length_norm;
-                    score += bt.score_terms[q.score_begin + i].idf * numerator / denominator;
-                  }
-                }
-              }
-              const uint32_t doc = ix.first_doc_id + slot[m];
-              wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
-            }
-          }
-        }
-        wave_lds_sync();
-      }
-    }
-  }
-
-  {
-    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-      uint32_t x = v[s];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + s], (unsigned long long)x);
-    }
-  }
-
-  // ---- merge the waves' lists into this workgroup's best `needed`, best first, to HBM -------------------------------
-  wave_topk_truncate(tk);
-  if (lane == 0) misc[wave] = tk.have;
-  __syncthreads();
-  {
-    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + wo.tk_keys);
-    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + wo.tk_docs);
-    const uint32_t cap = q.cap;
-    uint32_t have[kWavesPerBlock];
-    uint32_t total = 0;
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-      have[w] = min(misc[w], q.needed);
-      total += have[w];
-    }
-    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
-    for (uint32_t e = tid; e < kWavesPerBlock * cap; e += kWaveBlock) {
-      const uint32_t w = e / cap, i = e % cap;
-      if (i >= min(misc[w], q.needed)) continue;
-      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
-      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
-      uint32_t rank = i;
-      for (uint32_t w2 = 0; w2 < kWavesPerBlock; ++w2) {
-        if (w2 == w) continue;
-        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
-        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
-        uint32_t lo = 0, hi = min(misc[w2], q.needed);
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
-        }
-        rank += lo;
-      }
-      if (rank < q.needed) {
-        bt.cand_keys[obase + rank] = k;
-        bt.cand_docs[obase + rank] = d;
-      }
-    }
-    (void)have;
-    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// scoring kernel over doc-slot tf nibbles (no ranks)
-// ---------------------------------------------------------------------------------------------------------------
-//
-// Same contract as wave_score_kernel, different data path for the scoring phase: a match's tf under scored term i is
-// the nibble tfnib[row_i][slot/2] and its doc length is dl8[slot], both addressed by the doc slot alone. So nothing of
-// the rank machinery is needed (no prefix popcounts in the operand phase, no parked operand words, no per-step
-// re-fetch): a tile is  A. program on 4 words per lane  B. all matches of the tile into the match buffer
-// C. one match per lane: T+1 byte gathers, table lookups, top-k offer. Nibble 15 (tf >= 15) and dl8 255 take an exact
-// slow path (binary search of the posting segment / the u32 doc_len), both rare.
-
-struct NibOffsets {
-  uint32_t leaf, prog, misc, table, scratch, mbuf, tk_keys, tk_docs, total;
-};
-constexpr uint32_t kNibMatchBuf = 512;  // matches of one tile buffered per wave and round
-#ifndef MGX_NIB_WAVES
-#define MGX_NIB_WAVES 8
-#endif
-#ifndef MGX_NIB_UNROLL
-#define MGX_NIB_UNROLL 2
-#endif
-constexpr int kNibWaves = MGX_NIB_WAVES;     // autonomous waves per workgroup (they share the BM25 table)
-constexpr int kNibBlock = kNibWaves * 64;
-constexpr int kNibUnroll = MGX_NIB_UNROLL;   // matches in flight per lane in the scoring phase
-
-__host__ __device__ inline NibOffsets carve_nib(const WavePlan& p) {
-  NibOffsets o;
-  uint32_t at = 0;
-  o.leaf = at;     at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
-  o.prog = at;     at += align8(p.max_instr * 4);
-  o.misc = at;     at += 128;
-  at = (at + 15u) & ~15u;
-  o.table = at;    at += ((p.max_score * kTableTf * p.table_dl + 1u) & ~1u) * 8;
-  o.scratch = at;  at += p.has_list ? kNibWaves * kWordsPerTile * 8 : 0;
-  o.mbuf = at;     at += kNibWaves * kNibMatchBuf * 2;
-  o.tk_keys = at;  at += kNibWaves * 2 * p.max_cap * 8;
-  o.tk_docs = at;  at += kNibWaves * 2 * p.max_cap * 4;
-  o.total = at;
-  return o;
-}
-
-WavePlan PlanNib(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
-                 bool has_list) {
-  WavePlan p{max_leaves ? max_leaves : 1, max_score, max_instr ? max_instr : 1, max_cap, 0, has_list ? 1u : 0u, 0};
-  p.table_dl = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
-  p.bytes = carve_nib(p).total;
-  return p;
-}
-
 // exact tf of gram `g` in the doc at `slot` (the nibble saturated): binary search of the tile's posting segment
 __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot) {
   const uint32_t tile = slot >> kTileShift;
@@ -1347,34 +969,34 @@ __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uin
   return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
 }
 
-__global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+__global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const NibOffsets no = carve_nib(plan);
-  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + no.leaf);
-  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + no.prog);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + no.misc);
-  double* const table = reinterpret_cast<double*>(smem + no.table);
+  const WaveOffsets wo = carve_wave(plan);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + wo.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + wo.prog);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + wo.misc);
+  double* const table = reinterpret_cast<double*>(smem + wo.table);
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-  uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + no.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
-  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + no.mbuf) + static_cast<size_t>(wave) * kNibMatchBuf;
+  uint64_t* const scratch = reinterpret_cast<uint64_t*>(smem + wo.scratch) + static_cast<size_t>(wave) * kWordsPerTile;
+  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(smem + wo.mbuf) + static_cast<size_t>(wave) * kWaveMatchBuf;
 
   const DevItem it = bt.items[blockIdx.x];
   const uint32_t qi = it.query;
   const DevQuery q = bt.queries[qi];
   const uint32_t tdl = plan.table_dl;
-  for (uint32_t i = tid; i < q.n_leaves; i += kNibBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
-  for (uint32_t i = tid; i < q.n_instr; i += kNibBlock) prog[i] = bt.prog[q.prog_begin + i];
+  for (uint32_t i = tid; i < q.n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
   {
     const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
     const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
     double2* dst = reinterpret_cast<double2*>(table);
-    for (uint32_t e = tid; e < n_pairs; e += kNibBlock) dst[e] = src[e];
+    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
   }
   WaveTopK tk;
   tk.cap = q.cap;
   tk.needed = q.needed;
-  tk.keys = reinterpret_cast<uint64_t*>(smem + no.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
-  tk.docs = reinterpret_cast<uint32_t*>(smem + no.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.keys = reinterpret_cast<uint64_t*>(smem + wo.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + wo.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
   tk.have = 0;
   tk.pend = 0;
   tk.bound_key = 0;
@@ -1407,7 +1029,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   const bool desc = q.descending != 0;
 
-  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kNibWaves) {
+  for (uint32_t tile = tile_begin + wave; tile < tile_end; tile += kWavesPerBlock) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     wave_topk_refresh_gbound(tk);
     // ---- A. the program on this lane's four words ------------------------------------------------------------------
@@ -1439,7 +1061,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
     cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
     if (bt.debug_skip & 2u) continue;
 
-    // Rounds of at most kNibMatchBuf matches: B consumes bits of acc (a lane resumes where it stopped), C scores.
+    // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc (a lane resumes where it stopped), C scores.
     for (;;) {
       uint32_t n_left;
       const uint32_t mine = __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
@@ -1450,7 +1072,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
         uint32_t r = my_first;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          while (acc[k] != 0 && r < kNibMatchBuf) {
+          while (acc[k] != 0 && r < kWaveMatchBuf) {
             const uint32_t bit = __builtin_ctzll(acc[k]);
             acc[k] &= acc[k] - 1;
             mbuf[r] = static_cast<uint16_t>((lane << 8) | (k << 6) | bit);  // = the doc's slot inside the tile
@@ -1459,14 +1081,14 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
         }
       }
       wave_lds_sync();
-      const uint32_t nm = min(kNibMatchBuf, n_left);
-      // ---- C. one match per lane, kNibUnroll in flight -------------------------------------------------------------
-      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kNibUnroll) {
-        bool valid[kNibUnroll];
-        uint32_t slot[kNibUnroll], dli[kNibUnroll];
-        uint32_t tfv[kNibUnroll][kWaveScoreSlots];
+      const uint32_t nm = min(kWaveMatchBuf, n_left);
+      // ---- C. one match per lane, kScoreUnroll in flight -------------------------------------------------------------
+      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
+        bool valid[kScoreUnroll];
+        uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
+        uint32_t tfv[kScoreUnroll][kWaveScoreSlots];
 #pragma unroll
-        for (int m = 0; m < kNibUnroll; ++m) {
+        for (int m = 0; m < kScoreUnroll; ++m) {
           valid[m] = false;
           slot[m] = 0;
           dli[m] = 0;
@@ -1487,7 +1109,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
         }
         bool slow = false;
 #pragma unroll
-        for (int m = 0; m < kNibUnroll; ++m) {
+        for (int m = 0; m < kScoreUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
             const uint32_t sh = (slot[m] & 1u) * 4u;
 #pragma unroll
@@ -1500,7 +1122,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
         }
         if (__ballot(slow) != 0) {  // wave-uniform, rare: saturated nibble or doc length
 #pragma unroll
-          for (int m = 0; m < kNibUnroll; ++m) {
+          for (int m = 0; m < kScoreUnroll; ++m) {
             if (valid[m]) {
 #pragma unroll
               for (int i = 0; i < kWaveScoreSlots; ++i)
@@ -1510,7 +1132,7 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
           }
         }
 #pragma unroll
-        for (int m = 0; m < kNibUnroll; ++m) {
+        for (int m = 0; m < kScoreUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
             double score = 0.0;
 #pragma unroll
@@ -1552,23 +1174,23 @@ __global__ __launch_bounds__(kNibBlock, 6) void nib_score_kernel(DevIndex ix, De
   if (lane == 0) misc[wave] = tk.have;
   __syncthreads();
   {
-    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + no.tk_keys);
-    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + no.tk_docs);
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + wo.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + wo.tk_docs);
     const uint32_t cap = q.cap;
-    uint32_t have[kNibWaves];
+    uint32_t have[kWavesPerBlock];
     uint32_t total = 0;
-    for (int w = 0; w < kNibWaves; ++w) {
+    for (int w = 0; w < kWavesPerBlock; ++w) {
       have[w] = min(misc[w], q.needed);
       total += have[w];
     }
     const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
-    for (uint32_t e = tid; e < kNibWaves * cap; e += kNibBlock) {
+    for (uint32_t e = tid; e < kWavesPerBlock * cap; e += kWaveBlock) {
       const uint32_t w = e / cap, i = e % cap;
       if (i >= have[w]) continue;
       const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
       const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
       uint32_t rank = i;
-      for (uint32_t w2 = 0; w2 < kNibWaves; ++w2) {
+      for (uint32_t w2 = 0; w2 < kWavesPerBlock; ++w2) {
         if (w2 == w) continue;
         const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
         const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
@@ -2177,17 +1799,6 @@ int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const ui
   return 0;
 }
 
-int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* doc_len, uint64_t n_postings,
-                    uint32_t first_doc_id, uint16_t* out, hipStream_t s) {
-  if (n_postings == 0) return 0;
-  const uint64_t blocks = (n_postings + 255) / 256;
-  if (blocks > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  hipLaunchKernelGGL(build_tfdl_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, s, docids, tf, doc_len,
-                     n_postings, first_doc_id, out);
-  MGX_KCHECK();
-  return 0;
-}
-
 int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* row_lo, const uint64_t* row_hi,
                      uint32_t n_rows, uint32_t first_doc_id, uint64_t row_stride_bytes, uint8_t* nib, hipStream_t s) {
   for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
@@ -2259,20 +1870,6 @@ int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan,
     hipLaunchKernelGGL(wave_page_kernel<true>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
   else
     hipLaunchKernelGGL(wave_page_kernel<false>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
-  MGX_KCHECK();
-  return 0;
-}
-
-int LaunchNibScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
-  const uint64_t grid = bt.n_items;
-  if (grid == 0) return 0;
-  if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  if (plan.bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nib_score_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
-    if (e != hipSuccess) return static_cast<int>(e);
-  }
-  hipLaunchKernelGGL(nib_score_kernel, dim3(static_cast<uint32_t>(grid)), dim3(kNibBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }

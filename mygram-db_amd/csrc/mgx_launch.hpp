@@ -13,12 +13,9 @@ int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* 
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
                        uint32_t first_doc_id, uint32_t first_row, uint64_t tile_stride, uint64_t row_stride,
                        uint64_t* bitmaps, hipStream_t s);
-int LaunchBuildTfDl(const uint32_t* docids, const uint8_t* tf, const uint32_t* doc_len, uint64_t n_postings,
-                    uint32_t first_doc_id, uint16_t* out, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
-int LaunchNibScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
 
