@@ -851,7 +851,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
-      // the wave kernel re-reads the words of scored operands from their dense (bitmap) form
+      // scored terms must be dense grams (tf nibbles by doc slot). The kernel could score sparse ones through its exact
+      // posting lookup, but one list operand in the launch costs every workgroup the 16 KB scatter scratch (2 instead of
+      // 3 workgroups per CU: measured 12 % slower), so those few queries stay on the workgroup kernel.
       for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
       if (!ok) continue;
       on_wave[i] = 1;

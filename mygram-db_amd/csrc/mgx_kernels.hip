@@ -958,12 +958,17 @@ __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const Dev
   }
 }
 
-// exact tf of gram `g` in the doc at `slot` (the nibble saturated): binary search of the tile's posting segment
+// exact tf of gram `g` in the doc at `slot` (the nibble saturated, or the gram has no nibble row because its list is
+// sparse): binary search of the tile's posting segment; 0 when the doc lacks the gram
 __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot) {
   const uint32_t tile = slot >> kTileShift;
-  const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
   const uint64_t l0 = ix.offsets[g];
-  const uint64_t lo = l0 + r[tile], hi = l0 + r[tile + 1];
+  uint64_t lo = l0, hi = ix.offsets[g + 1];
+  if (row != kNoRow) {  // short lists have no skip row: the whole list is the segment
+    const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+    hi = l0 + r[tile + 1];
+    lo = l0 + r[tile];
+  }
   const uint32_t d = ix.first_doc_id + slot;
   const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
   return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
@@ -1013,15 +1018,20 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
     const DevLeaf lf = bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf];
     sterm[tid * 3] = lf.a;
     sterm[tid * 3 + 1] = lf.row;
-    sterm[tid * 3 + 2] = lf.b;
+    sterm[tid * 3 + 2] = lf.kind == kLeafGramBitmap ? lf.b : kNoRow;
   }
   __syncthreads();
+  // A scored term whose gram is sparse (list form) has no nibble row: it reads as "saturated" and takes the exact path.
   const uint8_t* nib[kWaveScoreSlots];
+  uint32_t no_nib = 0;
 #pragma unroll
   for (int i = 0; i < kWaveScoreSlots; ++i) {
     nib[i] = ix.tfnib;
-    if (static_cast<uint32_t>(i) < q.n_score)
-      nib[i] = ix.tfnib + static_cast<uint64_t>(wave_uniform(sterm[i * 3 + 2])) * ix.nib_row_stride;
+    if (static_cast<uint32_t>(i) < q.n_score) {
+      const uint32_t brow = wave_uniform(sterm[i * 3 + 2]);
+      if (brow == kNoRow) no_nib |= 1u << i;
+      else nib[i] = ix.tfnib + static_cast<uint64_t>(brow) * ix.nib_row_stride;
+    }
   }
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
@@ -1102,7 +1112,8 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
               // every gather of the iteration is issued before any of them is looked at
 #pragma unroll
               for (int i = 0; i < kWaveScoreSlots; ++i)
-                if (static_cast<uint32_t>(i) < q.n_score) tfv[m][i] = nib[i][slot[m] >> 1];
+                if (static_cast<uint32_t>(i) < q.n_score)
+                  tfv[m][i] = (no_nib >> i) & 1u ? 0xFFu : static_cast<uint32_t>(nib[i][slot[m] >> 1]);
               dli[m] = ix.dl8[slot[m]];
             }
           }
