@@ -736,6 +736,10 @@ struct mgx_batch {
     mgx::DevBatch dev_wave{};
     DevBuf d_items_wave, d_tables;
     uint32_t n_items_wave = 0;
+    // score mode: wave-kernel queries with a sorted-list operand (bigger LDS plan, launched beside the others)
+    mgx::WavePlan wplan_lists{};
+    mgx::DevBatch dev_wave_lists{};
+    DevBuf d_items_wave_lists;
     // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
     mgx::DevBatch dev_page_wave{}, dev_page_block{};
     DevBuf d_pq_wave, d_pq_block;
@@ -851,20 +855,25 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
-      // scored terms must be dense grams (tf nibbles by doc slot). The kernel could score sparse ones through its exact
-      // posting lookup, but one list operand in the launch costs every workgroup the 16 KB scatter scratch (2 instead of
-      // 3 workgroups per CU: measured 12 % slower), so those few queries stay on the workgroup kernel.
-      for (const DevScoreTerm& st : s.score) ok = ok && s.leaves[st.leaf].kind == kLeafGramBitmap;
+      // scored terms: dense grams (tf nibbles by doc slot) or sparse ones (exact posting lookup per match)
+      for (const DevScoreTerm& st : s.score)
+        ok = ok && (s.leaves[st.leaf].kind == kLeafGramBitmap || s.leaves[st.leaf].kind == kLeafList);
       if (!ok) continue;
-      on_wave[i] = 1;
-      for (const DevLeaf& lf : s.leaves) has_list = has_list || lf.kind == kLeafList || lf.kind == kLeafExplicit;
+      // A sorted-list operand needs the per-wave scatter scratch (16 KB per workgroup: 2 instead of 3 workgroups per
+      // CU), so queries with one are launched separately and the all-bitmap majority keeps the small LDS plan.
+      bool lists = false;
+      for (const DevLeaf& lf : s.leaves) lists = lists || lf.kind == kLeafList || lf.kind == kLeafExplicit;
+      on_wave[i] = lists ? 2 : 1;
+      has_list = has_list || lists;
       wl = std::max<uint32_t>(wl, dq[i].n_leaves);
       wsc = std::max<uint32_t>(wsc, dq[i].n_score);
       wi = std::max<uint32_t>(wi, dq[i].n_instr);
       wc = std::max<uint32_t>(wc, dq[i].cap);
     }
-    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, has_list);
-    if (g.wplan.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
+    g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, false);
+    g.wplan_lists = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, true);
+    (void)has_list;
+    if (g.wplan_lists.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
   if (page_mode) {
     // flat programs count on the wave kernel (registers only, two tiles in flight per wave)
@@ -981,8 +990,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
   }
   const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
-  std::vector<DevItem> items_wave, items_block;
-  for (const DevItem& it : items) (on_wave[it.query] ? items_wave : items_block).push_back(it);
+  std::vector<DevItem> items_wave, items_block, items_wave_lists;
+  for (const DevItem& it : items)
+    (on_wave[it.query] == 2 && score_mode ? items_wave_lists : on_wave[it.query] ? items_wave : items_block).push_back(it);
+  MGX_HIP(Upload(g.d_items_wave_lists, items_wave_lists.data(), items_wave_lists.size()));
   g.n_items = static_cast<uint32_t>(items_block.size());
   g.n_items_wave = static_cast<uint32_t>(items_wave.size());
   MGX_HIP(Upload(g.d_items, items_block.data(), items_block.size()));
@@ -990,7 +1001,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   MGX_HIP(Upload(g.d_list_begin, list_begin.data(), list_begin.size()));
   if (std::getenv("MGX_VERBOSE"))
     fprintf(stderr, "[mgx] %s group: %u queries; wave kernel %u items (lds %u B), block kernel %u items (lds %u B)\n",
-            score_mode ? "score" : "bitmap", n, g.n_items_wave, g.wplan.bytes, g.n_items, g.plan.bytes);
+            score_mode ? "score" : "bitmap", n, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()),
+            g.wplan.bytes, g.n_items, g.plan.bytes);
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
   d.n_items = g.n_items;
@@ -1048,7 +1060,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
   }
-  if (score_mode && g.n_items_wave != 0) {
+  if (score_mode && (g.n_items_wave != 0 || !items_wave_lists.empty())) {
     // BM25 contribution tables of the wave kernel: idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) for tf 1..8 and every doc
     // length below table_dl, per query and scored term — bm25_scorer.cpp:80-84 operation by operation (this file is
     // compiled with -ffp-contract=off), so a table entry is bit-identical to the direct evaluation on the device
@@ -1080,6 +1092,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   g.dev_wave = d;
   g.dev_wave.items = g.d_items_wave.as<DevItem>();
   g.dev_wave.n_items = g.n_items_wave;
+  g.dev_wave_lists = d;
+  g.dev_wave_lists.items = g.d_items_wave_lists.as<DevItem>();
+  g.dev_wave_lists.n_items = static_cast<uint32_t>(items_wave_lists.size());
   if (page_mode) {
     std::vector<DevItem> pw, pb;
     for (uint32_t i = 0; i < n; ++i) (on_wave[i] ? pw : pb).push_back(DevItem{i, 0, 0, 0});
@@ -1209,20 +1224,23 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    if (g.n_items != 0 && g.n_items_wave != 0) {
-      // fork: the general kernel's (small) share runs on the side stream while the wave kernel fills the chip
+    if ((g.n_items != 0 || g.dev_wave_lists.n_items != 0) && g.n_items_wave != 0) {
+      // fork: the (small) shares of the general kernel and of the list-operand plan run on the side stream while the
+      // all-bitmap wave launch fills the chip
       if (!b->fork_ev) {
         MGX_HIP(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         MGX_HIP(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
       }
       MGX_HIP(hipEventRecord(b->fork_ev, s));
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, idx->side_stream));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
       MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
       MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
     } else {
       MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, s));
       MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {
