@@ -219,8 +219,9 @@ def main():
                          "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k_ms > 0 else None,
                          "peak_measured_read": measured_peak,
                          "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
-                         "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 + per-wave top-k; queries with a sparse "
-                                   "scored gram run on mgx::tile_eval_kernel<0> on a side stream inside the same timed region)",
+                         "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
+                                   "queries with a sorted-list operand run on a second launch of the same kernel on a "
+                                   "side stream inside the same timed region)",
                          "kernel_ms": k_ms, "launches_timed": k_n,
                          "algorithmic_bytes_per_launch": alg_total,
                          "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1],
