@@ -339,3 +339,18 @@ def test_docid_pages_dense_and_sparse(score_kernel):
     qs.append(Query(["th"], ["he"], limit=7, descending=True))
     qs.append(Query(expr=("and", ("or", "th", "qu"), ("not", "he")), limit=15))
     p.check(qs)
+
+
+def test_saturated_tf_and_long_docs(score_kernel):
+    # dense grams whose tf exceeds the 4-bit nibble (>= 15 -> exact posting lookup), docs longer than the 8-bit doc
+    # length (>= 255 -> u32 doc_len) and than the BM25 table (direct formula), tf above the table's rows
+    docs = []
+    for i in range(1, 40_001):
+        reps = i % 27 + 1                       # tf("ab") = 1..27
+        pad = "x" * ((i % 9) * 45)              # doc lengths up to ~420
+        docs.append((i, "ab" * reps + " cd " + ("ef " * (i % 4)) + pad))
+    p = Pair(docs=docs)
+    p.check([Query(["ab", "cd"], sort_score=True, limit=25),
+             Query(["ab"], sort_score=True, limit=100, descending=False),
+             Query(["cd", "ef", "ab"], sort_score=True, limit=10, offset=5),
+             Query(["xx", "ab"], sort_score=True, limit=10)])
