@@ -238,7 +238,9 @@ int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queri
 int mgx_batch_execute(mgx_batch* batch, void* hip_stream);
 /* Waits for the last execute and copies the (small) results to host memory owned by the batch. */
 int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);
-/* Multi-GPU exchange (one rank per doc-range shard; only for batches whose queries are all MGX_SORT_SCORE).
+/* Multi-GPU exchange (one rank per doc-range shard). The batch must be all MGX_SORT_SCORE, or all docid-ordered
+ * pages (MGX_SORT_DOCID with 0 < limit <= 16384): a page is a best-first list under the key "doc id" (or its
+ * complement for ascending order), so the same two calls serve both.
  * Copies this shard's per-query top-(offset+limit) of the last execute into two CALLER-owned DEVICE blobs on
  * `hip_stream`, laid out so that ONE all-gather per blob moves everything:
  *   blob64[n_queries*stride + n_queries] : keys (order-preserving u64 of the fp64 score, best first, `stride` per

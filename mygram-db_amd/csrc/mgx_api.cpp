@@ -707,6 +707,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   } else if (in.sort == MGX_SORT_DOCID) {
     // a bounded page in docid order needs no materialised result bitmap: count pass + page pass
     out->mode = (in.limit != 0 && in.limit <= kMaxDocPage) ? kModeDocPage : kModeBitmap;
+    out->offset = 0;  // (pagination offset belongs to SORT _score, search_handler.cpp:469-470)
   } else {
     return Fail(MGX_ERR_INVALID_ARGUMENT, "unknown sort");
   }
@@ -774,7 +775,7 @@ struct mgx_batch {
   // docid-page group (kModeDocPage): per-tile counts / rank offsets, and one packed result block
   // [counters n*8 u64 | totals n u64 | page docs n*stride u32] mirrored in pinned host memory
   Group page;
-  DevBuf d_ptile_cnt, d_ptile_start, d_page_out;
+  DevBuf d_ptile_cnt, d_ptile_start, d_page_out, d_page_scratch;
   void* h_page_out = nullptr;
   size_t po_totals = 0, po_docs = 0, po_bytes = 0;
   uint32_t doc_page_stride = 0;
@@ -1359,11 +1360,13 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     }
   }
   const uint32_t* dp_docs = nullptr;
+  const unsigned long long* dp_totals = nullptr;
   if (!b->page.qids.empty()) {
     const char* h = static_cast<const char*>(b->h_page_out);
     const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(h);
     for (size_t i = 0; i < b->page.qids.size() * 8; ++i) b->page.h_counters[i] = hc[i];
     dp_docs = reinterpret_cast<const uint32_t*>(h + b->po_docs);
+    dp_totals = reinterpret_cast<const unsigned long long*>(h + b->po_totals);
   }
   // ---- assemble in batch order ----
   std::vector<uint32_t> pos_in_group(b->n_queries, 0);
@@ -1384,6 +1387,7 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     r.after_filters = c[3];
     r.total = c[4];
     if (sc && b->merged_shards) r.total = override_tot[gi];
+    if (pg && b->merged_shards) r.total = dp_totals[gi];
     r.n_docs = sc   ? page_n[gi]
                : pg ? static_cast<uint32_t>(std::min<uint64_t>(r.total, b->specs[qi].limit))
                     : static_cast<uint32_t>(take[gi]);
@@ -1483,13 +1487,23 @@ int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n)
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride,
                           void* hip_stream) {
   if (!batch || !stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null argument");
-  if (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty())
-    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: every query must be MGX_SORT_SCORE");
-  *stride = batch->top_stride;
+  const bool pages = batch->score.qids.empty() && batch->bitmap.qids.empty() && !batch->page.qids.empty();
+  if (!pages && (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty()))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
+                     "mgx_batch_export_topk: the batch must be all MGX_SORT_SCORE or all docid-ordered pages "
+                     "(0 < limit <= 16384)");
+  *stride = pages ? batch->doc_page_stride : batch->top_stride;
   if (!blob64 && !blob32) return MGX_OK;  // size query
   if (!blob64 || !blob32) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null blob");
   if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: not executed");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  if (pages) {
+    const mgx_batch::Group& g = batch->page;
+    MGX_HIP(hipSetDevice(batch->idx->device));
+    MGX_LAUNCH(mgx::LaunchExportPages(g.dev.queries, static_cast<uint32_t>(g.qids.size()), batch->doc_page_stride,
+                                      g.dev.page_docs, g.dev.totals, blob64, blob32, s));
+    return MGX_OK;
+  }
   const size_t n = batch->score.qids.size();
   const size_t ks = n * batch->top_stride;
   MGX_HIP(hipSetDevice(batch->idx->device));
@@ -1506,9 +1520,32 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                            void* hip_stream) {
   if (!batch || !blob64 || !blob32 || n_shards == 0)
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: null argument");
-  if (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty())
-    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: every query must be MGX_SORT_SCORE");
+  const bool pages = batch->score.qids.empty() && batch->bitmap.qids.empty() && !batch->page.qids.empty();
+  if (!pages && (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty()))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
+                     "mgx_batch_merge_shards: the batch must be all MGX_SORT_SCORE or all docid-ordered pages");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  if (pages) {
+    // shards hold disjoint doc ranges, but the merge needs no such knowledge: pages are best-first lists by doc id
+    mgx_batch::Group& g = batch->page;
+    const uint32_t n = static_cast<uint32_t>(g.qids.size());
+    const uint32_t stride = batch->doc_page_stride;
+    const uint64_t pitch = static_cast<uint64_t>(n) * stride + n;
+    MGX_HIP(hipSetDevice(batch->idx->device));
+    if (batch->d_page_scratch.bytes == 0)
+      MGX_HIP(batch->d_page_scratch.Alloc(static_cast<size_t>(n) * stride * 8 + static_cast<size_t>(n) * 4));
+    double* scratch_scores = batch->d_page_scratch.as<double>();
+    uint32_t* scratch_n = reinterpret_cast<uint32_t*>(scratch_scores + static_cast<size_t>(n) * stride);
+    MGX_LAUNCH(mgx::LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, n_shards, blob64, blob32,
+                                    blob32 + static_cast<uint64_t>(n) * stride, /*kq=*/stride, /*kj=*/pitch, /*cq=*/1,
+                                    /*cj=*/pitch, nullptr, nullptr, nullptr, 0, g.dev.page_docs, scratch_scores,
+                                    scratch_n, stride, nullptr, s));
+    MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * stride, n_shards, n, pitch,
+                                    const_cast<uint64_t*>(g.dev.totals), s));
+    batch->merged_shards = true;
+    batch->last_stream = s;
+    return MGX_OK;
+  }
   const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
   const uint64_t pitch = static_cast<uint64_t>(n) * batch->top_stride + n;  // elements per rank blob
   MGX_HIP(hipSetDevice(batch->idx->device));

@@ -1589,6 +1589,30 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
 #undef MGX_C
 }
 
+// A shard's docid-ordered pages in the exchange layout of mgx_batch_export_topk: a page is already a best-first list
+// under the key "doc id" (descending pages) or "complement of the doc id" (ascending pages).
+__global__ void export_pages_kernel(const DevQuery* __restrict__ queries, uint32_t n, uint32_t stride,
+                                    const uint32_t* __restrict__ page_docs, const uint64_t* __restrict__ totals,
+                                    uint64_t* __restrict__ blob64, uint32_t* __restrict__ blob32) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= static_cast<uint64_t>(n) * stride) return;
+  const uint32_t qi = static_cast<uint32_t>(e / stride), k = static_cast<uint32_t>(e % stride);
+  const DevQuery q = queries[qi];
+  const uint64_t total = totals[qi];
+  const uint32_t cnt = static_cast<uint32_t>(total < q.limit ? total : q.limit);
+  uint32_t dprime = 0;
+  if (k < cnt) {
+    const uint32_t d = page_docs[e];
+    dprime = q.descending ? d : ~d;
+  }
+  blob64[e] = dprime;
+  blob32[e] = dprime;
+  if (k == 0) {
+    blob64[static_cast<uint64_t>(n) * stride + qi] = total;
+    blob32[static_cast<uint64_t>(n) * stride + qi] = cnt;
+  }
+}
+
 // out[q] = sum over shards of totals[shard*pitch + q]
 __global__ void sum_totals_kernel(const uint64_t* __restrict__ totals, uint32_t n_shards, uint32_t n_queries,
                                   uint64_t pitch, uint64_t* __restrict__ out) {
@@ -1927,6 +1951,16 @@ int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, kq, kj,
                      cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
                      query_ids, list_begin);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchExportPages(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* page_docs,
+                      const uint64_t* totals, uint64_t* blob64, uint32_t* blob32, hipStream_t s) {
+  const uint64_t total = static_cast<uint64_t>(n) * stride;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(export_pages_kernel, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, s, queries, n,
+                     stride, page_docs, totals, blob64, blob32);
   MGX_KCHECK();
   return 0;
 }

@@ -24,6 +24,8 @@ int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t
                     uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
                     uint32_t page_stride, const uint32_t* list_begin, hipStream_t s);
+int LaunchExportPages(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* page_docs,
+                      const uint64_t* totals, uint64_t* blob64, uint32_t* blob32, hipStream_t s);
 int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t pitch, uint64_t* out,
                     hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,

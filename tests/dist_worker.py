@@ -140,6 +140,23 @@ def main():
             assert g.total == total, (q.terms, g.total, total)
             assert g.docs.tolist() == docs.tolist(), q.terms
             assert np.array_equal(g.scores, scores), q.terms
+        # docid-ordered pages across the shards (the reference's default order): totals add up, pages merge by doc id
+        pq = []
+        for i in range(10):
+            pick = [common[i % len(common)], common[(i + 1) % len(common)]]
+            pq.append(mg.engine.Query(pick, limit=[1, 10, 100][i % 3], descending=bool(i % 2)))
+        pq.append(mg.engine.Query(["k9"], limit=10, descending=True))              # only the first shard holds it
+        pq.append(mg.engine.Query(["7j", common[0]], limit=10, descending=False))  # only the second
+        pq.append(mg.engine.Query(["the"], ["an"], limit=50, descending=True))
+        pbatch = table.prepare(pq)
+        table.run(pbatch)
+        for q, g in zip(pq, pbatch.fetch()):
+            r = O.execute(oidx, ostore, q.terms, q.not_terms, [], compute_df=False, ngram_size=2, kanji_ngram_size=0,
+                          cross_boundary=True)
+            res = r["results"]
+            page = (res[::-1] if q.descending else res)[: q.limit]
+            assert g.total == len(res), (q.terms, g.total, len(res))
+            assert g.docs.tolist() == page.tolist(), (q.terms, g.docs.tolist()[:5], page.tolist()[:5])
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)
