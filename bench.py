@@ -2,7 +2,7 @@
 """bench.py — queries/sec + p50 latency of batched 3-term AND + BM25 top-10 on a 10M-doc bigram index (MI355X).
 
 One step = one batch of 1024 queries: tile kernel (set algebra + fused BM25 + per-workgroup top-k), merge kernel,
-(N > 1: two RCCL all-gathers of per-shard top-k + merge kernel), results copied back to the host. The query batch and
+(N > 1: one RCCL all-gather of per-shard top-k + merge kernel), results copied back to the host. The query batch and
 the index are resident in HBM before the timed region starts; four different batches are cycled.
 
     python bench.py --gpus 1 --steps 20 --warmup 3

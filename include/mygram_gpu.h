@@ -248,10 +248,13 @@ int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);
  *   blob32[n_queries*stride + n_queries] : doc ids parallel to the keys, then the number of valid entries per query.
  * Call with both blobs NULL to only learn *stride. */
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride, void* hip_stream);
-/* Merges the blobs of `n_shards` ranks, gathered rank after rank (the layout an RCCL all-gather produces), into the
- * final page and total of every query, on `hip_stream`; read the result with mgx_batch_fetch. */
-int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, const uint32_t* blob32,
-                           void* hip_stream);
+/* Merges the blobs of `n_shards` ranks into the final page and total of every query, on `hip_stream`; read the
+ * result with mgx_batch_fetch. Rank r's 64-bit blob starts at blob64 + r*pitch64 (u64 elements), its 32-bit blob at
+ * blob32 + r*pitch32 (u32 elements); pitch 0 = the blob's own size (blobs gathered separately, rank after rank).
+ * With explicit pitches a rank can export both blobs into ONE buffer (blob32 right behind blob64) and a single
+ * all-gather moves everything: pitch64 = bytes_per_rank/8, pitch32 = bytes_per_rank/4. */
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
+                           const uint32_t* blob32, uint64_t pitch32, void* hip_stream);
 /* Text-level terms across shards: df must be table-wide before idf is taken. mgx_batch_count_df enqueues only the df
  * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per term, in
  * batch order: query-major, then term order), which the caller sums over ranks in place (one RCCL all-reduce); the next

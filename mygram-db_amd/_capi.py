@@ -121,7 +121,7 @@ def load():
     L.mgx_batch_count_df.argtypes = [vp, vp]
     L.mgx_batch_df_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
-    L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, vp, vp]
+    L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, u64, vp, u64, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]
     L.mgx_batch_destroy.argtypes = [vp]

@@ -1250,7 +1250,8 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     }
     const uint32_t n = static_cast<uint32_t>(g.qids.size());
     MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, 0, g.dev.cand_keys, g.dev.cand_docs,
-                               g.dev.cand_n, /*kq=*/0, /*kj=*/g.dev.cand_stride, /*cq=*/0, /*cj=*/1,
+                               g.dev.cand_n, /*kq=*/0, /*kj=*/g.dev.cand_stride, /*dj=*/g.dev.cand_stride, /*cq=*/0,
+                               /*cj=*/1,
                                b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
                                b->d_top_n.as<uint32_t>(), b->top_stride, b->sc_docs(), b->sc_scores(), b->sc_n(),
                                b->page_stride,
@@ -1516,8 +1517,8 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
   return MGX_OK;
 }
 
-int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, const uint32_t* blob32,
-                           void* hip_stream) {
+int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
+                           const uint32_t* blob32, uint64_t pitch32, void* hip_stream) {
   if (!batch || !blob64 || !blob32 || n_shards == 0)
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_shards: null argument");
   const bool pages = batch->score.qids.empty() && batch->bitmap.qids.empty() && !batch->page.qids.empty();
@@ -1530,31 +1531,33 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
     mgx_batch::Group& g = batch->page;
     const uint32_t n = static_cast<uint32_t>(g.qids.size());
     const uint32_t stride = batch->doc_page_stride;
-    const uint64_t pitch = static_cast<uint64_t>(n) * stride + n;
+    if (pitch64 == 0) pitch64 = static_cast<uint64_t>(n) * stride + n;  // blobs laid rank after rank
+    if (pitch32 == 0) pitch32 = static_cast<uint64_t>(n) * stride + n;
     MGX_HIP(hipSetDevice(batch->idx->device));
     if (batch->d_page_scratch.bytes == 0)
       MGX_HIP(batch->d_page_scratch.Alloc(static_cast<size_t>(n) * stride * 8 + static_cast<size_t>(n) * 4));
     double* scratch_scores = batch->d_page_scratch.as<double>();
     uint32_t* scratch_n = reinterpret_cast<uint32_t*>(scratch_scores + static_cast<size_t>(n) * stride);
     MGX_LAUNCH(mgx::LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, n_shards, blob64, blob32,
-                                    blob32 + static_cast<uint64_t>(n) * stride, /*kq=*/stride, /*kj=*/pitch, /*cq=*/1,
-                                    /*cj=*/pitch, nullptr, nullptr, nullptr, 0, g.dev.page_docs, scratch_scores,
-                                    scratch_n, stride, nullptr, s));
-    MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * stride, n_shards, n, pitch,
+                                    blob32 + static_cast<uint64_t>(n) * stride, /*kq=*/stride, /*kj=*/pitch64,
+                                    /*dj=*/pitch32, /*cq=*/1, /*cj=*/pitch32, nullptr, nullptr, nullptr, 0,
+                                    g.dev.page_docs, scratch_scores, scratch_n, stride, nullptr, s));
+    MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * stride, n_shards, n, pitch64,
                                     const_cast<uint64_t*>(g.dev.totals), s));
     batch->merged_shards = true;
     batch->last_stream = s;
     return MGX_OK;
   }
   const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
-  const uint64_t pitch = static_cast<uint64_t>(n) * batch->top_stride + n;  // elements per rank blob
+  if (pitch64 == 0) pitch64 = static_cast<uint64_t>(n) * batch->top_stride + n;  // blobs laid rank after rank
+  if (pitch32 == 0) pitch32 = static_cast<uint64_t>(n) * batch->top_stride + n;
   MGX_HIP(hipSetDevice(batch->idx->device));
   MGX_LAUNCH(mgx::LaunchMergeTopK(batch->score.dev.queries, batch->score.d_ident.as<uint32_t>(), n, n_shards, blob64,
                                   blob32, blob32 + static_cast<uint64_t>(n) * batch->top_stride,
-                                  /*kq=*/batch->top_stride, /*kj=*/pitch, /*cq=*/1, /*cj=*/pitch, nullptr, nullptr,
-                                  nullptr, 0, batch->sc_docs(), batch->sc_scores(), batch->sc_n(), batch->page_stride,
-                                  nullptr, s));
-  MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch,
+                                  /*kq=*/batch->top_stride, /*kj=*/pitch64, /*dj=*/pitch32, /*cq=*/1, /*cj=*/pitch32,
+                                  nullptr, nullptr, nullptr, 0, batch->sc_docs(), batch->sc_scores(), batch->sc_n(),
+                                  batch->page_stride, nullptr, s));
+  MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch64,
                                   batch->sc_override(), s));
   batch->merged_shards = true;
   batch->last_stream = s;

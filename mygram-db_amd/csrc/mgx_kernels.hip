@@ -1434,13 +1434,14 @@ __global__ __launch_bounds__(kBlock) void wave_page_kernel(DevIndex ix, DevBatch
 // lists: n_lists sorted (best-first) lists per query; list j of query slot qq starts at keys[qq*kq + j*kj] (same for
 // docs) and holds cnt[qq*cq + j*cj] valid entries. Per-workgroup lists of one shard: kq = n_lists*stride, kj = stride,
 // cq = n_lists, cj = 1. Per-shard lists gathered rank by rank: kq = stride, kj = elements per rank blob, cq = 1,
-// cj = elements per rank blob. Writes the merged best `needed` (best first) to top_keys/top_docs[qq*top_stride..]
+// cj = elements per rank blob (dj: the same pitch for the doc-id array, which may differ from the keys' when both live in
+// one packed buffer per rank). Writes the merged best `needed` (best first) to top_keys/top_docs[qq*top_stride..]
 // and the page [offset, offset+limit) to page_docs/page_scores[qq*page_stride ..].
 __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __restrict__ queries, uint32_t n_lists,
                                                             const uint64_t* __restrict__ keys,
                                                             const uint32_t* __restrict__ docs,
                                                             const uint32_t* __restrict__ cnt, uint64_t kq,
-                                                            uint64_t kj, uint64_t cq, uint64_t cj,
+                                                            uint64_t kj, uint64_t dj, uint64_t cq, uint64_t cj,
                                                             uint64_t* __restrict__ top_keys,
                                                             uint32_t* __restrict__ top_docs,
                                                             uint32_t* __restrict__ top_n, uint32_t top_stride,
@@ -1456,6 +1457,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   const uint64_t l0 = list_begin ? list_begin[slot] : 0;
   if (list_begin) n_lists = list_begin[slot + 1] - list_begin[slot];
 #define MGX_K(j) (list_begin ? (l0 + (j)) * kj : static_cast<uint64_t>(slot) * kq + static_cast<uint64_t>(j) * kj)
+#define MGX_D(j) (list_begin ? (l0 + (j)) * kj : static_cast<uint64_t>(slot) * kq + static_cast<uint64_t>(j) * dj)
 #define MGX_C(j) (list_begin ? (l0 + (j)) * cj : static_cast<uint64_t>(slot) * cq + static_cast<uint64_t>(j) * cj)
   __shared__ uint32_t s_total;
   if (threadIdx.x == 0) s_total = 0;
@@ -1483,7 +1485,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
       const uint32_t j = e / q.needed, i = e % q.needed;
       const bool live = i < cnt[MGX_C(j)];
       s_keys[e] = live ? keys[MGX_K(j) + i] : 0;
-      s_docs[e] = live ? docs[MGX_K(j) + i] : 0;
+      s_docs[e] = live ? docs[MGX_D(j) + i] : 0;
     }
     __syncthreads();
   }
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
     const uint32_t at = atomicAdd(&s_nsurv, 1u);
     if (at < kSurv) {
       s_sk[at] = k;
-      s_sd[at] = staged ? s_docs[e] : docs[MGX_K(j) + i];
+      s_sd[at] = staged ? s_docs[e] : docs[MGX_D(j) + i];
     }
   }
   __syncthreads();
@@ -1546,7 +1548,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
     if (i >= (staged ? s_cnt[j] : cnt[MGX_C(j)])) continue;
     const uint64_t k = staged ? s_keys[e] : keys[MGX_K(j) + i];
     if (k < thr) continue;
-    const uint32_t d = staged ? s_docs[e] : docs[MGX_K(j) + i];
+    const uint32_t d = staged ? s_docs[e] : docs[MGX_D(j) + i];
     uint32_t rank = i;
     for (uint32_t j2 = 0; j2 < n_lists && rank < q.needed; ++j2) {
       if (j2 == j) continue;
@@ -1561,7 +1563,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
         }
       } else {
         const uint64_t* kk = keys + MGX_K(j2);
-        const uint32_t* dd = docs + MGX_K(j2);
+        const uint32_t* dd = docs + MGX_D(j2);
         uint32_t hi = min(cnt[MGX_C(j2)], q.needed);
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
@@ -1587,6 +1589,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   }
 #undef MGX_K
 #undef MGX_C
+#undef MGX_D
 }
 
 // A shard's docid-ordered pages in the exchange layout of mgx_batch_export_topk: a page is already a best-first list
@@ -1944,12 +1947,12 @@ int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t
 
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
-                    uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
+                    uint64_t dj, uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
                     uint32_t page_stride, const uint32_t* list_begin, hipStream_t s) {
   if (n_slots == 0) return 0;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, kq, kj,
-                     cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
+                     dj, cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
                      query_ids, list_begin);
   MGX_KCHECK();
   return 0;

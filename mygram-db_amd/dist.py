@@ -3,8 +3,8 @@
 Every rank owns a contiguous doc-id range as a complete small index: postings never cross shards, so
 set algebra needs no communication. What must be global is what BM25 reads: N, avgdl and each gram's document
 frequency (so idf — and therefore every score — is identical on all ranks); they are summed once at load time. Per
-batch the ranks exchange only their per-query top-(offset+limit): two all-gathers (one 64-bit blob, one 32-bit blob,
-see mgx_batch_export_topk) followed by a device-side merge with the ResultSorter::SortByScore comparator. RCCL has no
+batch the ranks exchange only their per-query top-(offset+limit): ONE all-gather of a packed blob (64-bit keys and
+totals, then 32-bit doc ids and counts, see mgx_batch_export_topk) followed by a device-side merge with the ResultSorter::SortByScore comparator. RCCL has no
 custom reduction operator, so the north star's "all-reduce of top-k" is realised as all-gather + local merge.
 """
 import numpy as np
@@ -87,15 +87,17 @@ class ShardedTable:
         return self.index.prepare(queries)
 
     def _buffers(self, batch):
+        """Per batch: this rank's packed blob and the gathered blobs of every rank. One rank's blob is
+        [keys | totals] as u64 followed by [docs | counts] as u32 (mgx_batch_export_topk), padded to a multiple of 8
+        bytes, so ONE all-gather moves both."""
         key = id(batch)
         if key not in self._blobs:
             stride = batch.topk_stride()
-            n = batch.n * stride + batch.n
+            n = batch.n * stride + batch.n          # elements of each blob
+            nbytes = (12 * n + 7) // 8 * 8          # 8n bytes of u64, 4n bytes of u32, padded
             dev = torch.device("cuda", self.index.device_index.device)
-            self._blobs[key] = (torch.empty(n, dtype=torch.int64, device=dev),
-                                torch.empty(n, dtype=torch.int32, device=dev),
-                                torch.empty(n * self.world, dtype=torch.int64, device=dev),
-                                torch.empty(n * self.world, dtype=torch.int32, device=dev))
+            self._blobs[key] = (n, nbytes, torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                                torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
         return self._blobs[key]
 
     def _df_tensor(self, batch, ptr, n):
@@ -131,16 +133,13 @@ class ShardedTable:
         batch.execute(stream)
         if not exchange:
             return
-        b64, b32, g64, g32 = self._buffers(batch)
-        batch.export_topk(b64.data_ptr(), b32.data_ptr(), stream)
+        n, nbytes, mine, gathered = self._buffers(batch)
+        batch.export_topk(mine.data_ptr(), mine.data_ptr() + 8 * n, stream)
         if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(g64, b64)
-            dist.all_gather_into_tensor(g32, b32)
+            dist.all_gather_into_tensor(gathered, mine)
         else:  # gloo: stage through host memory (CPU rehearsal of the exchange; RCCL is the production path)
-            h64 = [torch.empty(b64.numel(), dtype=torch.int64) for _ in range(self.world)]
-            h32 = [torch.empty(b32.numel(), dtype=torch.int32) for _ in range(self.world)]
-            dist.all_gather(h64, b64.cpu())
-            dist.all_gather(h32, b32.cpu())
-            g64.copy_(torch.cat(h64))
-            g32.copy_(torch.cat(h32))
-        batch.merge_shards(self.world, g64.data_ptr(), g32.data_ptr(), stream)
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(parts, mine.cpu())
+            gathered.copy_(torch.cat(parts))
+        batch.merge_shards(self.world, gathered.data_ptr(), gathered.data_ptr() + 8 * n, stream,
+                           pitch64=nbytes // 8, pitch32=nbytes // 4)

@@ -341,8 +341,8 @@ class PreparedBatch:
         check(load().mgx_batch_export_topk(self._h, blob64_ptr, blob32_ptr, C.byref(s), stream))
         return int(s.value)
 
-    def merge_shards(self, n_shards, blob64_ptr, blob32_ptr, stream=None):
-        check(load().mgx_batch_merge_shards(self._h, n_shards, blob64_ptr, blob32_ptr, stream))
+    def merge_shards(self, n_shards, blob64_ptr, blob32_ptr, stream=None, pitch64=0, pitch32=0):
+        check(load().mgx_batch_merge_shards(self._h, n_shards, blob64_ptr, pitch64, blob32_ptr, pitch32, stream))
 
 
 class Index:
