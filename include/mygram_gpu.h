@@ -248,6 +248,11 @@ int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);
  *   blob32[n_queries*stride + n_queries] : doc ids parallel to the keys, then the number of valid entries per query.
  * Call with both blobs NULL to only learn *stride. */
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride, void* hip_stream);
+/* Zero-copy form of the export for MGX_SORT_SCORE batches: the library keeps the shard's result in the exchange layout
+ * already; *device_blob is that buffer (blob64 at offset 0, blob32 at *offset32 bytes, *bytes in all, a multiple of 8),
+ * valid once the execute it belongs to has completed on its stream. NULL for other batches (use
+ * mgx_batch_export_topk). */
+int mgx_batch_export_buffer(mgx_batch* batch, void** device_blob, uint64_t* bytes, uint64_t* offset32);
 /* Merges the blobs of `n_shards` ranks into the final page and total of every query, on `hip_stream`; read the
  * result with mgx_batch_fetch. Rank r's 64-bit blob starts at blob64 + r*pitch64 (u64 elements), its 32-bit blob at
  * blob32 + r*pitch32 (u32 elements); pitch 0 = the blob's own size (blobs gathered separately, rank after rank).

@@ -20,7 +20,7 @@ EXPORTS = [
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
-    "mgx_batch_merge_shards", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
+    "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
     "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth",
 ]
@@ -121,6 +121,7 @@ def load():
     L.mgx_batch_count_df.argtypes = [vp, vp]
     L.mgx_batch_df_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
+    L.mgx_batch_export_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, u64, vp, u64, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]

@@ -757,7 +757,15 @@ struct mgx_batch {
   std::vector<double> h_text_idf;
   bool df_ready = false;  // mgx_batch_count_df ran (and the caller summed the counts) for the next execute
   // score group outputs
-  DevBuf d_cand_keys, d_cand_docs, d_cand_n, d_top_keys, d_top_docs, d_top_n;
+  DevBuf d_cand_keys, d_cand_docs, d_cand_n;
+  // This shard's merged top-(offset+limit) per query in the exchange layout of mgx_batch_export_topk, written in place
+  // by the merge kernel: [keys n*S u64 | totals n u64 | docs n*S u32 | counts n u32]  (S = top_stride)
+  DevBuf d_export;
+  size_t ex_off32 = 0, ex_bytes = 0;
+  uint64_t* ex_keys() const { return d_export.as<uint64_t>(); }
+  uint64_t* ex_totals(size_t n) const { return d_export.as<uint64_t>() + n * top_stride; }
+  uint32_t* ex_docs() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(d_export.p) + ex_off32); }
+  uint32_t* ex_counts(size_t n) const { return ex_docs() + n * top_stride; }
   // Everything mgx_batch_fetch needs from a score group sits in ONE device block, copied with one async memcpy into
   // pinned host memory: [counters n*9 u64 | total_override n u64 | page_scores n*L f64 | page_docs n*L u32 | page_n n u32]
   DevBuf d_score_out;
@@ -1041,9 +1049,12 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     MGX_HIP(b->d_cand_keys.Alloc(n_lists_total * max_needed * 8));
     MGX_HIP(b->d_cand_docs.Alloc(n_lists_total * max_needed * 4));
     MGX_HIP(b->d_cand_n.Alloc(n_lists_total * 4));
-    MGX_HIP(b->d_top_keys.Alloc(static_cast<size_t>(n) * max_needed * 8));
-    MGX_HIP(b->d_top_docs.Alloc(static_cast<size_t>(n) * max_needed * 4));
-    MGX_HIP(b->d_top_n.Alloc(static_cast<size_t>(n) * 4));
+    {
+      const size_t elems = static_cast<size_t>(n) * max_needed + n;
+      b->ex_off32 = elems * 8;
+      b->ex_bytes = (elems * 12 + 7) / 8 * 8;
+      MGX_HIP(b->d_export.Alloc(b->ex_bytes));
+    }
     d.cand_keys = b->d_cand_keys.as<uint64_t>();
     d.cand_docs = b->d_cand_docs.as<uint32_t>();
     d.cand_n = b->d_cand_n.as<uint32_t>();
@@ -1252,10 +1263,9 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, 0, g.dev.cand_keys, g.dev.cand_docs,
                                g.dev.cand_n, /*kq=*/0, /*kj=*/g.dev.cand_stride, /*dj=*/g.dev.cand_stride, /*cq=*/0,
                                /*cj=*/1,
-                               b->d_top_keys.as<uint64_t>(), b->d_top_docs.as<uint32_t>(),
-                               b->d_top_n.as<uint32_t>(), b->top_stride, b->sc_docs(), b->sc_scores(), b->sc_n(),
-                               b->page_stride,
-                               g.d_list_begin.as<uint32_t>(), s));
+                               b->ex_keys(), b->ex_docs(), b->ex_counts(n), b->top_stride, b->sc_docs(),
+                               b->sc_scores(), b->sc_n(), b->page_stride, g.d_list_begin.as<uint32_t>(),
+                               b->sc_counters(), b->ex_totals(n), s));
   }
   if (!b->bitmap.qids.empty()) {
     mgx_batch::Group& g = b->bitmap;
@@ -1508,12 +1518,21 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
   const size_t n = batch->score.qids.size();
   const size_t ks = n * batch->top_stride;
   MGX_HIP(hipSetDevice(batch->idx->device));
-  MGX_HIP(hipMemcpyAsync(blob64, batch->d_top_keys.p, ks * 8, hipMemcpyDeviceToDevice, s));
-  // totals: counter slot 4 of every query
-  MGX_HIP(hipMemcpy2DAsync(blob64 + ks, 8, static_cast<char*>(batch->d_score_out.p) + 4 * 8, 64, 8, n,
-                           hipMemcpyDeviceToDevice, s));
-  MGX_HIP(hipMemcpyAsync(blob32, batch->d_top_docs.p, ks * 4, hipMemcpyDeviceToDevice, s));
-  MGX_HIP(hipMemcpyAsync(blob32 + ks, batch->d_top_n.p, n * 4, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(blob64, batch->ex_keys(), (ks + n) * 8, hipMemcpyDeviceToDevice, s));
+  MGX_HIP(hipMemcpyAsync(blob32, batch->ex_docs(), (ks + n) * 4, hipMemcpyDeviceToDevice, s));
+  return MGX_OK;
+}
+
+int mgx_batch_export_buffer(mgx_batch* batch, void** device_blob, uint64_t* bytes, uint64_t* offset32) {
+  if (device_blob) *device_blob = nullptr;
+  if (bytes) *bytes = 0;
+  if (offset32) *offset32 = 0;
+  if (!batch || !device_blob || !bytes || !offset32)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_buffer: null argument");
+  if (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty()) return MGX_OK;  // none
+  *device_blob = batch->d_export.p;
+  *bytes = batch->ex_bytes;
+  *offset32 = batch->ex_off32;
   return MGX_OK;
 }
 
@@ -1541,7 +1560,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
     MGX_LAUNCH(mgx::LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, n_shards, blob64, blob32,
                                     blob32 + static_cast<uint64_t>(n) * stride, /*kq=*/stride, /*kj=*/pitch64,
                                     /*dj=*/pitch32, /*cq=*/1, /*cj=*/pitch32, nullptr, nullptr, nullptr, 0,
-                                    g.dev.page_docs, scratch_scores, scratch_n, stride, nullptr, s));
+                                    g.dev.page_docs, scratch_scores, scratch_n, stride, nullptr, nullptr, nullptr, s));
     MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * stride, n_shards, n, pitch64,
                                     const_cast<uint64_t*>(g.dev.totals), s));
     batch->merged_shards = true;
@@ -1556,7 +1575,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                                   blob32, blob32 + static_cast<uint64_t>(n) * batch->top_stride,
                                   /*kq=*/batch->top_stride, /*kj=*/pitch64, /*dj=*/pitch32, /*cq=*/1, /*cj=*/pitch32,
                                   nullptr, nullptr, nullptr, 0, batch->sc_docs(), batch->sc_scores(), batch->sc_n(),
-                                  batch->page_stride, nullptr, s));
+                                  batch->page_stride, nullptr, nullptr, nullptr, s));
   MGX_LAUNCH(mgx::LaunchSumTotals(blob64 + static_cast<uint64_t>(n) * batch->top_stride, n_shards, n, pitch64,
                                   batch->sc_override(), s));
   batch->merged_shards = true;

@@ -1449,8 +1449,12 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
                                                             double* __restrict__ page_scores,
                                                             uint32_t* __restrict__ page_n, uint32_t page_stride,
                                                             const uint32_t* __restrict__ query_ids,
-                                                            const uint32_t* __restrict__ list_begin) {
+                                                            const uint32_t* __restrict__ list_begin,
+                                                            const unsigned long long* __restrict__ counters,
+                                                            uint64_t* __restrict__ totals_out) {
   const uint32_t slot = blockIdx.x;
+  // (per-shard merge: this shard's match count goes next to its keys, where the exchange expects it)
+  if (totals_out && threadIdx.x == 0) totals_out[slot] = counters[static_cast<uint64_t>(slot) * 8 + 4];
   const DevQuery q = queries[query_ids[slot]];
   // with list_begin (CSR over query slots) the lists of slot qq are lists list_begin[qq] .. list_begin[qq+1]-1 of
   // one launch-wide array: list L at keys[L*kj], cnt[L*cj]
@@ -1949,11 +1953,12 @@ int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
                     uint64_t dj, uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
-                    uint32_t page_stride, const uint32_t* list_begin, hipStream_t s) {
+                    uint32_t page_stride, const uint32_t* list_begin, const unsigned long long* counters,
+                    uint64_t* totals_out, hipStream_t s) {
   if (n_slots == 0) return 0;
   hipLaunchKernelGGL(merge_topk_kernel, dim3(n_slots), dim3(kBlock), 0, s, queries, n_lists, keys, docs, cnt, kq, kj,
                      dj, cq, cj, top_keys, top_docs, top_n, top_stride, page_docs, page_scores, page_n, page_stride,
-                     query_ids, list_begin);
+                     query_ids, list_begin, counters, totals_out);
   MGX_KCHECK();
   return 0;
 }

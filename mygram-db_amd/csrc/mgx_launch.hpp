@@ -23,7 +23,8 @@ int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t
                     const uint64_t* keys, const uint32_t* docs, const uint32_t* cnt, uint64_t kq, uint64_t kj,
                     uint64_t dj, uint64_t cq, uint64_t cj, uint64_t* top_keys, uint32_t* top_docs, uint32_t* top_n,
                     uint32_t top_stride, uint32_t* page_docs, double* page_scores, uint32_t* page_n,
-                    uint32_t page_stride, const uint32_t* list_begin, hipStream_t s);
+                    uint32_t page_stride, const uint32_t* list_begin, const unsigned long long* counters,
+                    uint64_t* totals_out, hipStream_t s);
 int LaunchExportPages(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* page_docs,
                       const uint64_t* totals, uint64_t* blob64, uint32_t* blob32, hipStream_t s);
 int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t pitch, uint64_t* out,

@@ -89,15 +89,23 @@ class ShardedTable:
     def _buffers(self, batch):
         """Per batch: this rank's packed blob and the gathered blobs of every rank. One rank's blob is
         [keys | totals] as u64 followed by [docs | counts] as u32 (mgx_batch_export_topk), padded to a multiple of 8
-        bytes, so ONE all-gather moves both."""
+        bytes, so ONE all-gather moves both. SORT _score batches keep their result in that layout inside the library
+        (mgx_batch_export_buffer): the all-gather reads it in place."""
         key = id(batch)
         if key not in self._blobs:
-            stride = batch.topk_stride()
-            n = batch.n * stride + batch.n          # elements of each blob
-            nbytes = (12 * n + 7) // 8 * 8          # 8n bytes of u64, 4n bytes of u32, padded
             dev = torch.device("cuda", self.index.device_index.device)
-            self._blobs[key] = (n, nbytes, torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                                torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
+            ptr, nbytes, off32 = batch.export_buffer()
+            if ptr:
+                class _Arr:  # __cuda_array_interface__ view of library-owned memory
+                    __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+                mine, copy = torch.as_tensor(_Arr(), device=dev), False
+            else:
+                stride = batch.topk_stride()
+                n = batch.n * stride + batch.n          # elements of each blob
+                off32, nbytes = 8 * n, (12 * n + 7) // 8 * 8
+                mine, copy = torch.empty(nbytes, dtype=torch.uint8, device=dev), True
+            self._blobs[key] = (off32, nbytes, mine, copy, torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
         return self._blobs[key]
 
     def _df_tensor(self, batch, ptr, n):
@@ -133,13 +141,14 @@ class ShardedTable:
         batch.execute(stream)
         if not exchange:
             return
-        n, nbytes, mine, gathered = self._buffers(batch)
-        batch.export_topk(mine.data_ptr(), mine.data_ptr() + 8 * n, stream)
+        off32, nbytes, mine, copy, gathered = self._buffers(batch)
+        if copy:
+            batch.export_topk(mine.data_ptr(), mine.data_ptr() + off32, stream)
         if dist.get_backend() == "nccl":
             dist.all_gather_into_tensor(gathered, mine)
         else:  # gloo: stage through host memory (CPU rehearsal of the exchange; RCCL is the production path)
             parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
             dist.all_gather(parts, mine.cpu())
             gathered.copy_(torch.cat(parts))
-        batch.merge_shards(self.world, gathered.data_ptr(), gathered.data_ptr() + 8 * n, stream,
+        batch.merge_shards(self.world, gathered.data_ptr(), gathered.data_ptr() + off32, stream,
                            pitch64=nbytes // 8, pitch32=nbytes // 4)

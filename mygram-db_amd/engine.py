@@ -341,6 +341,13 @@ class PreparedBatch:
         check(load().mgx_batch_export_topk(self._h, blob64_ptr, blob32_ptr, C.byref(s), stream))
         return int(s.value)
 
+    def export_buffer(self):
+        """-> (device pointer, bytes, byte offset of the 32-bit part) of the library-owned exchange blob, or
+        (None, 0, 0) when the batch has none (docid-ordered pages export by copy)."""
+        p, nb, off = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        check(load().mgx_batch_export_buffer(self._h, C.byref(p), C.byref(nb), C.byref(off)))
+        return p.value, int(nb.value), int(off.value)
+
     def merge_shards(self, n_shards, blob64_ptr, blob32_ptr, stream=None, pitch64=0, pitch32=0):
         check(load().mgx_batch_merge_shards(self._h, n_shards, blob64_ptr, pitch64, blob32_ptr, pitch32, stream))
 
