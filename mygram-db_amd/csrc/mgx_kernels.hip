@@ -1014,6 +1014,8 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
   }
   // per scored term (LDS, misc[16..]): gram id, skip row (exact-tf path), bitmap row (nibble row)
   uint32_t* const sterm = misc + 16;
+  double* const zero_slot = reinterpret_cast<double*>(misc + 28);  // contribution of a term the doc does not hold
+  if (tid == 0) *zero_slot = 0.0;
   if (tid < q.n_score) {
     const DevLeaf lf = bt.leaves[q.leaf_begin + bt.score_terms[q.score_begin + tid].leaf];
     sterm[tid * 3] = lf.a;
@@ -1145,21 +1147,34 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
 #pragma unroll
         for (int m = 0; m < kScoreUnroll; ++m) {
           if (j0 + m * 64 < nm) {  // wave-uniform
-            double score = 0.0;
+            // Contributions without per-term branches: a term the doc lacks (or one outside the table) reads the 0.0
+            // slot — score + 0.0 is score bit for bit, contributions being > 0 — so the table reads go out together;
+            // tf above the table or a doc longer than it (rare) are then evaluated directly.
+            double contrib[kWaveScoreSlots];
+            bool direct = false;
 #pragma unroll
             for (int i = 0; i < kWaveScoreSlots; ++i) {
-              if (tfv[m][i] != 0) {
-                if (tfv[m][i] <= kTableTf && dli[m] < tdl) {
-                  score += table[(i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]];
-                } else {  // bm25_scorer.cpp:80-84, same operation order as the table
+              const bool in_table = tfv[m][i] - 1u < kTableTf && dli[m] < tdl;  // (tf 0 wraps around: not in the table)
+              direct = direct || (tfv[m][i] != 0 && !in_table);
+              const double* src = in_table ? table + ((i * kTableTf + tfv[m][i] - 1) * tdl + dli[m]) : zero_slot;
+              contrib[i] = *src;
+            }
+            if (__ballot(direct) != 0) {  // wave-uniform
+#pragma unroll
+              for (int i = 0; i < kWaveScoreSlots; ++i) {
+                if (tfv[m][i] != 0 && !(tfv[m][i] - 1u < kTableTf && dli[m] < tdl)) {
+                  // bm25_scorer.cpp:80-84, same operation order as the table
                   const double dl = static_cast<double>(dli[m]), tf = static_cast<double>(tfv[m][i]);
                   const double length_norm = q.one_minus_b + q.b * dl / q.avgdl_clamped;
                   const double numerator = tf * q.k1_plus_1;
                   const double denominator = tf + q.k1 * length_norm;
-                  score += bt.score_terms[q.score_begin + i].idf * numerator / denominator;
+                  contrib[i] = bt.score_terms[q.score_begin + i].idf * numerator / denominator;
                 }
               }
             }
+            double score = 0.0;
+#pragma unroll
+            for (int i = 0; i < kWaveScoreSlots; ++i) score += contrib[i];
             const uint32_t doc = ix.first_doc_id + slot[m];
             wave_topk_offer(tk, valid[m], score_key(score, desc), desc ? doc : ~doc);
           }
