@@ -220,7 +220,7 @@ def main():
                          "peak_measured_read": measured_peak,
                          "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
                          "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
-                                   "queries with a sorted-list operand run on a second launch of the same kernel on a "
+                                   "queries with a sorted-list operand run beside it as mgx::wave_score_lists_kernel on a "
                                    "side stream inside the same timed region)",
                          "kernel_ms": k_ms, "launches_timed": k_n,
                          "algorithmic_bytes_per_launch": alg_total,

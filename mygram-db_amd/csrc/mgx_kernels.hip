@@ -974,7 +974,7 @@ __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uin
   return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
 }
 
-__global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+__device__ __forceinline__ void wave_score_body(const DevIndex ix, const DevBatch bt, const WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const WaveOffsets wo = carve_wave(plan);
   DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + wo.leaf);
@@ -1234,6 +1234,15 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
     }
     if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
   }
+}
+
+// Two entry points over the same body: the all-bitmap launch of a step and the (small) launch of the queries that need
+// the sorted-list scratch run side by side; separate symbols keep them apart in profiles.
+__global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  wave_score_body(ix, bt, plan);
+}
+__global__ __launch_bounds__(kWaveBlock, 6) void wave_score_lists_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
+  wave_score_body(ix, bt, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1935,7 +1944,7 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  auto* kernel = &wave_score_kernel;
+  auto* kernel = plan.has_list ? &wave_score_lists_kernel : &wave_score_kernel;
   if (plan.bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
