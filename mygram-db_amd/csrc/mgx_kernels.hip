@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   const uint64_t total_slots = static_cast<uint64_t>(n_lists) * q.needed;
   // Small merges (the usual page: ~12 lists x 10 entries) are staged in LDS first: ranking an entry is a chain of
   // dependent probes into every other list, which costs a memory latency each when the lists stay in HBM.
-  constexpr uint32_t kStage = 2048;
+  constexpr uint32_t kStage = 1024;
   __shared__ uint64_t s_keys[kStage];
   __shared__ uint32_t s_docs[kStage];
   __shared__ uint32_t s_cnt[kStage];
@@ -1519,22 +1519,41 @@ __global__ __launch_bounds__(kBlock) void merge_topk_kernel(const DevQuery* __re
   }
   // A list that is full holds `needed` entries at or above its last key, so nothing below the largest such key can
   // reach the merged top: most entries of a many-list merge are dropped here without being ranked.
-  __shared__ unsigned long long s_thr;
-  if (threadIdx.x == 0) s_thr = 0;
+  // Second bound, the one that bites when many lists are full (top-100 over ~100 workgroup lists): with F full lists,
+  // their first a = ceil(needed / F) entries are `needed` entries at or above the smallest a-th key among them.
+  __shared__ unsigned long long s_thr, s_thr2;
+  __shared__ uint32_t s_full;
+  if (threadIdx.x == 0) {
+    s_thr = 0;
+    s_thr2 = ~0ull;
+    s_full = 0;
+  }
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) {
     const uint32_t c = staged ? s_cnt[j] : min(cnt[MGX_C(j)], q.needed);
     if (c >= q.needed && q.needed > 0) {
       const uint64_t k = staged ? s_keys[j * q.needed + q.needed - 1] : keys[MGX_K(j) + q.needed - 1];
       atomicMax(&s_thr, static_cast<unsigned long long>(k));
+      atomicAdd(&s_full, 1u);
     }
   }
   __syncthreads();
-  const uint64_t thr = s_thr;
+  if (s_full > 1) {
+    const uint32_t a = (q.needed + s_full - 1) / s_full;
+    for (uint32_t j = threadIdx.x; j < n_lists; j += kBlock) {
+      const uint32_t c = staged ? s_cnt[j] : min(cnt[MGX_C(j)], q.needed);
+      if (c >= q.needed) {
+        const uint64_t k = staged ? s_keys[j * q.needed + a - 1] : keys[MGX_K(j) + a - 1];
+        atomicMin(&s_thr2, static_cast<unsigned long long>(k));
+      }
+    }
+  }
+  __syncthreads();
+  const uint64_t thr = (s_full > 1 && s_thr2 > s_thr) ? static_cast<uint64_t>(s_thr2) : static_cast<uint64_t>(s_thr);
   // Everything below thr is worse than every entry at or above it, so the survivors can be ranked among themselves:
   // they are compacted and each counts the survivors that beat it (a few dozen LDS reads instead of a binary search in
   // every other list, which is what made merges of ~70 lists slow).
-  constexpr uint32_t kSurv = 1024;
+  constexpr uint32_t kSurv = 2048;
   __shared__ uint64_t s_sk[kSurv];
   __shared__ uint32_t s_sd[kSurv];
   __shared__ uint32_t s_nsurv;
