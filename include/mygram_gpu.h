@@ -261,8 +261,8 @@ int mgx_batch_export_buffer(mgx_batch* batch, void** device_blob, uint64_t* byte
 int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
                            const uint32_t* blob32, uint64_t pitch32, void* hip_stream);
 /* Text-level terms across shards: df must be table-wide before idf is taken. mgx_batch_count_df enqueues only the df
- * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per term, in
- * batch order: query-major, then term order), which the caller sums over ranks in place (one RCCL all-reduce); the next
+ * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per DISTINCT
+ * term of the batch, in order of first appearance — the same on every shard), which the caller sums over ranks in place (one RCCL all-reduce); the next
  * mgx_batch_execute then uses those counts instead of running its own df pass. *n == 0: nothing to exchange. */
 int mgx_batch_count_df(mgx_batch* batch, void* hip_stream);
 int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n);

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1136,9 +1137,18 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
   {
     std::string pool;
     std::vector<DevTextTerm> tts;
+    // the df of a term depends on the term (and on N), not on the query around it: one df query per distinct term
+    std::map<std::pair<std::string, uint64_t>, uint32_t> seen;
     for (QuerySpec& s : b->specs) {
       for (const QuerySpec::TextTerm& tt : s.text_terms) {
+        const auto key = std::make_pair(tt.pattern, s.total_docs);
+        const auto hit = seen.find(key);
+        if (hit != seen.end()) {
+          s.score[tt.score_index].text_term = hit->second;
+          continue;
+        }
         const uint32_t id = static_cast<uint32_t>(tts.size());
+        seen.emplace(key, id);
         DevTextTerm d{static_cast<uint32_t>(pool.size()), static_cast<uint32_t>(tt.pattern.size())};
         pool += tt.pattern;
         tts.push_back(d);
