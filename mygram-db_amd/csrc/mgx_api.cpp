@@ -885,8 +885,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     (void)has_list;
     if (g.wplan_lists.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
   }
-  if (page_mode) {
-    // flat programs count on the wave kernel (registers only, two tiles in flight per wave)
+  if (page_mode || df_mode) {
+    // flat programs count on the wave kernel (registers only, two tiles in flight per wave); the df pass of a
+    // text-level term (always a flat AND of its grams) enumerates and scans its candidates there too
     const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
     uint32_t wl = 1, wi = 1;
     bool has_list = false;
@@ -1203,6 +1204,7 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
   if (g.qids.empty()) return MGX_OK;
   MGX_HIP(hipSetDevice(idx->device));
   MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
+  MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, true, s));
   MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s));
   // counter slot 5 of every df query -> contiguous u64 array (the buffer ranks all-reduce)
   MGX_HIP(hipMemcpy2DAsync(b->d_text_df.p, sizeof(uint64_t), g.d_counters.as<unsigned long long>() + 5,
@@ -1298,7 +1300,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, s));
+    MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, false, s));
     MGX_LAUNCH(LaunchTileEval(kModeDocCount, idx->dev, g.dev, g.plan, s));
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev1, s));

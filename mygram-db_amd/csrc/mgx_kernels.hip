@@ -1289,7 +1289,12 @@ __device__ __forceinline__ void wave_operand_words(const DevIndex& ix, const Dev
   }
 }
 
-template <bool kLists>
+// kTextDf: the df pass of a text-level term (kModeTextDf queries with flat programs) — instead of a count per tile, the
+// tile's candidates are enumerated into a per-wave LDS buffer and every lane looks for the term in one candidate's text
+// (PopulateTermDocumentFrequency, search_pipeline.cpp:556-563); the hits are summed into counter slot 5.
+constexpr uint32_t kDfMatchBuf = 512;
+
+template <bool kLists, bool kTextDf>
 __global__ __launch_bounds__(kBlock) void wave_count_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem);
@@ -1298,8 +1303,10 @@ __global__ __launch_bounds__(kBlock) void wave_count_kernel(DevIndex ix, DevBatc
       smem + align8(plan.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf))) + align8(plan.max_instr * 4));
   const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
   uint64_t* const scratch = scratch_all + (kLists ? static_cast<size_t>(wave) * kWordsPerTile : 0);
-  constexpr int kT = kLists ? 1 : 2;  // tiles in flight per wave
+  constexpr int kT = (kLists || kTextDf) ? 1 : 2;  // tiles in flight per wave
   constexpr int kWaves = kBlock / 64;
+  uint16_t* const mbuf = reinterpret_cast<uint16_t*>(scratch_all + (kLists ? kWaves * kWordsPerTile : 0)) +
+                         static_cast<size_t>(wave) * kDfMatchBuf;
 
   const DevItem it = bt.items[blockIdx.x];
   const uint32_t qi = it.query;
@@ -1307,8 +1314,10 @@ __global__ __launch_bounds__(kBlock) void wave_count_kernel(DevIndex ix, DevBatc
   for (uint32_t i = tid; i < q.n_leaves; i += kBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
   for (uint32_t i = tid; i < q.n_instr; i += kBlock) prog[i] = bt.prog[q.prog_begin + i];
   __syncthreads();
+  TextPattern df_pattern{nullptr, 0, 0, 0, 0, 0};
+  if (kTextDf) df_pattern = text_pattern(bt.patterns + q.pat_off, q.pat_len);
 
-  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0, cnt_df = 0;
   const uint32_t tile_begin = it.tile_begin;
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
   for (uint32_t t0 = tile_begin + wave * kT; t0 < tile_end; t0 += kWaves * kT) {
@@ -1346,22 +1355,47 @@ __global__ __launch_bounds__(kBlock) void wave_count_kernel(DevIndex ix, DevBatc
         }
       }
     }
-#pragma unroll
-    for (int u = 0; u < kT; ++u) {
+    for (int u = 0; u < kT; ++u) {  // (kT is 1 or 2: unrolled by the compiler where it can be)
       const uint32_t tile = t0 + u;
       if (tile < tile_end) {  // wave-uniform
         uint32_t c = __popcll(acc[u][0]) + __popcll(acc[u][1]) + __popcll(acc[u][2]) + __popcll(acc[u][3]);
         cnt_res += c;
+        if (kTextDf) {
+          for (;;) {  // rounds of at most kDfMatchBuf candidates
+            uint32_t n_left;
+            const uint32_t mine =
+                __popcll(acc[u][0]) + __popcll(acc[u][1]) + __popcll(acc[u][2]) + __popcll(acc[u][3]);
+            uint32_t r = wave_excl_scan_total(mine, &n_left);
+            if (n_left == 0) break;  // wave-uniform
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
-        if (lane == 0) bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile] = c;
+            for (int k = 0; k < 4; ++k) {
+              while (acc[u][k] != 0 && r < kDfMatchBuf) {
+                const uint32_t bit = __builtin_ctzll(acc[u][k]);
+                acc[u][k] &= acc[u][k] - 1;
+                mbuf[r] = static_cast<uint16_t>((lane << 8) | (k << 6) | bit);
+                ++r;
+              }
+            }
+            wave_lds_sync();
+            const uint32_t nm = min(kDfMatchBuf, n_left);
+            for (uint32_t j = lane; j < nm; j += 64) {
+              const uint32_t slot = tile * kTileDocs + mbuf[j];
+              cnt_df += text_count_occurrences(ix.text, ix.text_off[slot], ix.text_off[slot + 1], df_pattern, true);
+            }
+            wave_lds_sync();
+          }
+        } else {
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+          if (lane == 0) bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile] = c;
+        }
       }
     }
   }
   {
-    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+    uint32_t v[6] = {cnt0, cnt1, cnt2, cnt3, cnt_res, cnt_df};
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
+    for (int s = 0; s < 6; ++s) {
       uint32_t x = v[s];
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
@@ -1933,15 +1967,14 @@ uint32_t WaveCountLdsBytes(const WavePlan& plan) {
          (plan.has_list ? (kBlock / 64) * kWordsPerTile * 8 : 0);
 }
 
-int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s) {
+int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, bool text_df, hipStream_t s) {
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
-  const uint32_t lds = WaveCountLdsBytes(plan);
-  if (plan.has_list)
-    hipLaunchKernelGGL(wave_count_kernel<true>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
-  else
-    hipLaunchKernelGGL(wave_count_kernel<false>, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
+  const uint32_t lds = WaveCountLdsBytes(plan) + (text_df ? (kBlock / 64) * kDfMatchBuf * 2 : 0);
+  auto* kernel = text_df ? (plan.has_list ? &wave_count_kernel<true, true> : &wave_count_kernel<false, true>)
+                         : (plan.has_list ? &wave_count_kernel<true, false> : &wave_count_kernel<false, false>);
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), lds, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
