@@ -1906,16 +1906,67 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_sort_by_score: null argument");
   const uint64_t start = std::min<uint64_t>(offset, n);
   const uint64_t end = limit == 0 ? n : std::min<uint64_t>(start + limit, n);
-  uint32_t* o = static_cast<uint32_t*>(std::malloc(((end - start) ? (end - start) : 1) * 4));
+  // (owned here until the call has succeeded: out-parameters stay NULL/0 on every failure path)
+  std::unique_ptr<uint32_t, void (*)(void*)> page(
+      static_cast<uint32_t*>(std::malloc(((end - start) ? (end - start) : 1) * 4)), std::free);
+  uint32_t* o = page.get();
   if (!o) return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
-  *out_docs = o;
-  *out_n = end - start;
-  if (end == start) return MGX_OK;
+  auto succeed = [&]() {
+    *out_docs = page.release();
+    *out_n = end - start;
+    return MGX_OK;
+  };
+  if (end == start) return succeed();
+  const bool bounded_page = limit != 0 && static_cast<uint64_t>(offset) + limit <= mgx::kMaxNeeded;
+  if (n > 65536 && !bounded_page) {
+    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED,
+                     "mgx_sort_by_score: more than 65536 entries need a bounded page (0 < offset+limit <= 1024)");
+  }
   if (n > 65536) {
-    std::free(o);
-    *out_docs = nullptr;
-    *out_n = 0;
-    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_sort_by_score: more than 65536 entries (use the fused batch path)");
+    // long arrays: per-wave top-(offset+limit) over strided shares, then the merge kernel of the batch path
+    try {
+      std::lock_guard<std::mutex> lock(idx->mu);
+      MGX_HIP(hipSetDevice(idx->device));
+      const uint32_t needed = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(offset) + limit, n));
+      uint32_t cap = 64;
+      while (cap < needed) cap <<= 1;
+      const uint32_t n_blocks = static_cast<uint32_t>(std::min<uint64_t>(256, (n + 16383) / 16384));
+      const uint32_t n_lists = n_blocks * (mgx::kBlock / 64);
+      mgx::DevQuery q{};
+      q.needed = needed;
+      q.cap = cap;
+      q.limit = limit;
+      q.offset = offset;
+      q.descending = descending ? 1 : 0;
+      const uint32_t zero = 0;
+      DevBuf d_r, d_s, d_k, d_d, d_ck, d_cd, d_cn, d_q, d_id, d_o, d_ps, d_pn;
+      MGX_HIP(mgx::Upload(d_r, results, n));
+      MGX_HIP(mgx::Upload(d_s, scores, n));
+      MGX_HIP(mgx::Upload(d_q, &q, 1));
+      MGX_HIP(mgx::Upload(d_id, &zero, 1));
+      MGX_HIP(d_k.Alloc(n * 8));
+      MGX_HIP(d_d.Alloc(n * 4));
+      MGX_HIP(d_ck.Alloc(static_cast<size_t>(n_lists) * needed * 8));
+      MGX_HIP(d_cd.Alloc(static_cast<size_t>(n_lists) * needed * 4));
+      MGX_HIP(d_cn.Alloc(static_cast<size_t>(n_lists) * 4));
+      MGX_HIP(d_o.Alloc(static_cast<size_t>(limit) * 4));
+      MGX_HIP(d_ps.Alloc(static_cast<size_t>(limit) * 8));
+      MGX_HIP(d_pn.Alloc(4));
+      MGX_LAUNCH(mgx::LaunchMakeSortKeys(d_r.as<uint32_t>(), d_s.as<double>(), n, descending, d_k.as<uint64_t>(),
+                                         d_d.as<uint32_t>(), idx->stream));
+      MGX_LAUNCH(mgx::LaunchTopKScan(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n, needed, cap, descending, n_blocks,
+                                     d_ck.as<uint64_t>(), d_cd.as<uint32_t>(), d_cn.as<uint32_t>(), idx->stream));
+      MGX_LAUNCH(mgx::LaunchMergeTopK(d_q.as<mgx::DevQuery>(), d_id.as<uint32_t>(), 1, n_lists, d_ck.as<uint64_t>(),
+                                      d_cd.as<uint32_t>(), d_cn.as<uint32_t>(), /*kq=*/0, /*kj=*/needed, /*dj=*/needed,
+                                      /*cq=*/0, /*cj=*/1, nullptr, nullptr, nullptr, 0, d_o.as<uint32_t>(),
+                                      d_ps.as<double>(), d_pn.as<uint32_t>(), limit, nullptr, nullptr, nullptr,
+                                      idx->stream));
+      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
+      MGX_HIP(hipStreamSynchronize(idx->stream));
+      return succeed();
+    } catch (const std::exception& e) {
+      return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
+    }
   }
   try {
     std::lock_guard<std::mutex> lock(idx->mu);
@@ -1931,7 +1982,7 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
                                       d_d.as<uint32_t>(), d_o.as<uint32_t>(), idx->stream));
     MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
     MGX_HIP(hipStreamSynchronize(idx->stream));
-    return MGX_OK;
+    return succeed();
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
   }

@@ -1897,6 +1897,49 @@ __global__ void rank_count_kernel(const uint64_t* __restrict__ keys, const uint3
   if (rank >= lo && rank < hi) out[rank - lo] = descending ? d : ~d;
 }
 
+// SortByScore over an arbitrarily long (key, docid') array when only a bounded page is wanted: every wave keeps the
+// best `needed` of a strided share of the array (WaveTopK, as in the scoring kernels) and leaves them as one sorted
+// candidate list; merge_topk_kernel then merges the lists like the per-workgroup lists of a query.
+__global__ __launch_bounds__(kBlock) void topk_scan_kernel(const uint64_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ dprime, uint64_t n,
+                                                           uint32_t needed, uint32_t cap, int descending,
+                                                           uint64_t* __restrict__ cand_keys,
+                                                           uint32_t* __restrict__ cand_docs,
+                                                           uint32_t* __restrict__ cand_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = lane_id(), wave = wave_id();
+  const uint32_t gw = blockIdx.x * (kBlock / 64) + wave, n_waves = gridDim.x * (kBlock / 64);
+  WaveTopK tk;
+  tk.cap = cap;
+  tk.needed = needed;
+  tk.keys = reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(wave) * 2 * cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kBlock / 64) * 2 * cap * 8) +
+            static_cast<size_t>(wave) * 2 * cap;
+  tk.have = 0;
+  tk.pend = 0;
+  tk.bound_key = 0;
+  tk.bound_doc = 0;
+  tk.gbound_ptr = nullptr;
+  tk.gbound = 0;
+  for (uint32_t i = lane; i < 2 * cap; i += 64) {
+    tk.keys[i] = 0;
+    tk.docs[i] = 0;
+  }
+  wave_lds_sync();
+  for (uint64_t base = static_cast<uint64_t>(gw) * 64; base < n; base += static_cast<uint64_t>(n_waves) * 64) {
+    const uint64_t i = base + lane;
+    const bool valid = i < n;
+    wave_topk_offer(tk, valid, valid ? keys[i] : 0ull, valid ? dprime[i] : 0u);
+  }
+  wave_topk_truncate(tk);
+  const uint32_t have = tk.have < needed ? tk.have : needed;
+  for (uint32_t i = lane; i < have; i += 64) {
+    cand_keys[static_cast<uint64_t>(gw) * needed + i] = tk.keys[i];
+    cand_docs[static_cast<uint64_t>(gw) * needed + i] = tk.docs[i];
+  }
+  if (lane == 0) cand_n[gw] = have;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
@@ -2108,6 +2151,32 @@ int LaunchScoreCandidatesText(const DevIndex& ix, const uint32_t* cand, uint64_t
   const double avg = avgdl > 1.0 ? avgdl : 1.0;
   hipLaunchKernelGGL(score_candidates_text_kernel, dim3(static_cast<uint32_t>((n_cand + 255) / 256)), dim3(256), 0, s,
                      ix, cand, n_cand, term_bytes, term_off, idfs, n_terms, k1, b, 1.0 - b, k1 + 1.0, avg, scores);
+  MGX_KCHECK();
+  return 0;
+}
+
+// keys/dprime: the (key, docid') pairs of make_sort_keys_kernel. Returns the number of candidate lists written
+// (negative: a HIP error code negated).
+int LaunchTopKScan(const uint64_t* keys, const uint32_t* dprime, uint64_t n, uint32_t needed, uint32_t cap,
+                   int descending, uint32_t n_blocks, uint64_t* cand_keys, uint32_t* cand_docs, uint32_t* cand_n,
+                   hipStream_t s) {
+  const uint32_t lds = (kBlock / 64) * 2 * cap * 12;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_scan_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(topk_scan_kernel, dim3(n_blocks), dim3(kBlock), lds, s, keys, dprime, n, needed, cap, descending,
+                     cand_keys, cand_docs, cand_n);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchMakeSortKeys(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint64_t* keys,
+                       uint32_t* dprime, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(make_sort_keys_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s, docs, scores,
+                     n, descending, keys, dprime);
   MGX_KCHECK();
   return 0;
 }

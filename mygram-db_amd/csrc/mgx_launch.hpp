@@ -42,6 +42,11 @@ int LaunchScoreCandidates(const DevIndex& ix, const uint32_t* cand, uint64_t n_c
 int LaunchScoreCandidatesText(const DevIndex& ix, const uint32_t* cand, uint64_t n_cand, const uint8_t* term_bytes,
                               const uint32_t* term_off, const double* idfs, uint32_t n_terms, double k1, double b,
                               double avgdl, double* scores, hipStream_t s);
+int LaunchTopKScan(const uint64_t* keys, const uint32_t* dprime, uint64_t n, uint32_t needed, uint32_t cap,
+                   int descending, uint32_t n_blocks, uint64_t* cand_keys, uint32_t* cand_docs, uint32_t* cand_n,
+                   hipStream_t s);
+int LaunchMakeSortKeys(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint64_t* keys,
+                       uint32_t* dprime, hipStream_t s);
 int LaunchSortByScore(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint32_t lo,
                       uint32_t hi, uint64_t* keys_tmp, uint32_t* dprime_tmp, uint32_t* out, hipStream_t s);
 

@@ -354,3 +354,19 @@ def test_saturated_tf_and_long_docs(score_kernel):
              Query(["ab"], sort_score=True, limit=100, descending=False),
              Query(["cd", "ef", "ab"], sort_score=True, limit=10, offset=5),
              Query(["xx", "ab"], sort_score=True, limit=10)])
+
+
+def test_sort_by_score_long_arrays():
+    # ResultSorter::SortByScore over more entries than the rank-by-counting kernel takes: bounded pages go through the
+    # per-wave top-k scan + merge; an unbounded sort of a long array is refused
+    idx = mg.Index(texts=["x"], ngram_size=1)
+    rng = np.random.default_rng(31)
+    n = 300_000
+    docs = rng.permutation(np.arange(1, n + 1, dtype=np.uint32))
+    scores = np.round(rng.random(n) * 50.0, 1)  # many ties: docid decides
+    for desc, limit, offset in [(True, 10, 0), (False, 10, 0), (True, 100, 37), (False, 1000, 24), (True, 1, 0)]:
+        got = idx.sort_by_score(docs, scores, desc, limit, offset)
+        want = O.sort_by_score(docs, scores, desc, limit, offset)
+        assert got.tolist() == want.tolist(), (desc, limit, offset)
+    with pytest.raises(mg._capi.MgxError):
+        idx.sort_by_score(docs, scores, True, 0, 0)
