@@ -211,6 +211,12 @@ typedef struct mgx_query {
   uint32_t n_expr;
   uint32_t universe_first;
   uint64_t universe_count;
+  /* Exact-text post-filter (PostFilterByText, search_pipeline.cpp:1239-1246): after NOT terms and filters, keep only
+   * the docs whose text contains EVERY positive term. The caller sets it when the reference would: memory.verify_text
+   * says so (ShouldApplyVerifyText :42-66), or a mixed-script term has a code point no query n-gram covers
+   * (RequiresExactTextForHybridFragments :138-150). Every positive term must then carry its normalized `text`;
+   * needs mgx_index_attach_text. after_filters still counts the docs before this filter, `total` those after it. */
+  uint32_t exact_text;
 } mgx_query;
 
 typedef struct mgx_batch mgx_batch;

@@ -60,7 +60,7 @@ class Query(C.Structure):
                 ("sort", C.c_uint32), ("limit", C.c_uint32), ("offset", C.c_uint32), ("reverse", C.c_uint32),
                 ("k1", C.c_double), ("b", C.c_double), ("total_docs", C.c_uint64), ("avg_doc_length", C.c_double),
                 ("expr", C.c_void_p), ("n_expr", C.c_uint32), ("universe_first", C.c_uint32),
-                ("universe_count", C.c_uint64)]
+                ("universe_count", C.c_uint64), ("exact_text", C.c_uint32)]
 
 
 class ExprToken(C.Structure):

@@ -434,8 +434,10 @@ struct QuerySpec {
     uint32_t score_index = 0;  // position among the query's scored terms
   };
   std::vector<TextTerm> text_terms;
+  std::vector<std::string> verify_patterns;  // kOpVerifyText: every positive term's text
   uint64_t total_docs = 0;       // N of ComputeIDF for the text-level terms
   uint32_t pat_off = 0, pat_len = 0;  // kModeTextDf specs: the term in the batch's pattern pool
+  uint32_t vt_begin = 0;              // first of the query's verify patterns in the batch-wide array
 };
 
 struct Compiler {
@@ -652,6 +654,16 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     c.Emit(in.filters[i].negate ? kOpAndNot : kOpAnd, id);
   }
   c.Emit(kOpCount, 3);
+  if (in.exact_text) {
+    if (!idx->dev.text) return Fail(MGX_ERR_INVALID_ARGUMENT, "exact_text without mgx_index_attach_text");
+    for (uint32_t i = 0; i < in.n_terms; ++i) {
+      const mgx_term& t = in.terms[i];
+      if (!t.text || t.text_len == 0 || t.text_len > 4096)
+        return Fail(MGX_ERR_INVALID_ARGUMENT, "exact_text: every positive term needs its normalized text (1..4096 bytes)");
+      out->verify_patterns.emplace_back(reinterpret_cast<const char*>(t.text), t.text_len);
+    }
+    c.Emit(kOpVerifyText);  // (not a flat op: the query runs on the general workgroup kernel)
+  }
 
   out->limit = in.limit;
   out->offset = in.offset;
@@ -753,7 +765,7 @@ struct mgx_batch {
   // df pass of the text-level scored terms: one kModeTextDf query per term (the AND of its grams + a text scan)
   Group textdf;
   std::vector<mgx::QuerySpec> df_specs;
-  DevBuf d_patterns, d_text_terms, d_text_idf, d_text_df;
+  DevBuf d_patterns, d_text_terms, d_text_idf, d_text_df, d_verify_terms;
   std::vector<uint64_t> h_text_df, text_total_docs;
   std::vector<double> h_text_idf;
   bool df_ready = false;  // mgx_batch_count_df ran (and the caller summed the counts) for the next execute
@@ -835,6 +847,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     q.out_slot = i;
     q.pat_off = s.pat_off;
     q.pat_len = s.pat_len;
+    q.vt_begin = s.vt_begin;
+    q.vt_count = static_cast<uint32_t>(s.verify_patterns.size());
     q.k1 = s.k1;
     q.b = s.b;
     q.one_minus_b = 1.0 - s.b;
@@ -1025,6 +1039,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   d.patterns = b->d_patterns.as<uint8_t>();
   d.text_terms = b->d_text_terms.as<DevTextTerm>();
   d.text_idf = b->d_text_idf.as<double>();
+  d.verify_terms = b->d_verify_terms.as<DevTextTerm>();
   d.n_queries = n;
   d.counters = score_mode  ? b->sc_counters()
                : page_mode ? b->d_page_out.as<unsigned long long>()
@@ -1172,6 +1187,19 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
           return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct n-grams in one text-level term");
         b->df_specs.push_back(std::move(ds));
       }
+    }
+    // exact-text filters: their patterns share the pool
+    std::vector<DevTextTerm> vts;
+    for (QuerySpec& s : b->specs) {
+      s.vt_begin = static_cast<uint32_t>(vts.size());
+      for (const std::string& pat : s.verify_patterns) {
+        vts.push_back(DevTextTerm{static_cast<uint32_t>(pool.size()), static_cast<uint32_t>(pat.size())});
+        pool += pat;
+      }
+    }
+    if (!vts.empty()) {
+      MGX_HIP(Upload(b->d_verify_terms, vts.data(), vts.size()));
+      if (tts.empty()) MGX_HIP(Upload(b->d_patterns, reinterpret_cast<const uint8_t*>(pool.data()), pool.size(), 16));
     }
     const uint32_t n_tt = static_cast<uint32_t>(tts.size());
     if (n_tt != 0) {

@@ -60,6 +60,8 @@ enum Op : uint32_t {
   kOpThreshBegin,   // bit-sliced counters = 0
   kOpThreshAdd,     // counters += W(leaf)
   kOpThreshEnd,     // acc = (counters >= arg)
+  kOpVerifyText,    // acc &= docs whose text contains every pattern of the query (PostFilterByText,
+                    // search_pipeline.cpp:1239-1246); general workgroup kernel only
 };
 inline constexpr uint32_t MakeInstr(Op op, uint32_t arg) { return (static_cast<uint32_t>(op) << 24) | (arg & 0xFFFFFFu); }
 
@@ -99,6 +101,7 @@ struct DevQuery {
   uint32_t stack_depth;
   uint32_t out_slot;  // row of this query in the per-mode output arrays
   uint32_t pat_off, pat_len;  // kModeTextDf: the term searched in the candidates' text
+  uint32_t vt_begin, vt_count;  // kOpVerifyText: the query's patterns in DevBatch::verify_terms
   double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;  // BM25 constants, pre-evaluated on the host
 };
 
@@ -145,6 +148,7 @@ struct DevBatch {
   const uint8_t* patterns;         // text-level terms of the batch, concatenated
   const DevTextTerm* text_terms;
   const double* text_idf;          // [n_text_terms] ComputeIDF(N, df) of the current execute's df pass
+  const DevTextTerm* verify_terms;  // patterns of the queries that filter their result by exact text
   uint32_t n_queries;
   // outputs
   unsigned long long* counters;  // [n_queries][8]: funnel slots 0..3, slot 4 = final result count

@@ -605,6 +605,24 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
             acc = gt | eq;
             break;
           }
+          case kOpVerifyText: {
+            // exact-text post-filter: a doc stays only if its text contains every pattern (rare query shapes only —
+            // mixed-script terms under hybrid n-grams, or verify_text asked for by the caller; one doc at a time)
+            uint64_t bits = acc;
+            while (bits) {
+              const uint32_t bpos = __builtin_ctzll(bits);
+              bits &= bits - 1;
+              const uint32_t slot = tile * kTileDocs + tid * 64 + bpos;
+              const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
+              bool all = true;
+              for (uint32_t v = 0; all && v < q.vt_count; ++v) {
+                const DevTextTerm vt = bt.verify_terms[q.vt_begin + v];
+                all = text_count_occurrences(ix.text, t0, t1, text_pattern(bt.patterns + vt.pat_off, vt.pat_len), true) != 0;
+              }
+              if (!all) acc &= ~(1ull << bpos);
+            }
+            break;
+          }
           default: break;
         }
       }

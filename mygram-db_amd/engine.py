@@ -61,6 +61,36 @@ def normalize_text(text):
     return "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in text)
 
 
+def _is_cjk_ideograph_pipeline(cp):
+    """IsCjkIdeograph of src/server/search_pipeline.cpp:70-78."""
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F or
+            0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF)
+
+
+def has_uncovered_hybrid_fragment(normalized, ngram_size, kanji_ngram_size, cross_boundary):
+    """HasUncoveredHybridFragment (src/server/search_pipeline.cpp:80-136): a term that mixes CJK ideographs with other
+    code points and has a code point no query n-gram covers; such a query is post-filtered by exact text (:858-866)."""
+    if not normalized or kanji_ngram_size <= 0:
+        return False
+    ascii_n = ngram_size if ngram_size > 0 else 2
+    cps = [ord(c) for c in normalized]
+    if len(cps) < 2:
+        return False
+    flags = [_is_cjk_ideograph_pipeline(c) for c in cps]
+    if all(flags) or not any(flags):
+        return False
+    covered = [False] * len(cps)
+    for i, start_is_cjk in enumerate(flags):
+        n = kanji_ngram_size if start_is_cjk else ascii_n
+        if n <= 0 or i + n > len(cps):
+            continue
+        if not cross_boundary and any(flags[i + j] != start_is_cjk for j in range(1, n)):
+            continue
+        for j in range(n):
+            covered[i + j] = True
+    return not all(covered)
+
+
 def compute_idf(total_docs, doc_freq):
     """BM25Scorer::ComputeIDF, src/index/bm25_scorer.cpp:14-25 (host side: once per term per query)."""
     if total_docs == 0:
@@ -213,13 +243,16 @@ class Query:
     """The parts of query::Query (src/query/query_parser.h:207-243) the hot path consumes."""
 
     def __init__(self, terms=(), not_terms=(), filters=(), sort_score=False, limit=100, offset=0, descending=True,
-                 k1=1.2, b=0.75, fuzzy=0, expr=None, universe=None):
+                 k1=1.2, b=0.75, fuzzy=0, expr=None, universe=None, verify_text=False):
         """`expr`: boolean tree over term strings instead of the plain AND of `terms` (query::QueryNode):
         "term" | ("and", e, ...) | ("or", e, ...) | ("not", e). `universe` = (first_doc_id, count) of the NOT universe
         (DocumentStore::GetAllDocIds); None = every slot of the index."""
         self.terms, self.not_terms, self.filters = list(terms), list(not_terms), list(filters)
         self.sort_score, self.limit, self.offset, self.descending = sort_score, limit, offset, descending
         self.k1, self.b, self.fuzzy = k1, b, fuzzy
+        # verify_text: the caller's memory.verify_text decision (ShouldApplyVerifyText, search_pipeline.cpp:42-66);
+        # queries with an uncovered mixed-script fragment are post-filtered by exact text regardless (:858-866)
+        self.verify_text = verify_text
         self.expr, self.universe = expr, universe
         if expr is not None and not self.terms:
             seen = []
@@ -594,12 +627,21 @@ class Index:
             if q.expr is None and any(not t.grams for t in tis):
                 raise _capi.MgxError(4, "a term shorter than one n-gram needs the substring fallback "
                                         "(SearchNormalizedSubstring), which is not on the device path")
+            exact = q.expr is None and (q.verify_text or any(
+                has_uncovered_hybrid_fragment(t.normalized, self.ngram_size, self.kanji_ngram_size, self.cross_boundary)
+                for t in tis))
+            if exact:
+                self.ensure_text()
             cterms = (_capi.Term * len(tis))()
             for j, t in enumerate(tis):
                 ids = np.asarray(t.gram_ids, dtype=np.uint32)
                 keep.append(ids)
                 thr = t.threshold if (q.fuzzy and t.threshold < len(ids)) else 0
                 idf, text_ptr, text_len = 0.0, None, 0
+                if exact:
+                    tb = np.frombuffer(t.normalized.encode("utf-8"), dtype=np.uint8).copy()
+                    keep.append(tb)
+                    text_ptr, text_len = tb.ctypes.data, len(tb)
                 if q.sort_score:
                     if t.df is None:  # text-level term
                         self.ensure_text()
@@ -630,6 +672,7 @@ class Index:
                              C.cast(cf, C.c_void_p), len(q.filters),
                              _capi.SORT_SCORE if q.sort_score else _capi.SORT_DOCID, q.limit, q.offset,
                              int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
+            cq.exact_text = int(exact)
             if expr_tokens is not None:
                 cq.expr = C.cast(expr_tokens, C.c_void_p)
                 cq.n_expr = len(expr_tokens)

@@ -292,6 +292,58 @@ static int is_cjk_ideograph(uint32_t cp) {
          (cp >= 0x2A700 && cp <= 0x2B73F) || (cp >= 0x2B740 && cp <= 0x2B81F) || (cp >= 0xF900 && cp <= 0xFAFF);
 }
 
+/* src/server/search_pipeline.cpp:70-78 (this copy of the predicate knows one more CJK extension block than the one in
+ * string_utils.cpp) */
+static int pipeline_is_cjk_ideograph(uint32_t cp) {
+  return (cp >= 0x4E00 && cp <= 0x9FFF) || (cp >= 0x3400 && cp <= 0x4DBF) || (cp >= 0x20000 && cp <= 0x2A6DF) ||
+         (cp >= 0x2A700 && cp <= 0x2B73F) || (cp >= 0x2B740 && cp <= 0x2B81F) || (cp >= 0x2B820 && cp <= 0x2CEAF) ||
+         (cp >= 0xF900 && cp <= 0xFAFF);
+}
+
+/* src/server/search_pipeline.cpp:80-136 HasUncoveredHybridFragment: a normalized term that mixes CJK ideographs with
+ * other code points and has a code point that no query n-gram (of the size its script starts) covers. */
+int orc_has_uncovered_hybrid_fragment(const uint8_t* term, size_t len, int ngram_size, int kanji_ngram_size,
+                                      int cross_boundary) {
+  if (len == 0 || kanji_ngram_size <= 0) return 0;
+  const int ascii_n = ngram_size > 0 ? ngram_size : 2;
+  size_t cpn = 0;
+  uint32_t* cps = utf8_to_codepoints(term, len, &cpn);
+  if (cpn < 2) {
+    free(cps);
+    return 0;
+  }
+  int has_cjk = 0, has_other = 0;
+  for (size_t i = 0; i < cpn; ++i) {
+    if (pipeline_is_cjk_ideograph(cps[i])) has_cjk = 1; else has_other = 1;
+  }
+  if (!has_cjk || !has_other) {
+    free(cps);
+    return 0;
+  }
+  uint8_t* covered = (uint8_t*)calloc(cpn, 1);
+  for (size_t i = 0; i < cpn; ++i) {
+    const int start_is_cjk = pipeline_is_cjk_ideograph(cps[i]);
+    const int n = start_is_cjk ? kanji_ngram_size : ascii_n;
+    if (n <= 0 || i + (size_t)n > cpn) continue;
+    if (!cross_boundary) {
+      int crossed = 0;
+      for (int j = 1; j < n; ++j) {
+        if (pipeline_is_cjk_ideograph(cps[i + (size_t)j]) != start_is_cjk) {
+          crossed = 1;
+          break;
+        }
+      }
+      if (crossed) continue;
+    }
+    for (int j = 0; j < n; ++j) covered[i + (size_t)j] = 1;
+  }
+  int uncovered = 0;
+  for (size_t i = 0; i < cpn; ++i) uncovered = uncovered || !covered[i];
+  free(covered);
+  free(cps);
+  return uncovered;
+}
+
 /* src/utils/string_utils.cpp:452-509 */
 void orc_generate_hybrid_ngrams(const uint8_t* text, size_t len, int ascii_n, int kanji_n, int cross_boundary,
                                 orc_strlist* out) {
@@ -1118,7 +1170,28 @@ int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* tb,
     results = r2;
   }
   out->after_filters = results.n;
-  /* ApplyVerifyTextFilter :856-857 is a no-op with memory.verify_text="off" (the default, src/config/config.h:317-330) */
+  /* ApplyVerifyTextFilter :856-857 is a no-op with memory.verify_text="off" (the default, src/config/config.h:317-330).
+   * :858-866: a mixed-script term with a code point no query n-gram covers makes the n-gram AND too weak, so the
+   * results are filtered by the exact text of ALL terms (PostFilterByText :1239-1246). */
+  {
+    int exact = 0;
+    for (size_t i = 0; i < n_terms; ++i)
+      exact = exact || orc_has_uncovered_hybrid_fragment(tis[i].normalized, tis[i].normalized_len, ngram_size,
+                                                         kanji_ngram_size, cross_boundary);
+    out->exact_text_applied = exact;
+    if (exact && results.n > 0 && ds != NULL) {
+      size_t w = 0;
+      for (size_t r = 0; r < results.n; ++r) {
+        size_t tl;
+        const uint8_t* tx = docstore_text(ds, results.v[r], &tl);
+        int all = tx != NULL;
+        for (size_t i = 0; all && i < n_terms; ++i)
+          all = bytes_find(tx, tl, tis[i].normalized, tis[i].normalized_len, 0) != (size_t)-1;
+        if (all) results.v[w++] = results.v[r];
+      }
+      results.n = w;
+    }
+  }
 
 done:
   out->results = results.v ? results.v : u32_dup(NULL, 0);

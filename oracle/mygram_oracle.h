@@ -138,6 +138,7 @@ typedef struct orc_pipeline_result {
   uint32_t term_order[64]; /* index into the caller's term array */
   uint64_t term_df[64];    /* text-verified document frequency (0 when not computed) */
   uint64_t term_estimated_size[64];
+  int exact_text_applied; /* search_pipeline.cpp:858-866 fired: results were filtered by the terms' exact text */
 } orc_pipeline_result;
 
 /* One column filter already resolved to a sorted docid set (FilterIndex bitmap, src/storage/filter_index.h:39-124):
@@ -152,6 +153,9 @@ typedef struct orc_filter {
  * compute_df and ds != NULL), :2012-2014 sort by estimated_size, :795-869 Execute, :871-932 ApplyNotFilter.
  * Terms are raw search terms (normalised here with orc_normalize_ascii_lower). filter_threshold is
  * SearchHandler::filter_threshold_ (1000). */
+/* src/server/search_pipeline.cpp:80-136 */
+int orc_has_uncovered_hybrid_fragment(const uint8_t* term, size_t len, int ngram_size, int kanji_ngram_size,
+                                      int cross_boundary);
 int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* term_bytes, const uint32_t* term_off,
                 size_t n_terms, const uint8_t* not_bytes, const uint32_t* not_off, size_t n_not,
                 const orc_filter* filters, size_t n_filters, int ngram_size, int kanji_ngram_size, int cross_boundary,

@@ -90,7 +90,8 @@ class _PipelineResult(C.Structure):
     _fields_ = [("results", C.POINTER(C.c_uint32)), ("n_results", C.c_size_t), ("total_candidates", C.c_size_t),
                 ("after_intersection", C.c_size_t), ("after_not", C.c_size_t), ("after_filters", C.c_size_t),
                 ("empty_term_detected", C.c_int), ("n_terms", C.c_size_t), ("term_order", C.c_uint32 * 64),
-                ("term_df", C.c_uint64 * 64), ("term_estimated_size", C.c_uint64 * 64)]
+                ("term_df", C.c_uint64 * 64), ("term_estimated_size", C.c_uint64 * 64),
+                ("exact_text_applied", C.c_int)]
 
 
 class _Filter(C.Structure):
@@ -314,9 +315,16 @@ def execute(index, store, terms, not_terms=(), filters=(), filter_threshold=1000
         "term_order": [int(pr.term_order[i]) for i in range(pr.n_terms)],
         "term_df": [int(pr.term_df[i]) for i in range(pr.n_terms)],
         "term_estimated_size": [int(pr.term_estimated_size[i]) for i in range(pr.n_terms)],
+        "exact_text_applied": bool(pr.exact_text_applied),
     }
     lib().orc_pipeline_result_free(C.byref(pr))
     return out
+
+
+def has_uncovered_hybrid_fragment(term, ngram_size, kanji_ngram_size, cross_boundary):
+    """search_pipeline.cpp:80-136 on a NORMALIZED term."""
+    t = _b(term)
+    return bool(lib().orc_has_uncovered_hybrid_fragment(t, len(t), ngram_size, kanji_ngram_size, int(cross_boundary)))
 
 
 def search_scored(index, store, terms, total_docs, avg_doc_length, k1=1.2, b=0.75, descending=True, limit=10,

@@ -370,3 +370,49 @@ def test_sort_by_score_long_arrays():
         assert got.tolist() == want.tolist(), (desc, limit, offset)
     with pytest.raises(mg._capi.MgxError):
         idx.sort_by_score(docs, scores, True, 0, 0)
+
+
+# ---- exact-text post-filter (PostFilterByText) ------------------------------------------------------------------------
+
+def test_pipeline_execute_vectors_on_device():
+    # every Execute vector of tests/server/search_pipeline_test.cpp on the device, among them
+    # MixedScriptBoundaryFragmentRequiresExactTextMatch (:1492-1512): "京タ" must not match "京都"
+    for v in G.load("pipeline.json")["execute"]:
+        ic, qp = v["index"], v["query_params"]
+        # the device index is built with the index-side settings; the query side uses the query parameters
+        p = Pair(docs=[(d, t) for d, t in v["docs"]], ngram=ic["ngram"], kanji=ic["kanji"], cross=True)
+        p.dev.kanji_ngram_size, p.dev.cross_boundary = qp["kanji"], qp["cross_boundary"]
+        filters = [(p.add_filter(f["docs"]), f["negate"]) for f in v["filters"]]
+        for desc in (False, True):
+            q = Query(v["terms"], v["not_terms"], filters, limit=0, descending=desc)
+            g = p.dev.search_batch([q])[0]
+            want = v["expect_results"][::-1] if desc else v["expect_results"]
+            if g.empty_term_detected:
+                assert want == [], v["id"]
+                continue
+            assert g.docs.tolist() == want, (v["id"], g.docs.tolist())
+            for k, w in v.get("expect_funnel", {}).items():
+                assert getattr(g, k) == w, (v["id"], k)
+
+
+def test_exact_text_filter_all_modes(score_kernel):
+    # hybrid index (bigrams, kanji unigrams, no cross-boundary n-grams): a mixed-script term with an uncovered code
+    # point is filtered by exact text in docid pages (count + page pass), full results and SORT _score alike
+    rng = np.random.default_rng(41)
+    kana, kanji = "タワーカナ", "京都東大阪"
+    docs = []
+    for i in range(1, 30_001):
+        body = "".join(rng.choice(list(kanji + kana), size=int(rng.integers(2, 9))))
+        docs.append((i, body + (" 京タワー" if i % 97 == 0 else "") + (" 京都" if i % 5 == 0 else "")))
+    p = Pair(docs=docs, ngram=2, kanji=1, cross=False)
+    qs = [Query(["京タ"], limit=10, descending=True), Query(["京タ"], limit=0), Query(["京タ", "都"], limit=50),
+          Query(["京タ"], sort_score=True, limit=10), Query(["京タ", "ワー"], sort_score=True, limit=5, descending=False)]
+    got = p.check(qs)
+    assert all(g.total > 0 for g in got[:2])
+    # the caller's verify_text decision: n-gram false positives ("ab" and "bc" present, "abc" absent) are dropped
+    p2 = Pair(docs=[(1, "abc"), (2, "ab bc"), (3, "xabcx bc"), (4, "bcab")])
+    g = p2.dev.search_batch([Query(["abc"], limit=0, descending=False),
+                             Query(["abc"], limit=0, descending=False, verify_text=True),
+                             Query(["abc", "bc"], limit=10, verify_text=True)])
+    assert g[0].docs.tolist() == [1, 2, 3, 4] and g[1].docs.tolist() == [1, 3] and g[1].after_filters == 4
+    assert g[2].docs.tolist() == [3, 1] and g[2].total == 2

@@ -125,8 +125,22 @@ def test_execute_full_pipeline_fixture():
         r = O.execute(idx, store, v["terms"], v["not_terms"], filters, ngram_size=qp["ngram"],
                       kanji_ngram_size=qp["kanji"], cross_boundary=qp["cross_boundary"])
         assert r["results"].tolist() == v["expect_results"], v["id"]
+        assert r["exact_text_applied"] == v.get("expect_exact_text", False), v["id"]
         for k, want in v.get("expect_funnel", {}).items():
             assert r[k] == want, (v["id"], k)
+
+
+def test_uncovered_hybrid_fragment_rule():
+    # src/server/search_pipeline.cpp:80-136: only mixed-script terms with a code point outside every query n-gram
+    f = O.has_uncovered_hybrid_fragment
+    assert f("京タ", 2, 1, False)            # 京 is a unigram; タ is the last code point and cannot start a bigram
+    assert f("京タ", 2, 1, True)             # ... whatever the cross-boundary setting
+    assert f("タ京", 2, 1, False)            # the bigram タ京 crosses the script boundary: not generated
+    assert not f("タ京", 2, 1, True)         # generated: both code points covered
+    assert not f("京都", 2, 1, False)        # one script only
+    assert not f("京タワ", 2, 1, False)      # タワ covers the kana
+    assert not f("京タ", 2, 0, False)        # no hybrid mode
+    assert not f("a", 2, 1, False)
 
 
 def test_ngram_rules():
