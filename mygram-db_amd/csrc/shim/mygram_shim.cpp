@@ -77,6 +77,35 @@ bool IsCjkIdeograph(uint32_t c) {
          (c >= 0x2A700 && c <= 0x2B73F) || (c >= 0x2B740 && c <= 0x2B81F) || (c >= 0xF900 && c <= 0xFAFF);
 }
 
+// src/server/search_pipeline.cpp:70-78 (knows one more extension block than the string_utils predicate above) and
+// :80-136 HasUncoveredHybridFragment: a mixed-script term with a code point that no query n-gram covers
+bool IsCjkIdeographPipeline(uint32_t c) { return IsCjkIdeograph(c) || (c >= 0x2B820 && c <= 0x2CEAF); }
+
+bool HasUncoveredHybridFragment(std::string_view normalized, int ngram_size, int kanji_ngram_size, bool cross) {
+  if (normalized.empty() || kanji_ngram_size <= 0) return false;
+  const int ascii_n = ngram_size > 0 ? ngram_size : 2;
+  const CodePoints cps = Decode(normalized);
+  const size_t n = cps.cp.size();
+  if (n < 2) return false;
+  bool has_cjk = false, has_other = false;
+  for (uint32_t c : cps.cp) (IsCjkIdeographPipeline(c) ? has_cjk : has_other) = true;
+  if (!has_cjk || !has_other) return false;
+  std::vector<bool> covered(n, false);
+  for (size_t i = 0; i < n; ++i) {
+    const bool start_is_cjk = IsCjkIdeographPipeline(cps.cp[i]);
+    const int w = start_is_cjk ? kanji_ngram_size : ascii_n;
+    if (w <= 0 || i + static_cast<size_t>(w) > n) continue;
+    bool crossed = false;
+    if (!cross)
+      for (int j = 1; j < w; ++j) crossed = crossed || IsCjkIdeographPipeline(cps.cp[i + j]) != start_is_cjk;
+    if (crossed) continue;
+    for (int j = 0; j < w; ++j) covered[i + j] = true;
+  }
+  for (bool c : covered)
+    if (!c) return true;
+  return false;
+}
+
 // bytes of code points [a, b): contiguous in the source when no invalid byte sits between them; re-assembled from the
 // decoded spans otherwise (CodepointsToUtf8 :241-272 re-encodes, which is the same bytes for valid input)
 std::string Window(std::string_view text, const CodePoints& cps, size_t a, size_t b) {
@@ -640,17 +669,20 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
     filter_store.emplace_back();
     auto& ids = id_store.back();
     ids.reserve(q.terms.size() + q.not_terms.size());
+    // exact-text post-filter: the caller's verify_text decision, or a mixed-script term with an uncovered fragment
+    // (search_pipeline.cpp:856-866)
+    bool exact = q.verify_text;
+    for (const auto& ti : tis)
+      exact = exact || HasUncoveredHybridFragment(ti.normalized, index.GetNgramSize(), im->query_kanji,
+                                                  index.GetCrossBoundaryNgrams());
     for (const auto& ti : tis) {
       ids.push_back(ti.gram_ids);
       mgx_term mt{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0};
-      if (q.sort_by_score) {
-        if (ti.is_gram) {
-          mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
-        } else {
-          text_store.push_back(ti.normalized);
-          mt.text = reinterpret_cast<const uint8_t*>(text_store.back().data());
-          mt.text_len = static_cast<uint32_t>(text_store.back().size());
-        }
+      if (q.sort_by_score && ti.is_gram) mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
+      if (exact || (q.sort_by_score && !ti.is_gram)) {
+        text_store.push_back(ti.normalized);
+        mt.text = reinterpret_cast<const uint8_t*>(text_store.back().data());
+        mt.text_len = static_cast<uint32_t>(text_store.back().size());
       }
       term_store.back().push_back(mt);
     }
@@ -678,6 +710,7 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
     m.b = q.bm25.b;
     m.total_docs = total_docs;
     m.avg_doc_length = avgdl;
+    m.exact_text = exact ? 1u : 0u;
     mq.push_back(m);
     device_slot.push_back(qi);
   }

@@ -215,6 +215,8 @@ struct BatchQuery {
   std::vector<std::string> not_terms;
   std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
   bool sort_by_score = false;          // SORT _score
+  bool verify_text = false;            // the caller's ShouldApplyVerifyText(memory.verify_text, terms) decision
+                                       // (search_pipeline.cpp:42-66); mixed-script fragments force it (:858-866)
   query::SortOrder order = query::SortOrder::DESC;
   uint32_t limit = 100;                // api.default_limit (src/config/config.h:61)
   uint32_t offset = 0;

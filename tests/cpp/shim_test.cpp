@@ -250,6 +250,32 @@ int main() {
       std::printf("ExecuteBatch(ast) error: %s\n", r.error().message().c_str());
     }
   }
+  {  // tests/server/search_pipeline_test.cpp:1492-1512 MixedScriptBoundaryFragmentRequiresExactTextMatch, and the
+     // caller-driven verify_text filter
+    using namespace mygramdb::search_pipeline;
+    Index index(2, 1, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning techniques");
+    index.AddDocument(3, "old article about cats");
+    index.AddDocument(4, "\xe4\xba\xac\xe9\x83\xbd");                              // 京都
+    index.AddDocument(5, "\xe4\xba\xac\xe3\x82\xbf\xe3\x83\xaf\xe3\x83\xbc");  // 京タワー
+    index.AddDocument(6, "lea ear arn rni nin ing");
+    std::vector<BatchQuery> qs(3);
+    qs[0].terms = {"\xe4\xba\xac\xe3\x82\xbf"};  // 京タ
+    qs[1].terms = {"learning"};
+    qs[2].terms = {"learning"};
+    qs[2].verify_text = true;
+    for (auto& q : qs) q.order = SortOrder::ASC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      EXPECT((*r)[0].results == (V{5}));
+      EXPECT((*r)[1].results == (V{1, 2, 6}));
+      EXPECT((*r)[2].results == (V{1, 2}) && (*r)[2].total == 2 && (*r)[2].after_filters == 3);
+    } else {
+      std::printf("ExecuteBatch(exact) error: %s\n", r.error().message().c_str());
+    }
+  }
   std::printf("shim_test: %d checks, %d failed\n", g_checked, g_failed);
   return g_failed == 0 ? 0 : 1;
 }
