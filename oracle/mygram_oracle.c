@@ -1072,7 +1072,7 @@ void orc_pipeline_result_free(orc_pipeline_result* r) {
 int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* tb, const uint32_t* toff, size_t n_terms,
                 const uint8_t* nb, const uint32_t* noff, size_t n_not, const orc_filter* filters, size_t n_filters,
                 int ngram_size, int kanji_ngram_size, int cross_boundary, size_t filter_threshold, int compute_df,
-                orc_pipeline_result* out) {
+                int verify_text, orc_pipeline_result* out) {
   memset(out, 0, sizeof(*out));
   if (n_terms > 64) return 11;
   term_info* tis = (term_info*)calloc(n_terms ? n_terms : 1, sizeof(term_info));
@@ -1170,11 +1170,12 @@ int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* tb,
     results = r2;
   }
   out->after_filters = results.n;
-  /* ApplyVerifyTextFilter :856-857 is a no-op with memory.verify_text="off" (the default, src/config/config.h:317-330).
+  /* ApplyVerifyTextFilter :856-857 (:1248-1266) filters by exact text when memory.verify_text says so ("off" is the
+   * default, src/config/config.h:317-330).
    * :858-866: a mixed-script term with a code point no query n-gram covers makes the n-gram AND too weak, so the
    * results are filtered by the exact text of ALL terms (PostFilterByText :1239-1246). */
   {
-    int exact = 0;
+    int exact = verify_text != 0; /* the caller's ShouldApplyVerifyText(memory.verify_text, terms) :42-66 */
     for (size_t i = 0; i < n_terms; ++i)
       exact = exact || orc_has_uncovered_hybrid_fragment(tis[i].normalized, tis[i].normalized_len, ngram_size,
                                                          kanji_ngram_size, cross_boundary);
@@ -1201,6 +1202,24 @@ done:
   return 0;
 }
 
+/* PostFilterByText, src/server/search_pipeline.cpp:1239-1246: candidates whose stored text contains every
+ * (already normalized) term; order kept. */
+uint32_t* orc_post_filter_by_text(const orc_docstore* ds, const uint32_t* cand, size_t nc, const uint8_t* tb,
+                                  const uint32_t* toff, size_t n_terms, size_t* out_n) {
+  uint32_t* out = (uint32_t*)malloc((nc ? nc : 1) * sizeof(uint32_t));
+  size_t w = 0;
+  for (size_t c = 0; c < nc; ++c) {
+    size_t tl;
+    const uint8_t* tx = docstore_text(ds, cand[c], &tl);
+    int all = tx != NULL;
+    for (size_t i = 0; all && i < n_terms; ++i)
+      all = bytes_find(tx, tl, tb + toff[i], toff[i + 1] - toff[i], 0) != (size_t)-1;
+    if (all) out[w++] = cand[c];
+  }
+  *out_n = w;
+  return out;
+}
+
 /* src/server/handlers/search_handler.cpp:405-470 on top of ExecuteFullPipeline's regular branch
  * (src/server/search_pipeline.cpp:2002-2030). */
 int orc_search_scored(const orc_index* idx, const orc_docstore* ds, const uint8_t* tb, const uint32_t* toff,
@@ -1209,7 +1228,7 @@ int orc_search_scored(const orc_index* idx, const orc_docstore* ds, const uint8_
                       uint32_t offset, uint32_t* top_docs, double* top_scores, size_t* n_top, uint64_t* total) {
   orc_pipeline_result pr;
   int rc = orc_execute(idx, ds, tb, toff, n_terms, NULL, NULL, 0, NULL, 0, ngram_size, kanji_ngram_size,
-                       cross_boundary, filter_threshold, 1, &pr);
+                       cross_boundary, filter_threshold, 1, 0, &pr);
   if (rc != 0) return rc;
   *total = pr.n_results;
   *n_top = 0;

@@ -152,14 +152,17 @@ typedef struct orc_filter {
 /* src/server/search_pipeline.cpp:569-603 GenerateTermInfos (+ :542-565 PopulateTermDocumentFrequency when
  * compute_df and ds != NULL), :2012-2014 sort by estimated_size, :795-869 Execute, :871-932 ApplyNotFilter.
  * Terms are raw search terms (normalised here with orc_normalize_ascii_lower). filter_threshold is
- * SearchHandler::filter_threshold_ (1000). */
+ * SearchHandler::filter_threshold_ (1000). verify_text = the caller's ShouldApplyVerifyText decision (:42-66). */
 /* src/server/search_pipeline.cpp:80-136 */
 int orc_has_uncovered_hybrid_fragment(const uint8_t* term, size_t len, int ngram_size, int kanji_ngram_size,
                                       int cross_boundary);
 int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* term_bytes, const uint32_t* term_off,
                 size_t n_terms, const uint8_t* not_bytes, const uint32_t* not_off, size_t n_not,
                 const orc_filter* filters, size_t n_filters, int ngram_size, int kanji_ngram_size, int cross_boundary,
-                size_t filter_threshold, int compute_df, orc_pipeline_result* out);
+                size_t filter_threshold, int compute_df, int verify_text, orc_pipeline_result* out);
+/* PostFilterByText, src/server/search_pipeline.cpp:1239-1246 (terms already normalized); caller frees the result. */
+uint32_t* orc_post_filter_by_text(const orc_docstore* ds, const uint32_t* cand, size_t n_cand,
+                                  const uint8_t* term_bytes, const uint32_t* term_off, size_t n_terms, size_t* out_n);
 void orc_pipeline_result_free(orc_pipeline_result* r);
 
 /* The whole SEARCH ... SORT _score DESC LIMIT k path for one query: orc_execute(compute_df=1), then

@@ -71,7 +71,9 @@ def lib():
     L.orc_sort_by_score.argtypes = [u32p, f64p, sz, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(sz)]
     L.orc_execute.restype = C.c_int
     L.orc_execute.argtypes = [C.c_void_p, C.c_void_p, u8p, u32p, sz, u8p, u32p, sz, C.c_void_p, sz, C.c_int, C.c_int,
-                              C.c_int, sz, C.c_int, C.c_void_p]
+                              C.c_int, sz, C.c_int, C.c_int, C.c_void_p]
+    L.orc_post_filter_by_text.restype = C.POINTER(C.c_uint32)
+    L.orc_post_filter_by_text.argtypes = [C.c_void_p, u32p, sz, u8p, u32p, sz, C.POINTER(sz)]
     L.orc_pipeline_result_free.argtypes = [C.c_void_p]
     L.orc_search_scored.restype = C.c_int
     L.orc_search_scored.argtypes = [C.c_void_p, C.c_void_p, u8p, u32p, sz, C.c_int, C.c_int, C.c_int, sz, C.c_uint64,
@@ -287,7 +289,7 @@ def sort_by_score(results, scores, descending=True, limit=0, offset=0):
 
 
 def execute(index, store, terms, not_terms=(), filters=(), filter_threshold=1000, compute_df=False,
-            ngram_size=None, kanji_ngram_size=None, cross_boundary=None):
+            ngram_size=None, kanji_ngram_size=None, cross_boundary=None, verify_text=False):
     """search_pipeline::GenerateTermInfos + sort + Execute. filters = [(sorted docids, negate)]."""
     tb, toff = pack_terms(terms)
     nb, noff = pack_terms(not_terms)
@@ -303,7 +305,7 @@ def execute(index, store, terms, not_terms=(), filters=(), filter_threshold=1000
                            index.ngram_size if ngram_size is None else ngram_size,
                            index.kanji_ngram_size if kanji_ngram_size is None else kanji_ngram_size,
                            int(index.cross_boundary if cross_boundary is None else cross_boundary),
-                           filter_threshold, int(compute_df), C.byref(pr))
+                           filter_threshold, int(compute_df), int(verify_text), C.byref(pr))
     if rc != 0:
         raise ValueError("orc_execute rc=%d" % rc)
     res = np.ctypeslib.as_array(pr.results, shape=(max(pr.n_results, 1),))[: pr.n_results].copy()
@@ -319,6 +321,18 @@ def execute(index, store, terms, not_terms=(), filters=(), filter_threshold=1000
     }
     lib().orc_pipeline_result_free(C.byref(pr))
     return out
+
+
+def post_filter_by_text(store, candidates, normalized_terms):
+    """PostFilterByText, search_pipeline.cpp:1239-1246."""
+    cand = np.ascontiguousarray(candidates, dtype=np.uint32)
+    tb, toff = pack_terms(normalized_terms)
+    n = C.c_size_t()
+    p = lib().orc_post_filter_by_text(store._h, cand.ctypes.data, len(cand),
+                                      tb.ctypes.data, toff.ctypes.data, len(normalized_terms), C.byref(n))
+    out = np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[: n.value].copy()
+    lib().orc_free(p)
+    return out.astype(np.uint32)
 
 
 def has_uncovered_hybrid_fragment(term, ngram_size, kanji_ngram_size, cross_boundary):

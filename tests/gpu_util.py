@@ -88,7 +88,7 @@ class Pair:
             return len(res), page, None, {"empty_term_detected": True}
         r = O.execute(self.oidx, self.ostore, q.terms, q.not_terms, filters, compute_df=q.sort_score,
                       ngram_size=self.dev.ngram_size, kanji_ngram_size=self.dev.kanji_ngram_size,
-                      cross_boundary=self.dev.cross_boundary)
+                      cross_boundary=self.dev.cross_boundary, verify_text=q.verify_text)
         res = r["results"]
         if q.sort_score:
             terms = [mg.engine.normalize_text(q.terms[i]) for i in r["term_order"]]

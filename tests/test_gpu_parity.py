@@ -384,7 +384,8 @@ def test_pipeline_execute_vectors_on_device():
         p.dev.kanji_ngram_size, p.dev.cross_boundary = qp["kanji"], qp["cross_boundary"]
         filters = [(p.add_filter(f["docs"]), f["negate"]) for f in v["filters"]]
         for desc in (False, True):
-            q = Query(v["terms"], v["not_terms"], filters, limit=0, descending=desc)
+            q = Query(v["terms"], v["not_terms"], filters, limit=0, descending=desc,
+                      verify_text=v.get("verify_text", False))
             g = p.dev.search_batch([q])[0]
             want = v["expect_results"][::-1] if desc else v["expect_results"]
             if g.empty_term_detected:

@@ -123,11 +123,20 @@ def test_execute_full_pipeline_fixture():
             store.add(doc_id, text)
         filters = [(f["docs"], f["negate"]) for f in v["filters"]]
         r = O.execute(idx, store, v["terms"], v["not_terms"], filters, ngram_size=qp["ngram"],
-                      kanji_ngram_size=qp["kanji"], cross_boundary=qp["cross_boundary"])
+                      kanji_ngram_size=qp["kanji"], cross_boundary=qp["cross_boundary"],
+                      verify_text=v.get("verify_text", False))
         assert r["results"].tolist() == v["expect_results"], v["id"]
         assert r["exact_text_applied"] == v.get("expect_exact_text", False), v["id"]
         for k, want in v.get("expect_funnel", {}).items():
             assert r[k] == want, (v["id"], k)
+
+
+def test_post_filter_by_text_vectors():
+    for v in G.load("pipeline.json")["post_filter_by_text"]:
+        store = O.DocumentStore()
+        for doc_id, text in v["docs"]:
+            store.add(doc_id, text)
+        assert O.post_filter_by_text(store, v["candidates"], v["terms"]).tolist() == v["expect"], v["id"]
 
 
 def test_uncovered_hybrid_fragment_rule():
