@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -185,6 +186,50 @@ void mgx_columns_destroy(mgx_columns* cols) { mgx::DestroyColumns(reinterpret_ca
 static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   auto idx = std::make_unique<mgx_index>();
   idx->device = d->device;
+  const uint64_t G = d->n_grams;
+  const uint64_t P = G ? d->offsets[G] : 0;
+  const uint64_t n_docs = d->n_docs;
+  if (n_docs == 0 || n_docs > 0xFFFFFFFFull || static_cast<uint64_t>(d->first_doc_id) + n_docs > 0x100000000ull)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_create: n_docs must be in [1, 2^32) and ids fit uint32");
+  // The contract of the descriptor is checked, not assumed: the build kernels turn every doc id into a bit / nibble
+  // address without a bounds guard, so one id outside the owned range (a shard given the wrong first_doc_id) would be
+  // an out-of-bounds device write. One host pass over the postings (threads over gram ranges).
+  {
+    for (uint64_t g = 0; g < G; ++g)
+      if (d->offsets[g + 1] < d->offsets[g])
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: offsets must be non-decreasing");
+    const uint64_t lo_id = d->first_doc_id, hi_id = lo_id + n_docs;  // [lo_id, hi_id)
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned n_thr = P < (1u << 22) ? 1u : hw;
+    std::vector<int> bad(n_thr, 0);
+    auto check = [&](unsigned t) {
+      // thread t takes the grams whose postings start in its share of [0, P)
+      const uint64_t p_lo = P * t / n_thr, p_hi = P * (t + 1) / n_thr;
+      uint64_t g = static_cast<uint64_t>(std::lower_bound(d->offsets, d->offsets + G, p_lo) - d->offsets);
+      for (; g < G && d->offsets[g] < p_hi; ++g) {
+        const uint64_t a = d->offsets[g], b = d->offsets[g + 1];
+        uint64_t prev = 0;
+        for (uint64_t p = a; p < b; ++p) {
+          const uint64_t id = d->docids[p];
+          if (id < lo_id || id >= hi_id) bad[t] = MGX_ERR_OUT_OF_RANGE;
+          else if (p > a && id <= prev) bad[t] = bad[t] ? bad[t] : MGX_ERR_INVALID_ARGUMENT;
+          prev = id;
+        }
+      }
+    };
+    if (n_thr == 1) {
+      check(0);
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(check, t);
+      for (auto& th : pool) th.join();
+    }
+    for (int b : bad) {
+      if (b == MGX_ERR_OUT_OF_RANGE)
+        return mgx::Fail(b, "mgx_index_create: a doc id lies outside [first_doc_id, first_doc_id + n_docs)");
+      if (b) return mgx::Fail(b, "mgx_index_create: doc ids must ascend strictly inside every posting list");
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
@@ -194,12 +239,6 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   MGX_HIP(hipSetDevice(d->device));
   MGX_HIP(hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking));
   MGX_HIP(hipStreamCreateWithFlags(&idx->side_stream, hipStreamNonBlocking));
-
-  const uint64_t G = d->n_grams;
-  const uint64_t P = G ? d->offsets[G] : 0;
-  const uint64_t n_docs = d->n_docs;
-  if (n_docs == 0 || n_docs > 0xFFFFFFFFull || static_cast<uint64_t>(d->first_doc_id) + n_docs > 0x100000000ull)
-    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_create: n_docs must be in [1, 2^32) and ids fit uint32");
   const uint32_t n_tiles = static_cast<uint32_t>((n_docs + mgx::kTileDocs - 1) >> mgx::kTileShift);
   idx->n_grams = G;
   idx->h_offsets.assign(d->offsets, d->offsets + G + 1);
@@ -838,9 +877,12 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     q.mode = s.mode;
     q.limit = s.limit;
     q.offset = s.offset;
-    q.needed = s.offset + s.limit;
+    // (offset + limit fits 32 bits only where it is bounded: score mode enforces needed <= kMaxNeeded; docid pages
+    // carry limit alone — a caller's SearchAnd(terms, UINT32_MAX) must not wrap, nor spin a doubling loop forever)
+    q.needed = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(s.offset) + s.limit, 0xFFFFFFFFull));
     uint32_t cap = 64;
-    while (cap < q.needed) cap <<= 1;
+    if (s.mode == kModeScore)
+      while (cap < q.needed && cap < (1u << 30)) cap <<= 1;
     q.cap = cap;
     q.descending = s.reverse;
     q.stack_depth = s.stack_depth;
@@ -1052,7 +1094,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     d.page_stride = b->doc_page_stride;
   }
   d.bounds = score_mode ? d.counters + static_cast<size_t>(n) * 8 : nullptr;
+#ifdef MGX_ABLATION
   d.debug_skip = std::getenv("MGX_DEBUG_SKIP") ? static_cast<uint32_t>(atoi(std::getenv("MGX_DEBUG_SKIP"))) : 0u;
+#endif
   if (score_mode) {
     uint32_t max_needed = 1, max_limit = 1;
     for (const DevQuery& q : dq) {

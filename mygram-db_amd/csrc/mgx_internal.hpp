@@ -160,7 +160,7 @@ struct DevBatch {
   uint32_t cand_stride;
   const double* tables;  // [n_queries][table_stride] BM25 contribution tables of the wave kernel, built once at prepare
   uint32_t table_stride;
-  uint32_t debug_skip;   // timing ablations only (MGX_DEBUG_SKIP): 1 = no scoring, 2 = no enumeration+scoring, 4 = no parking
+  uint32_t debug_skip;   // -DMGX_ABLATION builds only (MGX_DEBUG_SKIP: 1 = no scoring, 2 = no enumeration + scoring); 0 otherwise
   // bitmap mode
   uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]
   uint32_t* tile_cnt;    // [n_bitmap_queries][n_tiles]

@@ -1,16 +1,19 @@
 // mgx_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the MygramDB query hot path.
 //
 // Kernel families (SURVEY.md §2.2 names in brackets):
-//   build_tile_off_kernel / build_bitmap_kernel  index-side precomputation (skip rows, dense bitmaps)
-//   tile_eval_kernel<kModeScore>   [K1+K2+K3+K5+K6+K7] set algebra over 16384-doc tiles + fused BM25 + top-k
-//   tile_eval_kernel<kModeBitmap>  [K1..K5] same algebra, result bitmaps + per-tile counts to HBM
+//   build_tile_off_kernel / build_bitmap_kernel / build_tfnib_kernel   index-side precomputation
+//   wave_score_kernel              [K1+K2+K5+K6+K7] the dominant kernel of SORT _score batches: 512-thread workgroups of
+//                                  8 autonomous waves, each wave owns whole 16384-doc tiles (4 bitmap words per lane),
+//                                  BM25 from doc-slot tf nibbles + LDS contribution tables, per-wave running top-k
+//   tile_eval_kernel<mode>         [K1..K7] the general 256-thread workgroup kernel: any tile program (stack, bit-sliced
+//                                  threshold counters, list-form scored terms, text-level terms, exact-text filter)
+//   wave_count_kernel / wave_page_kernel   docid-ordered pages of flat programs (count pass, rank scan, page pass)
 //   merge_topk_kernel              [K7/C1 merge] per-query merge of per-workgroup (or per-shard) sorted top-k lists
 //   scan_tiles_kernel / expand_kernel  result bitmaps -> ascending/descending docid pages
 //   retain_kernel                  [K4] Index::FilterByNgrams
-//   score_candidates_kernel        [K6] BM25Scorer::ScoreDocuments over an explicit candidate list
+//   score_candidates*_kernel       [K6] BM25Scorer::ScoreDocuments over an explicit candidate list
 //
-// All of them are HBM/LDS-bound integer work; none uses MFMA. One workgroup = 256 threads = 4 wave64; in the tile
-// kernels every thread owns one 64-bit word of each 16384-bit tile bitmap.
+// All of them are HBM/LDS/issue-bound integer and fp64 work; none uses MFMA (nothing here is a dense contraction).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -19,6 +22,14 @@
 #include "mgx_launch.hpp"
 
 namespace mgx {
+
+// Timing ablations (skip scoring / enumeration) exist only in -DMGX_ABLATION builds; the product library has no such
+// switch in its hot loop.
+#ifdef MGX_ABLATION
+#define MGX_ABLATE(bt, bit) (((bt).debug_skip & (bit)) != 0)
+#else
+#define MGX_ABLATE(bt, bit) false
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // small device helpers
@@ -1089,7 +1100,7 @@ __device__ __forceinline__ void wave_score_body(const DevIndex ix, const DevBatc
       }
     }
     cnt_res += __popcll(acc[0]) + __popcll(acc[1]) + __popcll(acc[2]) + __popcll(acc[3]);
-    if (bt.debug_skip & 2u) continue;
+    if (MGX_ABLATE(bt, 2u)) continue;
 
     // Rounds of at most kWaveMatchBuf matches: B consumes bits of acc (a lane resumes where it stopped), C scores.
     for (;;) {
@@ -1113,7 +1124,7 @@ __device__ __forceinline__ void wave_score_body(const DevIndex ix, const DevBatc
       wave_lds_sync();
       const uint32_t nm = min(kWaveMatchBuf, n_left);
       // ---- C. one match per lane, kScoreUnroll in flight -------------------------------------------------------------
-      for (uint32_t j0 = 0; j0 < nm && !(bt.debug_skip & 1u); j0 += 64 * kScoreUnroll) {
+      for (uint32_t j0 = 0; j0 < nm && !MGX_ABLATE(bt, 1u); j0 += 64 * kScoreUnroll) {
         bool valid[kScoreUnroll];
         uint32_t slot[kScoreUnroll], dli[kScoreUnroll];
         uint32_t tfv[kScoreUnroll][kWaveScoreSlots];

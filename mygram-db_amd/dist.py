@@ -78,7 +78,6 @@ class ShardedTable:
         self.index.total_docs = n
         self.index.avg_doc_length = (total_len / n) if n else 0.0
         self.keys, self.global_sizes = keys, gsizes
-        self._blobs = {}
         # rehearsal switch: run the export / all-gather / merge path even with a single rank
         self.force_exchange = bool(dist.is_available() and dist.is_initialized() and
                                    __import__("os").environ.get("MGX_FORCE_EXCHANGE"))
@@ -91,8 +90,9 @@ class ShardedTable:
         [keys | totals] as u64 followed by [docs | counts] as u32 (mgx_batch_export_topk), padded to a multiple of 8
         bytes, so ONE all-gather moves both. SORT _score batches keep their result in that layout inside the library
         (mgx_batch_export_buffer): the all-gather reads it in place."""
-        key = id(batch)
-        if key not in self._blobs:
+        # The buffers live ON the batch object: the zero-copy views alias memory the batch owns (d_export), so they must
+        # die with it. (Keying a table-wide cache on id(batch) handed a recycled id the previous batch's freed pointers.)
+        if getattr(batch, "_exchange", None) is None:
             dev = torch.device("cuda", self.index.device_index.device)
             ptr, nbytes, off32 = batch.export_buffer()
             if ptr:
@@ -105,20 +105,20 @@ class ShardedTable:
                 n = batch.n * stride + batch.n          # elements of each blob
                 off32, nbytes = 8 * n, (12 * n + 7) // 8 * 8
                 mine, copy = torch.empty(nbytes, dtype=torch.uint8, device=dev), True
-            self._blobs[key] = (off32, nbytes, mine, copy, torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
-        return self._blobs[key]
+            batch._exchange = (off32, nbytes, mine, copy,
+                               torch.empty(nbytes * self.world, dtype=torch.uint8, device=dev))
+        return batch._exchange
 
     def _df_tensor(self, batch, ptr, n):
         """The batch's device df array (u64; counts stay far below 2^63) as an int64 torch tensor, without a copy."""
-        key = ("df", id(batch))
-        if key not in self._blobs:
+        if getattr(batch, "_df_view", None) is None:
             dev = self.index.device_index.device
 
             class _Arr:  # __cuda_array_interface__ view of library-owned memory
                 __cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2}
 
-            self._blobs[key] = torch.as_tensor(_Arr(), device=torch.device("cuda", dev))
-        return self._blobs[key]
+            batch._df_view = torch.as_tensor(_Arr(), device=torch.device("cuda", dev))
+        return batch._df_view
 
     def run(self, batch):
         """Executes `batch` on this shard, exchanges per-shard top-k and merges: afterwards batch.fetch*() returns

@@ -140,6 +140,19 @@ def main():
             assert g.total == total, (q.terms, g.total, total)
             assert g.docs.tolist() == docs.tolist(), q.terms
             assert np.array_equal(g.scores, scores), q.terms
+        # fresh batches of different shapes, each dropped before the next is prepared (a serving loop): the exchange
+        # buffers belong to the batch, so a recycled Python id / device address must never leak a stale blob or layout
+        for rnd in range(6):
+            sub = qs[rnd::6][: 5 + 3 * rnd]
+            lim = [10, 3, 25, 1, 50, 7][rnd]
+            sub = [mg.engine.Query(q.terms, sort_score=True, limit=lim, offset=rnd % 3) for q in sub]
+            fb = table.prepare(sub)
+            table.run(fb)
+            for q, g in zip(sub, fb.fetch()):
+                total, docs, scores = O.search_scored(oidx, ostore, q.terms, n, avg, limit=q.limit, offset=q.offset)
+                assert g.total == total and g.docs.tolist() == docs.tolist() and np.array_equal(g.scores, scores), \
+                    (rnd, q.terms)
+            del fb
         # docid-ordered pages across the shards (the reference's default order): totals add up, pages merge by doc id
         pq = []
         for i in range(10):

@@ -110,3 +110,31 @@ def test_query_ngram_rules_match_oracle():
 def test_compute_idf_matches_oracle():
     for n, df in [(100, 10), (100, 0), (0, 10), (10, 20), (10_000_000, 3_141_592)]:
         assert mg.compute_idf(n, df) == O.compute_idf(n, df)
+
+
+def _raw_index_desc(first_doc_id, n_docs, offsets, docids):
+    off = np.asarray(offsets, dtype=np.uint64)
+    ids = np.asarray(docids, dtype=np.uint32)
+    tf = np.ones(len(ids), dtype=np.uint8)
+    dl = np.ones(n_docs, dtype=np.uint32)
+    d = mg._capi.IndexDesc(C.sizeof(mg._capi.IndexDesc), mg._capi.ABI_VERSION, 0, 0, first_doc_id, n_docs,
+                           len(off) - 1, off.ctypes.data, ids.ctypes.data, tf.ctypes.data, dl.ctypes.data, 0.0)
+    return d, (off, ids, tf, dl)
+
+
+@pytest.mark.parametrize("first,n_docs,offsets,docids,code,what", [
+    (10, 5, [0, 2, 3], [10, 15, 11], 3, "outside"),       # 15 is one past the owned range [10, 15)
+    (10, 5, [0, 2, 3], [9, 12, 11], 3, "outside"),        # below first_doc_id (a shard given the wrong base)
+    (1, 8, [0, 3, 4], [2, 2, 5, 1], 2, "ascend"),         # duplicate inside a list
+    (1, 8, [0, 3, 4], [3, 2, 5, 1], 2, "ascend"),         # descending inside a list
+    (1, 8, [0, 3, 2], [1, 2, 3], 2, "non-decreasing"),    # offsets go backwards
+])
+def test_index_create_checks_its_contract_before_any_device_write(first, n_docs, offsets, docids, code, what):
+    """The build kernels address bitmap bits / tf nibbles by doc id without a bounds guard: the descriptor's contract
+    (ids inside the owned range, strictly ascending per gram, monotonic offsets) is validated on the host first — and
+    before the device is even looked for, so this runs on the CPU box."""
+    d, keep = _raw_index_desc(first, n_docs, offsets, docids)
+    h = C.c_void_p()
+    rc = mg._capi.load().mgx_index_create(C.byref(d), C.byref(h))
+    assert rc == code and h.value is None
+    assert what in mg._capi.load().mgx_last_error().decode()
