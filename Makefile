@@ -26,7 +26,13 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -s -C oracle
 
+# timing-ablation build of the library (tools only: MGX_DEBUG_SKIP then skips kernel phases; never shipped as the product)
+ablation:
+	$(HIPCC) $(HIPFLAGS) -DMGX_ABLATION -c $(CSRC)/mgx_kernels.hip -o /tmp/mgx_kernels_abl.o
+	$(HIPCC) $(HIPFLAGS) -DMGX_ABLATION -x hip -c $(CSRC)/mgx_api.cpp -o /tmp/mgx_api_abl.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o mygram-db_amd/libmygram_gpu_ablation.so /tmp/mgx_kernels_abl.o /tmp/mgx_api_abl.o $(CSRC)/mgx_columns.o $(CSRC)/mgx_tools.o -pthread
+
 clean:
 	rm -f $(OBJS) $(LIB)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean ablation

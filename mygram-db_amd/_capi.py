@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmygram_gpu.so")
+# MGX_LIBRARY: tools only (e.g. the -DMGX_ABLATION build of `make ablation`); the product is libmygram_gpu.so
+LIB_PATH = os.environ.get("MGX_LIBRARY") or os.path.join(_HERE, "libmygram_gpu.so")
 
 ABI_VERSION = 1
 GRAM_ABSENT = 0xFFFFFFFF

@@ -120,7 +120,72 @@ struct mgx_index {
   bool can_score = false;
   uint64_t words_per_row = 0;  // n_tiles * 256
   uint64_t filter_row_stride = 0;  // words; words_per_row + padding
+  // BM25 contribution tables of the fast scoring path: idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) for tf 0..14 and every
+  // doc length below table_dl, one table per (dense gram, idf, k1, b, avgdl). These are table constants (idf comes from
+  // the gram's posting count and N), so they are built once on first use and a query carries their addresses.
+  struct TableKey {
+    uint32_t row;
+    uint64_t idf, k1, b, avg;
+    bool operator==(const TableKey& o) const { return row == o.row && idf == o.idf && k1 == o.k1 && b == o.b && avg == o.avg; }
+  };
+  struct TableKeyHash {
+    size_t operator()(const TableKey& k) const {
+      uint64_t h = k.row * 0x9E3779B97F4A7C15ull;
+      for (uint64_t v : {k.idf, k.k1, k.b, k.avg}) h = (h ^ v) * 0xFF51AFD7ED558CCDull + (h >> 29);
+      return static_cast<size_t>(h);
+    }
+  };
+  std::mutex table_mu;
+  std::unordered_map<TableKey, uint32_t, TableKeyHash> table_slot;
+  DevBuf d_table_pool;
+  uint32_t table_cap = 0, table_used = 0, table_dl = 0;
+  size_t table_doubles() const { return static_cast<size_t>(mgx::kFastPoolTf + 1) * table_dl; }
 };
+
+namespace mgx {
+static inline uint64_t Bits(double d) {
+  uint64_t u;
+  std::memcpy(&u, &d, 8);
+  return u;
+}
+
+// Device address of the contribution table of (dense gram row, idf, k1, b, avgdl); built and uploaded on first use.
+// 0 when the pool is exhausted (the query then runs on the general path).
+static uint64_t GetContributionTable(mgx_index* idx, uint32_t bm_row, double idf, double k1, double b, double avgdl) {
+  if (idx->table_cap == 0) return 0;
+  const mgx_index::TableKey key{bm_row, Bits(idf), Bits(k1), Bits(b), Bits(avgdl)};
+  std::lock_guard<std::mutex> lock(idx->table_mu);
+  const auto hit = idx->table_slot.find(key);
+  const size_t nd = idx->table_doubles();
+  if (hit != idx->table_slot.end())
+    return reinterpret_cast<uint64_t>(idx->d_table_pool.as<double>() + static_cast<size_t>(hit->second) * nd);
+  if (idx->table_used == idx->table_cap) return 0;
+  // bm25_scorer.cpp:80-84 operation by operation (this file is compiled with -ffp-contract=off), so an entry is
+  // bit-identical to the direct evaluation; row 0 (a term the doc lacks) is +0.0
+  std::vector<double> t(nd, 0.0);
+  const double one_minus_b = 1.0 - b, k1_plus_1 = k1 + 1.0, avg = std::max(avgdl, 1.0);
+  for (uint32_t tfi = 1; tfi <= kFastPoolTf; ++tfi) {
+    for (uint32_t dli = 0; dli < idx->table_dl; ++dli) {
+      const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
+      const double length_norm = one_minus_b + b * dl / avg;
+      const double numerator = tf * k1_plus_1;
+      const double denominator = tf + k1 * length_norm;
+      t[static_cast<size_t>(tfi) * idx->table_dl + dli] = idf * numerator / denominator;
+    }
+  }
+  const uint32_t slot = idx->table_used;
+  double* dst = idx->d_table_pool.as<double>() + static_cast<size_t>(slot) * nd;
+  if (hipSetDevice(idx->device) != hipSuccess ||
+      hipMemcpy(dst, t.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  idx->table_used++;
+  idx->table_slot.emplace(key, slot);
+  return reinterpret_cast<uint64_t>(dst);
+}
+}  // namespace mgx
+
 
 extern "C" {
 
@@ -310,6 +375,11 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
       idx->dev.nib_row_stride = stride;
     }
   }
+  if (idx->can_score) {  // (sparse scored grams get tables too: keyed by gram id, see UploadGroup)
+    idx->table_dl = mgx::FastTableDl(max_doc_len);
+    idx->table_cap = static_cast<uint32_t>(std::min<uint64_t>(2 * bm_grams.size() + 4096, 1u << 20));
+    MGX_HIP(idx->d_table_pool.Alloc(static_cast<size_t>(idx->table_cap) * idx->table_doubles() * sizeof(double)));
+  }
   if (idx->can_score) {
     std::vector<uint8_t> dl8(n_docs);
     for (uint64_t i = 0; i < n_docs; ++i) dl8[i] = static_cast<uint8_t>(std::min<uint32_t>(d->doc_len[i], 255u));
@@ -377,7 +447,7 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
          idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes +
-         idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes;
+         idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes + idx->d_table_pool.bytes;
   return MGX_OK;
 }
 
@@ -465,6 +535,8 @@ struct QuerySpec {
   double k1 = 1.2, b = 0.75, avgdl = 0.0;
   uint64_t list_postings = 0;  // sum of |L| over gram operands (algorithmic bytes = 4x)
   bool wave_ok = true;         // flat program + every scored term in its own register slot
+  bool flat = true;            // LOAD/AND/OR/ANDNOT/COUNT only
+  bool fast_score_ok = true;   // every scored term reads a dense gram's tf column (no text-level / absent terms)
   double est_density = 0.0;    // estimated fraction of docs that match (work per tile grows with it)
   // text-level scored terms (mgx_term.text): pattern bytes and the grams whose AND is the term's candidate set
   struct TextTerm {
@@ -521,7 +593,7 @@ struct Compiler {
       }
     }
     q->prog.push_back(MakeInstr(op, arg));
-    if (op != kOpLoad && op != kOpAnd && op != kOpOr && op != kOpAndNot && op != kOpCount) q->wave_ok = false;
+    if (op != kOpLoad && op != kOpAnd && op != kOpOr && op != kOpAndNot && op != kOpCount) q->wave_ok = q->flat = false;
     if (op == kOpPush) {
       ++sp;
       q->stack_depth = std::max(q->stack_depth, sp);
@@ -737,7 +809,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
         out->text_terms.push_back(std::move(tt));
         DevScoreTerm st{};
         st.leaf = kNoLeaf;
-        out->wave_ok = false;  // the wave kernel scores from tf columns only
+        out->wave_ok = out->fast_score_ok = false;  // the wave kernels score from tf columns only
         out->score.push_back(st);
         continue;
       }
@@ -749,7 +821,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       st.idf = t.idf;
       // the same gram scored twice (a repeated term) keeps the first slot; the block kernel handles that shape
       if (t.gram_ids[0] == MGX_GRAM_ABSENT)
-        out->wave_ok = false;  // an empty operand: never a member, contributes nothing
+        out->wave_ok = out->fast_score_ok = false;  // an empty operand: never a member, contributes nothing
       else if (out->leaves[st.leaf].score_slot == kNoSlot && i < static_cast<uint32_t>(kWaveScoreSlots))
         out->leaves[st.leaf].score_slot = i;
       else
@@ -793,6 +865,10 @@ struct mgx_batch {
     mgx::WavePlan wplan_lists{};
     mgx::DevBatch dev_wave_lists{};
     DevBuf d_items_wave_lists;
+    // score mode, fast path (and_score_kernel<T>): resolved query descriptors and one item list per number of scored terms
+    mgx::FastPlan fplan{};
+    mgx::DevBatch dev_fast[mgx::kFastMaxScore]{};
+    DevBuf d_fast_queries, d_items_fast[mgx::kFastMaxScore];
     // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
     mgx::DevBatch dev_page_wave{}, dev_page_block{};
     DevBuf d_pq_wave, d_pq_block;
@@ -913,12 +989,85 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     if (!df_mode) b->list_bytes += 4 * s.list_postings;
   }
   g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode || df_mode);
-  std::vector<uint8_t> on_wave(n, 0);
+  std::vector<uint8_t> on_wave(n, 0);  // 0 general kernel, 1 wave kernel, 2 wave kernel with list operands, 3 fast path
+  std::vector<DevFastQuery> fastq;
+  std::vector<uint64_t> wave_tables;
   if (score_mode) {
+    // ---- fast path: flat programs over bitmap-form operands, 1..4 scored terms that are dense grams --------------
+    // and_score_kernel is opt-in (MGX_FAST_PATH=1): measured slower than wave_score_kernel on the benchmark batch
+    // (both are bound by the gather line traffic, and this one holds fewer waves per CU)
+    const bool allow_fast = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr && std::getenv("MGX_FAST_PATH") != nullptr &&
+                            atoi(std::getenv("MGX_FAST_PATH")) != 0;
+    mgx_index* idx = b->idx;
+    uint32_t fsc = 0, fcap = 64;
+    for (uint32_t i = 0; allow_fast && i < n; ++i) {
+      const QuerySpec& s = specs[g.qids[i]];
+      if (!s.flat || !s.fast_score_ok || s.score.empty() || s.score.size() > static_cast<size_t>(kFastMaxScore)) continue;
+      DevFastQuery f{};
+      bool ok = true;
+      for (uint32_t ins : s.prog) {
+        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+        if (op == kOpCount) {
+          if (f.n_ops == 0) { ok = false; break; }
+          f.ops[f.n_ops - 1].code |= arg << 8;
+          continue;
+        }
+        const DevLeaf& lf = s.leaves[arg];
+        if (f.n_ops == static_cast<uint32_t>(kFastMaxOps) || (op == kOpLoad) != (f.n_ops == 0)) { ok = false; break; }
+        FastOp o{};
+        uint64_t stride = 0;
+        if (lf.kind == kLeafGramBitmap) {
+          o.base = reinterpret_cast<uint64_t>(idx->dev.gram_bitmaps + static_cast<uint64_t>(lf.b) * idx->dev.gb_row_stride);
+          stride = idx->dev.gb_tile_stride * 8;
+        } else if (lf.kind == kLeafFilterBitmap) {  // rows are appended at run time and may move: relative to the base
+          o.base = static_cast<uint64_t>(lf.b) * idx->dev.fb_row_stride * 8;
+          stride = idx->dev.fb_tile_stride * 8;
+          o.code |= 16u;
+        } else {
+          ok = false;
+          break;
+        }
+        if (stride > 0xFFFFFFFFull) { ok = false; break; }
+        o.tile_stride = static_cast<uint32_t>(stride);
+        o.code |= (op == kOpLoad || op == kOpOr) ? kFastOr : op == kOpAnd ? kFastAnd : kFastAndNot;
+        f.ops[f.n_ops++] = o;
+      }
+      if (!ok || f.n_ops == 0) continue;
+      for (size_t t = 0; ok && t < s.score.size(); ++t) {
+        const DevLeaf& lf = s.leaves[s.score[t].leaf];
+        if (lf.kind != kLeafGramBitmap) { ok = false; break; }
+        FastScore& fs = f.score[t];
+        fs.nib = reinterpret_cast<uint64_t>(idx->dev.tfnib + static_cast<uint64_t>(lf.b) * idx->dev.nib_row_stride);
+        fs.table = GetContributionTable(idx, lf.b, s.score[t].idf, s.k1, s.b, s.avgdl);
+        fs.idf = s.score[t].idf;
+        fs.gram = lf.a;
+        fs.skip_row = lf.row;
+        ok = fs.table != 0;
+      }
+      if (!ok) continue;
+      f.n_score = static_cast<uint32_t>(s.score.size());
+      f.needed = dq[i].needed;
+      f.cap = dq[i].cap;
+      f.descending = dq[i].descending;
+      f.k1 = dq[i].k1;
+      f.b = dq[i].b;
+      f.one_minus_b = dq[i].one_minus_b;
+      f.k1_plus_1 = dq[i].k1_plus_1;
+      f.avgdl_clamped = dq[i].avgdl_clamped;
+      if (fastq.empty()) fastq.resize(n);
+      fastq[i] = f;
+      on_wave[i] = 3;
+      fsc = std::max(fsc, f.n_score);
+      fcap = std::max(fcap, f.cap);
+    }
+    g.fplan = PlanFast(fsc, fcap, idx->dev.max_doc_len);
+    if (g.fplan.bytes > 160 * 1024)  // (a page of ~1000 entries per wave does not fit beside the tables)
+      for (auto& w : on_wave) w = 0;
     const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
     uint32_t wl = 0, wsc = 0, wi = 0, wc = 64;
     bool has_list = false;
     for (uint32_t i = 0; i < n; ++i) {
+      if (on_wave[i] == 3) continue;
       const QuerySpec& s = specs[g.qids[i]];
       bool ok = allow && s.wave_ok;
       // scored terms: dense grams (tf nibbles by doc slot) or sparse ones (exact posting lookup per match)
@@ -927,6 +1076,18 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       if (!ok) continue;
       // A sorted-list operand needs the per-wave scatter scratch (16 KB per workgroup: 2 instead of 3 workgroups per
       // CU), so queries with one are launched separately and the all-bitmap majority keeps the small LDS plan.
+      // the scored terms' contribution tables come from the index's pool (a sparse gram has no bitmap row: its table is
+      // keyed by the gram id above the bitmap rows); without one the query runs on the general kernel
+      uint64_t tabs[kWaveScoreSlots] = {0, 0, 0};
+      for (size_t t = 0; ok && t < s.score.size(); ++t) {
+        const DevLeaf& lf = s.leaves[s.score[t].leaf];
+        const uint32_t key = lf.kind == kLeafGramBitmap ? lf.b : 0x80000000u | lf.a;
+        tabs[t] = GetContributionTable(idx, key, s.score[t].idf, s.k1, s.b, s.avgdl);
+        ok = tabs[t] != 0;
+      }
+      if (!ok) continue;
+      if (wave_tables.empty()) wave_tables.assign(static_cast<size_t>(n) * kWaveScoreSlots, 0);
+      for (int t = 0; t < kWaveScoreSlots; ++t) wave_tables[static_cast<size_t>(i) * kWaveScoreSlots + t] = tabs[t];
       bool lists = false;
       for (const DevLeaf& lf : s.leaves) lists = lists || lf.kind == kLeafList || lf.kind == kLeafExplicit;
       on_wave[i] = lists ? 2 : 1;
@@ -939,7 +1100,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     g.wplan = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, false);
     g.wplan_lists = PlanWave(wl, wsc, wi, wc, b->idx->dev.max_doc_len, true);
     (void)has_list;
-    if (g.wplan_lists.bytes > 160 * 1024) std::fill(on_wave.begin(), on_wave.end(), 0);
+    if (g.wplan_lists.bytes > 160 * 1024)
+      for (auto& w : on_wave)
+        if (w != 3) w = 0;
   }
   if (page_mode || df_mode) {
     // flat programs count on the wave kernel (registers only, two tiles in flight per wave); the df pass of a
@@ -1007,7 +1170,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // (a text scan per candidate costs about what scoring a match does)
       const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
       uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
-      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTilesPerItem)) & ~7u;  // whole rounds of the waves of a workgroup
+      static const uint32_t kMaxTiles = std::getenv("MGX_MAX_ITEM_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_MAX_ITEM_TILES"))) : static_cast<uint32_t>(kMaxTilesPerItem);
+      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTiles)) & ~7u;  // whole rounds of the waves of a workgroup
       // the workgroup kernel walks its tiles one after the other (~4 us each): short items keep the few queries it
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;
@@ -1057,9 +1221,14 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
   }
   const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
-  std::vector<DevItem> items_wave, items_block, items_wave_lists;
-  for (const DevItem& it : items)
-    (on_wave[it.query] == 2 && score_mode ? items_wave_lists : on_wave[it.query] ? items_wave : items_block).push_back(it);
+  std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore];
+  for (const DevItem& it : items) {
+    const uint8_t w = on_wave[it.query];
+    if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
+    else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
+  }
+  if (!fastq.empty()) MGX_HIP(Upload(g.d_fast_queries, fastq.data(), fastq.size()));
+  for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));
   MGX_HIP(Upload(g.d_items_wave_lists, items_wave_lists.data(), items_wave_lists.size()));
   g.n_items = static_cast<uint32_t>(items_block.size());
   g.n_items_wave = static_cast<uint32_t>(items_wave.size());
@@ -1067,9 +1236,13 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   MGX_HIP(Upload(g.d_items_wave, items_wave.data(), items_wave.size()));
   MGX_HIP(Upload(g.d_list_begin, list_begin.data(), list_begin.size()));
   if (std::getenv("MGX_VERBOSE"))
-    fprintf(stderr, "[mgx] %s group: %u queries; wave kernel %u items (lds %u B), block kernel %u items (lds %u B)\n",
-            score_mode ? "score" : "bitmap", n, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()),
-            g.wplan.bytes, g.n_items, g.plan.bytes);
+    fprintf(stderr,
+            "[mgx] %s group: %u queries; fast path %zu items (lds %u B, ring %u), wave kernel %u items (lds %u B), "
+            "block kernel %u items (lds %u B)\n",
+            score_mode ? "score" : "bitmap", n,
+            items_fast[0].size() + items_fast[1].size() + items_fast[2].size() + items_fast[3].size(), g.fplan.bytes,
+            g.fplan.ring, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()), g.wplan.bytes, g.n_items,
+            g.plan.bytes);
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
   d.n_items = g.n_items;
@@ -1133,34 +1306,15 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
   }
-  if (score_mode && (g.n_items_wave != 0 || !items_wave_lists.empty())) {
-    // BM25 contribution tables of the wave kernel: idf*tf*(k1+1)/(tf + k1*(1-b+b*dl/avgdl)) for tf 1..8 and every doc
-    // length below table_dl, per query and scored term — bm25_scorer.cpp:80-84 operation by operation (this file is
-    // compiled with -ffp-contract=off), so a table entry is bit-identical to the direct evaluation on the device
-    const uint32_t tdl = g.wplan.table_dl;
-    const uint32_t stride = (g.wplan.max_score * kTableTf * tdl + 1) & ~1u;
-    std::vector<double> tables(static_cast<size_t>(n) * stride, 0.0);
-    for (uint32_t i = 0; i < n; ++i) {
-      if (!on_wave[i]) continue;
-      const QuerySpec& s = specs[g.qids[i]];
-      const double one_minus_b = 1.0 - s.b, k1_plus_1 = s.k1 + 1.0, avg = std::max(s.avgdl, 1.0);
-      double* t = tables.data() + static_cast<size_t>(i) * stride;
-      for (size_t term = 0; term < s.score.size(); ++term) {
-        const double idf = s.score[term].idf;
-        for (uint32_t tfi = 1; tfi <= kTableTf; ++tfi) {
-          for (uint32_t dli = 0; dli < tdl; ++dli) {
-            const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
-            const double length_norm = one_minus_b + s.b * dl / avg;
-            const double numerator = tf * k1_plus_1;
-            const double denominator = tf + s.k1 * length_norm;
-            t[(term * kTableTf + tfi - 1) * tdl + dli] = idf * numerator / denominator;
-          }
-        }
-      }
-    }
-    MGX_HIP(Upload(g.d_tables, tables.data(), tables.size()));
-    d.tables = g.d_tables.as<double>();
-    d.table_stride = stride;
+  if (score_mode && !wave_tables.empty()) {
+    MGX_HIP(Upload(g.d_tables, wave_tables.data(), wave_tables.size()));
+    d.wave_tables = g.d_tables.as<uint64_t>();
+  }
+  d.fast_queries = g.d_fast_queries.as<DevFastQuery>();
+  for (int t = 0; t < kFastMaxScore; ++t) {
+    g.dev_fast[t] = d;
+    g.dev_fast[t].items = g.d_items_fast[t].as<DevItem>();
+    g.dev_fast[t].n_items = static_cast<uint32_t>(items_fast[t].size());
   }
   g.dev_wave = d;
   g.dev_wave.items = g.d_items_wave.as<DevItem>();
@@ -1320,24 +1474,30 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    if ((g.n_items != 0 || g.dev_wave_lists.n_items != 0) && g.n_items_wave != 0) {
+    uint32_t n_fast = 0;
+    for (int t = 0; t < kFastMaxScore; ++t) n_fast += g.dev_fast[t].n_items;
+    const bool main_work = n_fast != 0 || g.n_items_wave != 0;
+    const bool side_work = g.n_items != 0 || g.dev_wave_lists.n_items != 0;
+    hipStream_t side = s;
+    if (main_work && side_work) {
       // fork: the (small) shares of the general kernel and of the list-operand plan run on the side stream while the
-      // all-bitmap wave launch fills the chip
+      // main launch fills the chip
       if (!b->fork_ev) {
         MGX_HIP(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
         MGX_HIP(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
       }
       MGX_HIP(hipEventRecord(b->fork_ev, s));
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, idx->side_stream));
-      MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, idx->side_stream));
-      MGX_HIP(hipEventRecord(b->join_ev, idx->side_stream));
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+      side = idx->side_stream;
+    }
+    MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
+    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side));
+    for (int t = 0; t < kFastMaxScore; ++t)
+      MGX_LAUNCH(LaunchAndScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
+    MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+    if (side != s) {
+      MGX_HIP(hipEventRecord(b->join_ev, side));
       MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
-    } else {
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
-      MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, s));
-      MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, s));
     }
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev1, s));

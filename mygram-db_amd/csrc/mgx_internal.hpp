@@ -130,6 +130,51 @@ struct DevIndex {
   uint32_t max_doc_len;
 };
 
+// ---- fast path of SORT _score batches: flat programs over bitmap-form operands, <= kFastMaxScore dense scored terms --
+// The query arrives at the kernel fully resolved: every operand is a device address + tile stride (no operand-kind
+// dispatch, no leaf table), every scored term is the address of its tf-nibble row and of its BM25 contribution table.
+// The tables are per (gram, idf, k1, b, avgdl) — table constants, not query data — and live in a pool owned by the
+// index (built on first use, bm25_scorer.cpp:80-84 operation by operation on the host), so a query carries addresses
+// instead of the values.
+constexpr int kFastMaxOps = 8;
+constexpr int kFastMaxScore = 4;
+constexpr uint32_t kFastLdsTf = 6;    // table rows tf 0..6 are staged in LDS (row 0 = zeros: a term the doc lacks)
+constexpr uint32_t kFastPoolTf = 14;  // rows tf 0..14 exist in the pool (a nibble of 15 = "15 or more": exact lookup)
+constexpr int kFastBlock = 512;       // 8 autonomous waves per workgroup share the query's tables
+constexpr int kFastWaves = kFastBlock / 64;
+
+enum FastOpKind : uint32_t { kFastOr = 0, kFastAnd = 1, kFastAndNot = 2 };  // (LOAD = OR into the empty accumulator)
+struct FastOp {
+  uint64_t base;         // address of the operand's words of tile 0; filter bitmaps: byte offset from DevIndex::filter_bitmaps
+  uint32_t tile_stride;  // bytes from one tile's 2 KiB of this row to the next tile's
+  uint32_t code;         // kind | (relative-to-filter-base flag << 4) | (funnel counter mask counted AFTER this op << 8)
+};
+struct FastScore {
+  uint64_t nib;          // address of the term's tf-nibble row (DevIndex::tfnib + row * nib_row_stride)
+  uint64_t table;        // address of its contribution table: (kFastPoolTf + 1) rows x tdl doubles
+  double idf;            // direct evaluation (tf >= 15 or a doc longer than the table)
+  uint32_t gram, skip_row;
+};
+struct DevFastQuery {
+  uint32_t n_ops, n_score, needed, cap;
+  uint32_t descending, pad0, pad1, pad2;
+  double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;
+  double pad3;
+  FastOp ops[kFastMaxOps];
+  FastScore score[kFastMaxScore];
+};
+static_assert(sizeof(DevFastQuery) % 16 == 0, "DevFastQuery is read with 16-byte scalar loads");
+
+struct FastPlan {
+  uint32_t tdl;        // doc-length extent of the tables (even)
+  uint32_t ring;       // match-buffer entries per wave
+  uint32_t max_score, max_cap;
+  uint32_t dl_escape;  // dl8 can hold the escape value 255 (max_doc_len >= 255)
+  uint32_t bytes;
+};
+FastPlan PlanFast(uint32_t max_score, uint32_t max_cap, uint32_t max_doc_len);
+uint32_t FastTableDl(uint32_t max_doc_len);  // tdl of an index
+
 // One workgroup's share of a query: tiles [tile_begin, tile_begin + n_tiles). The host cuts every query into items
 // of about equal estimated cost (expensive queries — many matches per tile — get more, shorter items), so no
 // workgroup is a long tail. `list` is the item's index in the launch-wide candidate arrays.
@@ -158,8 +203,8 @@ struct DevBatch {
   uint32_t* cand_docs;
   uint32_t* cand_n;      // [n_items]
   uint32_t cand_stride;
-  const double* tables;  // [n_queries][table_stride] BM25 contribution tables of the wave kernel, built once at prepare
-  uint32_t table_stride;
+  const uint64_t* wave_tables;  // [n_queries][kWaveScoreSlots] addresses of the scored terms' pool tables (wave kernel)
+  const DevFastQuery* fast_queries;  // [n_queries] resolved descriptors of the fast-path queries (others: unused rows)
   uint32_t debug_skip;   // -DMGX_ABLATION builds only (MGX_DEBUG_SKIP: 1 = no scoring, 2 = no enumeration + scoring); 0 otherwise
   // bitmap mode
   uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]

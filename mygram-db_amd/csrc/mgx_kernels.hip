@@ -225,6 +225,7 @@ struct WaveTopK {
   uint64_t* keys;
   uint32_t* docs;
   uint32_t cap, needed;
+  bool lds_sort;         // -DMGX_ABLATION builds: force the LDS bitonic truncation (A/B of the in-register one)
   uint32_t have, pend;   // wave-uniform
   uint64_t bound_key;    // valid when have >= needed
   uint32_t bound_doc;
@@ -277,6 +278,92 @@ __device__ void wave_topk_truncate(WaveTopK& t) {
   }
 }
 
+// wave_topk_truncate for cap == 64, in registers: the LDS version above sorts all 128 slots with ~28 compare-exchange
+// stages of LDS round trips (~900 instructions), and every wave of every work item pays it at least twice (warm-up and
+// the final list) — a third of the scoring kernel's instructions. Here the <= 64 pending entries are sorted one per
+// lane with cross-lane moves (ds_swizzle / bpermute, no LDS memory), merged with the kept list by the bitonic
+// "reverse, take the better, merge" step, and written back once: ~340 instructions.
+__device__ __forceinline__ void lane_exchange(uint64_t& k, uint32_t& d, uint64_t pk, uint32_t pd, bool keep_better) {
+  const bool mine_better = better(k, d, pk, pd);
+  const bool keep_mine = keep_better == mine_better;
+  k = keep_mine ? k : pk;
+  d = keep_mine ? d : pd;
+}
+template <int J>
+__device__ __forceinline__ void lane_partner(uint64_t k, uint32_t d, uint64_t* pk, uint32_t* pd) {
+  uint32_t lo = static_cast<uint32_t>(k), hi = static_cast<uint32_t>(k >> 32), plo, phi;
+  if (J < 32) {  // bit-mode swizzle: lane ^ J inside each half of the wave
+    constexpr int pat = (J << 10) | 0x1F;
+    plo = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(lo), pat));
+    phi = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(hi), pat));
+    *pd = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(d), pat));
+  } else {
+    plo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(lo), 32, 64));
+    phi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(hi), 32, 64));
+    *pd = static_cast<uint32_t>(__shfl_xor(static_cast<int>(d), 32, 64));
+  }
+  *pk = (static_cast<uint64_t>(phi) << 32) | plo;
+}
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step(uint64_t& k, uint32_t& d, uint32_t lane) {
+  uint64_t pk;
+  uint32_t pd;
+  lane_partner<J>(k, d, &pk, &pd);
+  const bool up = (lane & K) == 0, lower = (lane & J) == 0;  // K == 64: one best-first block
+  lane_exchange(k, d, pk, pd, up == lower);
+}
+template <int K>
+__device__ __forceinline__ void bitonic_merge(uint64_t& k, uint32_t& d, uint32_t lane) {
+  if constexpr (K >= 64) bitonic_step<K, 32>(k, d, lane);
+  if constexpr (K >= 32) bitonic_step<K, 16>(k, d, lane);
+  if constexpr (K >= 16) bitonic_step<K, 8>(k, d, lane);
+  if constexpr (K >= 8) bitonic_step<K, 4>(k, d, lane);
+  if constexpr (K >= 4) bitonic_step<K, 2>(k, d, lane);
+  bitonic_step<K, 1>(k, d, lane);
+}
+
+__device__ __forceinline__ void wave_topk_truncate64(WaveTopK& t) {
+  const uint32_t lane = lane_id();
+  if (t.pend == 0) return;
+  wave_lds_sync();
+  uint64_t k = lane < t.pend ? t.keys[64 + lane] : 0ull;
+  uint32_t d = lane < t.pend ? t.docs[64 + lane] : 0u;
+  bitonic_merge<2>(k, d, lane);
+  bitonic_merge<4>(k, d, lane);
+  bitonic_merge<8>(k, d, lane);
+  bitonic_merge<16>(k, d, lane);
+  bitonic_merge<32>(k, d, lane);
+  bitonic_merge<64>(k, d, lane);  // lane i: the i-th best pending entry
+  // kept list reversed against it: the better of each pair is the top 64 of the union, as a bitonic sequence
+  const uint64_t rk = t.keys[63 - lane];
+  const uint32_t rd = t.docs[63 - lane];
+  if (better(rk, rd, k, d)) {
+    k = rk;
+    d = rd;
+  }
+  bitonic_merge<64>(k, d, lane);
+  wave_lds_sync();
+  t.keys[lane] = k;
+  t.docs[lane] = d;
+  const uint32_t total = t.have + t.pend;
+  t.have = total < 64u ? total : 64u;
+  t.pend = 0;
+  wave_lds_sync();
+  if (t.have >= t.needed) {
+    t.bound_key = wave_uniform(t.keys[t.needed - 1]);
+    t.bound_doc = wave_uniform(t.docs[t.needed - 1]);
+    if (t.gbound_ptr && t.bound_key > t.gbound) {
+      if (lane == 0) atomicMax(t.gbound_ptr, static_cast<unsigned long long>(t.bound_key));
+      t.gbound = t.bound_key;
+    }
+  }
+}
+
+// the truncation that matches the list's capacity (the two keep different invariants about the pending region)
+__device__ __forceinline__ void wave_topk_flush(WaveTopK& t) {
+  if (t.cap == 64u && !t.lds_sort) wave_topk_truncate64(t); else wave_topk_truncate(t);
+}
+
 __device__ __forceinline__ void wave_topk_refresh_gbound(WaveTopK& t) {
   if (t.gbound_ptr) {
     const uint64_t g = wave_uniform(static_cast<uint64_t>(
@@ -285,14 +372,19 @@ __device__ __forceinline__ void wave_topk_refresh_gbound(WaveTopK& t) {
   }
 }
 
-// Offer one candidate per lane (valid=false for idle lanes). Wave-uniform control flow.
+__device__ __forceinline__ void wave_topk_flush(WaveTopK& t);
+
+// Offer one candidate per lane (valid=false for idle lanes). Wave-uniform control flow. kReg64: the list has cap == 64
+// and is truncated in registers (wave_topk_truncate64); the kernels that were tuned around the LDS truncation keep it
+// (inlining both into their loops cost them registers: wave_score_kernel went from 12 to 68 bytes of scratch).
+template <bool kReg64 = false>
 __device__ __forceinline__ void wave_topk_offer(WaveTopK& t, bool valid, uint64_t key, uint32_t doc) {
   bool surv = valid && key >= t.gbound && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
   uint64_t mask = __ballot(surv);
   if (mask == 0) return;
   uint32_t ns = __popcll(mask);
   if (t.pend + ns > t.cap) {
-    wave_topk_truncate(t);
+    if (kReg64) wave_topk_flush(t); else wave_topk_truncate(t);
     surv = surv && key >= t.gbound && (t.have < t.needed || better(key, doc, t.bound_key, t.bound_doc));
     mask = __ballot(surv);
     if (mask == 0) return;
@@ -432,6 +524,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   if (MODE == kModeScore) {
     tk.cap = q.cap;
     tk.needed = q.needed;
+    tk.lds_sort = false;
     tk.keys = reinterpret_cast<uint64_t*>(smem + lo_.tk_keys) + static_cast<size_t>(wave_id()) * 2 * q.cap;
     tk.docs = reinterpret_cast<uint32_t*>(smem + lo_.tk_docs) + static_cast<size_t>(wave_id()) * 2 * q.cap;
     tk.have = 0;
@@ -864,6 +957,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
 // 80 VGPRs (12 B spill), ~42 KB LDS: 3 workgroups = 24 waves per CU. (An earlier version located tf through the
 // posting rank — prefix popcounts, operand words parked in LDS, per-step re-fetch — and was 1.4x slower.)
 
+uint32_t FastTableDl(uint32_t max_doc_len);
+
 constexpr int kScoreUnroll = 2;          // matches in flight per lane in phase C
 constexpr uint32_t kWaveMatchBuf = 512;  // matches of one tile buffered per wave and round
 
@@ -890,7 +985,7 @@ __host__ __device__ inline WaveOffsets carve_wave(const WavePlan& p) {
 WavePlan PlanWave(uint32_t max_leaves, uint32_t max_score, uint32_t max_instr, uint32_t max_cap, uint32_t max_doc_len,
                   bool has_list) {
   WavePlan p{max_leaves ? max_leaves : 1, max_score, max_instr ? max_instr : 1, max_cap, 0, has_list ? 1u : 0u, 0};
-  p.table_dl = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
+  p.table_dl = FastTableDl(max_doc_len);  // the extent of the pool's tables
   p.bytes = carve_wave(p).total;
   return p;
 }
@@ -1020,15 +1115,17 @@ __device__ __forceinline__ void wave_score_body(const DevIndex ix, const DevBatc
   const uint32_t tdl = plan.table_dl;
   for (uint32_t i = tid; i < q.n_leaves; i += kWaveBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
   for (uint32_t i = tid; i < q.n_instr; i += kWaveBlock) prog[i] = bt.prog[q.prog_begin + i];
-  {
-    const uint32_t n_pairs = (q.n_score * kTableTf * tdl + 1) / 2;
-    const double2* src = reinterpret_cast<const double2*>(bt.tables + static_cast<uint64_t>(qi) * bt.table_stride);
-    double2* dst = reinterpret_cast<double2*>(table);
-    for (uint32_t e = tid; e < n_pairs; e += kWaveBlock) dst[e] = src[e];
+  // The query's BM25 contribution tables come from the index's pool (one table per (gram, idf, k1, b, avgdl), built on
+  // first use): rows tf 1..kTableTf of every scored term are staged, tdl doubles each (tdl is even).
+  for (uint32_t i = 0; i < q.n_score; ++i) {
+    const double2* src = reinterpret_cast<const double2*>(bt.wave_tables[static_cast<uint64_t>(qi) * kWaveScoreSlots + i]) + tdl / 2;
+    double2* dst = reinterpret_cast<double2*>(table + i * kTableTf * tdl);
+    for (uint32_t e = tid; e < kTableTf * tdl / 2; e += kWaveBlock) dst[e] = src[e];
   }
   WaveTopK tk;
   tk.cap = q.cap;
   tk.needed = q.needed;
+  tk.lds_sort = false;
   tk.keys = reinterpret_cast<uint64_t*>(smem + wo.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
   tk.docs = reinterpret_cast<uint32_t*>(smem + wo.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
   tk.have = 0;
@@ -1272,6 +1369,436 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_kernel(DevIndex ix, 
 }
 __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_lists_kernel(DevIndex ix, DevBatch bt, WavePlan plan) {
   wave_score_body(ix, bt, plan);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// and_score_kernel: the fast path of SORT _score batches (flat AND/OR/ANDNOT programs over bitmap-form operands)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// Same results as wave_score_kernel, a third of its instructions. What changed, and why (profiles/r01_final_pmc_sq.json:
+// the old kernel issued 1,567 VALU instructions per tile visit at 73 % VALU busy — issue-bound, not bandwidth-bound):
+//   * no interpreter and no operand-kind dispatch: the query arrives resolved (DevFastQuery): an operand is an
+//     address + tile stride in scalar registers, the loads of up to four operands are issued back to back;
+//   * byte gathers go through buffer descriptors (one SRD per nibble row and one for dl8 in SGPRs; the per-lane part
+//     is a 32-bit offset), so a gather costs one shift instead of a 64-bit address computation;
+//   * matches are appended to a per-wave buffer that carries over from tile to tile and are scored only in FULL groups
+//     of 128 (two per lane): a sparse query (16 matches per tile) scores 64-lane-wide instead of at 25 % utilisation;
+//   * BM25 contribution tables are per gram and come from the index's pool (built once per (gram, idf, k1, b, avgdl)):
+//     rows tf 0..6 are staged in LDS (row 0 = zeros, so a term the doc lacks needs no branch), tf 7..14 are read
+//     from the pool (L2-resident) by the few lanes that need them, tf >= 15 / over-long docs are evaluated directly.
+// One workgroup = 8 autonomous waves on one query; a wave owns whole 16384-doc tiles (a lane owns 256 doc slots =
+// eight 32-bit words). No workgroup barrier inside the tile loop.
+
+constexpr uint32_t kFastRare = 128;  // per wave: < 64 left over + at most 64 set aside by one scoring step
+
+struct FastOffsets {
+  uint32_t table, ring, rare, tk_keys, tk_docs, misc, total;
+};
+__host__ __device__ inline FastOffsets carve_fast(const FastPlan& p) {
+  FastOffsets o;
+  uint32_t at = 0;
+  o.table = at;    at += p.max_score * (kFastLdsTf + 1) * p.tdl * 8;
+  o.ring = at;     at += kFastWaves * p.ring * 4;
+  o.rare = at;     at += kFastWaves * kFastRare * 4;
+  o.tk_keys = at;  at += kFastWaves * 2 * p.max_cap * 8;
+  o.tk_docs = at;  at += kFastWaves * 2 * p.max_cap * 4;
+  o.misc = at;     at += 64;
+  o.total = at;
+  return o;
+}
+uint32_t FastTableDl(uint32_t max_doc_len) {
+  const uint32_t t = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
+  return (t + 1u) & ~1u;  // even: table rows are copied 16 bytes at a time
+}
+FastPlan PlanFast(uint32_t max_score, uint32_t max_cap, uint32_t max_doc_len) {
+  FastPlan p{FastTableDl(max_doc_len), 512, max_score ? max_score : 1, max_cap, max_doc_len >= 255 ? 1u : 0u, 0};
+  p.bytes = carve_fast(p).total;
+  return p;
+}
+
+// merge of the waves' kept lists into the item's candidate list (best first) — shared epilogue of the scoring kernels
+template <int kWaves>
+__device__ __forceinline__ void waves_to_item_list(const DevBatch& bt, const WaveTopK& tk, uint32_t needed, uint32_t cap,
+                                                   const uint64_t* all_keys, const uint32_t* all_docs, uint32_t* misc,
+                                                   uint32_t list, unsigned long long* gbound_ptr) {
+  const uint32_t tid = threadIdx.x;
+  if (lane_id() == 0) misc[wave_id()] = tk.have;
+  __syncthreads();
+  uint32_t have[kWaves];
+  uint32_t total = 0;
+  for (int w = 0; w < kWaves; ++w) {
+    have[w] = min(misc[w], needed);
+    total += have[w];
+  }
+  const uint64_t obase = static_cast<uint64_t>(list) * bt.cand_stride;
+  for (uint32_t e = tid; e < kWaves * cap; e += kWaves * 64) {
+    const uint32_t w = e / cap, i = e % cap;
+    if (i >= have[w]) continue;
+    const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+    const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+    uint32_t rank = i;  // entries of the other waves' (sorted) lists that beat this one, plus its own position
+    for (uint32_t w2 = 0; w2 < kWaves; ++w2) {
+      if (w2 == w) continue;
+      const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+      const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+      uint32_t lo = 0, hi = have[w2];
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < needed) {
+      bt.cand_keys[obase + rank] = k;
+      bt.cand_docs[obase + rank] = d;
+      // the needed-th best of the whole item (8 waves' matches merged) is a far tighter query-wide bound than any one
+      // wave's: later items of the query start from it
+      if (rank == needed - 1 && gbound_ptr && !MGX_ABLATE(bt, 8u))
+        atomicMax(gbound_ptr, static_cast<unsigned long long>(k));
+    }
+  }
+  if (tid == 0) bt.cand_n[list] = min(total, needed);
+}
+
+// Global-address-space views of resolved addresses: the compiler cannot see that an integer turned pointer is global
+// memory and would emit flat loads (which also tick the LDS counter).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef const u32x4 __attribute__((address_space(1)))* gptr_u4;
+typedef const f64x2 __attribute__((address_space(1)))* gptr_d2;
+
+constexpr int kFastPerLane = 4;                     // matches per lane scored in one round: their gathers fly together
+constexpr uint32_t kFastGroup = 64 * kFastPerLane;  // matches per round
+constexpr int kFastPrefetch = 3;                    // operands of the NEXT tile requested before this tile is scored
+
+template <int T>
+__device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan,
+                                               const DevFastQuery* __restrict__ fq, const DevItem it) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const FastOffsets fo = carve_fast(plan);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = wave_uniform(tid >> 6);
+  double* const table = reinterpret_cast<double*>(smem + fo.table);
+  uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + fo.ring) + wave * plan.ring;
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + fo.misc);
+  const uint32_t tdl = plan.tdl;
+  const uint32_t lds_rows = (kFastLdsTf + 1) * tdl;  // doubles per term in LDS
+  const uint32_t n_ops = fq->n_ops;
+  const uint32_t needed = fq->needed, cap = fq->cap;
+  const bool desc = fq->descending != 0;
+  const uint32_t tile_begin = it.tile_begin;
+  const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
+  const uint64_t filter_base = reinterpret_cast<uint64_t>(ix.filter_bitmaps);
+
+  // This lane's 32 bytes of operand `o` for `tile` (two 16-byte loads, issued and not waited for).
+  auto load_operand = [&](uint32_t o, uint32_t tile, uint4 (&w)[2]) {
+    const FastOp op = fq->ops[o];
+    const uint64_t base = op.base + ((op.code & 16u) ? filter_base : 0ull) + static_cast<uint64_t>(tile) * op.tile_stride;
+    const gptr_u4 p = reinterpret_cast<gptr_u4>(base) + lane * 2;
+    const u32x4 v0 = p[0], v1 = p[1];
+    w[0] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+    w[1] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+  };
+  // The memory system answers in microseconds under this kernel's load and a wave has nothing else to do meanwhile, so
+  // what counts is how few DEPENDENT round trips a tile costs: the first tile's operands are requested before anything
+  // else (they fly while the tables are staged), every later tile's while its predecessor is enumerated and scored.
+  uint4 wn[kFastPrefetch][2];
+  {
+    const uint32_t t0 = tile_begin + wave;
+#pragma unroll
+    for (int u = 0; u < kFastPrefetch; ++u) {
+      wn[u][0] = wn[u][1] = make_uint4(0, 0, 0, 0);
+      if (static_cast<uint32_t>(u) < n_ops && t0 < tile_end) load_operand(u, t0, wn[u]);
+    }
+  }
+
+  // ---- stage the terms' tables (rows tf 0..6) ------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const gptr_d2 src = reinterpret_cast<gptr_d2>(fq->score[i].table);
+    f64x2* dst = reinterpret_cast<f64x2*>(table + i * lds_rows);
+    for (uint32_t e = tid; e < lds_rows / 2; e += kFastBlock) dst[e] = src[e];
+  }
+  WaveTopK tk;
+  tk.cap = cap;
+  tk.needed = needed;
+  tk.lds_sort = MGX_ABLATE(bt, 16u);
+  tk.keys = reinterpret_cast<uint64_t*>(smem + fo.tk_keys) + static_cast<size_t>(wave) * 2 * cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + fo.tk_docs) + static_cast<size_t>(wave) * 2 * cap;
+  tk.have = 0;
+  tk.pend = 0;
+  tk.bound_key = 0;
+  tk.bound_doc = 0;
+  tk.gbound_ptr = bt.bounds ? bt.bounds + it.query : nullptr;
+  tk.gbound = 0;
+  for (uint32_t i = lane; i < 2 * cap; i += 64) {
+    tk.keys[i] = 0;
+    tk.docs[i] = 0;
+  }
+  __syncthreads();
+
+  // buffer descriptors of the byte columns (wave-uniform: built from kernel arguments and scalar loads only)
+  __amdgpu_buffer_rsrc_t nib_rsrc[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+    nib_rsrc[i] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fq->score[i].nib), 0,
+                                                    static_cast<int>((ix.n_docs + 1u) >> 1), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dl_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(ix.dl8), 0, static_cast<int>(ix.n_docs), 0x00020000);
+
+  uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
+  uint32_t pend = 0;  // matches waiting in the ring (wave-uniform)
+
+  // Matches the LDS tables do not cover (a term with tf > 6, a doc-length escape) are set aside in a small per-wave
+  // buffer and scored 64 at a time by score_rare: the hot loop below then holds no division, no binary search and no
+  // pool access, and the rare work itself runs at full lane utilisation.
+  uint32_t* const rbuf = reinterpret_cast<uint32_t*>(smem + fo.rare) + wave * kFastRare;
+  uint32_t n_rare = 0;  // wave-uniform
+
+  // scores rbuf[0 .. n), n <= 64: every term evaluated on its own (pool table, exact tf lookup, direct formula)
+  auto score_rare = [&](uint32_t n) {
+    const bool valid = lane < n;
+    const uint32_t slot = valid ? rbuf[lane] : 0u;
+    uint32_t d = __builtin_amdgcn_raw_buffer_load_b8(dl_rsrc, slot, 0, 0);
+    if (plan.dl_escape && d == 255u) d = ix.doc_len[slot];
+    double score = 0.0;
+#pragma nounroll
+    for (int i = 0; i < T; ++i) {
+      const FastScore st = fq->score[i];
+      uint32_t t = (reinterpret_cast<const uint8_t*>(st.nib)[slot >> 1] >> ((slot & 1u) << 2)) & 15u;
+      if (t == 15u) t = exact_tf(ix, st.gram, st.skip_row, slot);
+      double c = 0.0;
+      if (t != 0u) {
+        if (t <= kFastPoolTf && d < tdl) {
+          c = reinterpret_cast<const double*>(st.table)[t * tdl + d];
+        } else {  // bm25_scorer.cpp:80-84, same operation order as the tables
+          const double dl = static_cast<double>(d), tfd = static_cast<double>(t);
+          const double length_norm = fq->one_minus_b + fq->b * dl / fq->avgdl_clamped;
+          const double numerator = tfd * fq->k1_plus_1;
+          const double denominator = tfd + fq->k1 * length_norm;
+          c = st.idf * numerator / denominator;
+        }
+      }
+      score += c;  // (0.0 + c0 is c0; a term the doc lacks adds +0.0 where bm25_scorer.cpp:86 skips it)
+    }
+    const uint32_t doc = ix.first_doc_id + slot;
+    wave_topk_offer<true>(tk, valid, score_key(score, desc), desc ? doc : ~doc);
+  };
+
+  // scores the pending matches ring[g0 .. g0+n), n <= kFastGroup: one per lane and step, kFastPerLane steps whose
+  // T + 1 byte gathers are all requested before the first is looked at (one memory round trip per round)
+  auto score_group = [&](uint32_t g0, uint32_t n) {
+    uint32_t slot[kFastPerLane], dli[kFastPerLane], nb[kFastPerLane][T];
+#pragma unroll
+    for (int m = 0; m < kFastPerLane; ++m) {
+      const uint32_t j = m * 64 + lane;
+      slot[m] = j < n ? ring[g0 + j] : 0u;
+    }
+#pragma unroll
+    for (int m = 0; m < kFastPerLane; ++m) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) nb[m][i] = __builtin_amdgcn_raw_buffer_load_b8(nib_rsrc[i], slot[m] >> 1, 0, 0);
+      dli[m] = __builtin_amdgcn_raw_buffer_load_b8(dl_rsrc, slot[m], 0, 0);
+    }
+#pragma nounroll
+    for (int m = 0; m < kFastPerLane; ++m) {  // (one copy of the scoring + offer code; the selects below are cheap)
+      if (static_cast<uint32_t>(m) * 64u >= n) break;  // wave-uniform
+      uint32_t sl = slot[0], dl = dli[0], nbm[T];
+#pragma unroll
+      for (int i = 0; i < T; ++i) nbm[i] = nb[0][i];
+#pragma unroll
+      for (int mm = 1; mm < kFastPerLane; ++mm) {
+        if (m == mm) {  // wave-uniform
+          sl = slot[mm];
+          dl = dli[mm];
+#pragma unroll
+          for (int i = 0; i < T; ++i) nbm[i] = nb[mm][i];
+        }
+      }
+      bool valid = static_cast<uint32_t>(m) * 64u + lane < n;
+      const uint32_t sh = (sl & 1u) << 2;
+      uint32_t mx = 0;
+      double score = 0.0;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const uint32_t tf = (nbm[i] >> sh) & 15u;
+        mx = max(mx, tf);
+        // a term the doc lacks reads row 0 (+0.0); tf > 6 reads just past the staged rows (allocated LDS, any value):
+        // such a match goes to rbuf and its score here is never offered
+        const double c = table[i * lds_rows + min(tf, kFastLdsTf + 1u) * tdl + dl];
+        score = i == 0 ? c : score + c;
+      }
+      const bool rare = valid && (mx > kFastLdsTf || (plan.dl_escape && dl == 255u));
+      const uint64_t rm = __ballot(rare);
+      if (rm != 0) {  // wave-uniform
+        if (rare) rbuf[n_rare + __popcll(rm & ((1ull << lane) - 1ull))] = sl;
+        n_rare += __popcll(rm);
+        valid = valid && !rare;
+        wave_lds_sync();
+        if (n_rare >= 64u) {  // a full group of set-aside matches: score it, move the (< 64) rest to the front
+          score_rare(64u);
+          const uint32_t left = n_rare - 64u;
+          const uint32_t v0 = lane < left ? rbuf[64u + lane] : 0u;
+          wave_lds_sync();
+          if (lane < left) rbuf[lane] = v0;
+          n_rare = left;
+          wave_lds_sync();
+        }
+      }
+      if (MGX_ABLATE(bt, 1u)) {  // (ablation: score, do not offer)
+        asm volatile("" ::"v"(score));
+        continue;
+      }
+      const uint32_t doc = ix.first_doc_id + sl;
+      wave_topk_offer<true>(tk, valid, score_key(score, desc), desc ? doc : ~doc);
+    }
+  };
+
+  // The tile loop runs one extra, tile-less pass at the end that only flushes the wave's last partial group, so the
+  // scoring code exists once.
+  for (uint32_t tile = tile_begin + wave;; tile += kFastWaves) {
+    const bool flush = tile >= tile_end;  // wave-uniform
+    uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t mine = 0;
+    if (!flush) {
+      wave_topk_refresh_gbound(tk);
+      // ---- A. the operands of this lane's 256 doc slots, combined in registers ---------------------------------------
+      auto combine = [&](uint32_t o, const uint4 (&w)[2]) {
+        const uint32_t code = fq->ops[o].code;
+        const uint32_t x[8] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w};
+        const uint32_t kind = code & 15u;
+        if (kind == kFastOr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] |= x[j];
+        } else if (kind == kFastAnd) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] &= x[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] &= ~x[j];
+        }
+        const uint32_t cmask = code >> 8;
+        if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
+          uint32_t pc = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pc += __popc(a[j]);
+          if (cmask & 1u) cnt0 += pc;
+          if (cmask & 2u) cnt1 += pc;
+          if (cmask & 4u) cnt2 += pc;
+          if (cmask & 8u) cnt3 += pc;
+        }
+      };
+      // operands beyond the prefetched ones are requested now (their round trip is exposed: rare query shapes)
+#pragma unroll
+      for (int u = 0; u < kFastPrefetch; ++u)
+        if (static_cast<uint32_t>(u) < n_ops) combine(u, wn[u]);
+      for (uint32_t o = kFastPrefetch; o < n_ops; o += 2) {
+        uint4 w0[2], w1[2];
+        load_operand(o, tile, w0);
+        if (o + 1 < n_ops) load_operand(o + 1, tile, w1);
+        combine(o, w0);
+        if (o + 1 < n_ops) combine(o + 1, w1);
+      }
+      // the next tile's operands: in flight while this tile is enumerated and scored
+      if (tile + kFastWaves < tile_end) {
+#pragma unroll
+        for (int u = 0; u < kFastPrefetch; ++u)
+          if (static_cast<uint32_t>(u) < n_ops) load_operand(u, tile + kFastWaves, wn[u]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mine += __popc(a[j]);
+      cnt_res += mine;
+      if (MGX_ABLATE(bt, 2u)) mine = 0;  // operands + counts only
+    }
+
+    // ---- B. append the matches (doc slots) to the wave's buffer; C. score every full round ---------------------------
+    const uint32_t slot0 = tile * kTileDocs + lane * 256u;
+    for (;;) {
+      uint32_t n_new;
+      const uint32_t my_first = wave_excl_scan_total(mine, &n_new);
+      bool more = false;  // wave-uniform: bits left in a[] after this round
+      if (n_new != 0) {
+        const uint32_t space = plan.ring - pend;
+        if (n_new <= space) {  // the usual case: everything fits, no per-match capacity test
+          uint32_t* out = ring + pend + my_first;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            uint32_t x = a[j];
+            while (x != 0) {
+              *out++ = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
+              x &= x - 1;
+            }
+          }
+          mine = 0;
+          pend += n_new;
+        } else {  // a dense tile: take what fits, keep the rest of the bits for the next round
+          uint32_t r = my_first;
+          mine = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            uint32_t x = a[j];
+            while (x != 0 && r < space) {
+              ring[pend + r] = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
+              x &= x - 1;
+              ++r;
+            }
+            a[j] = x;
+            mine += __popc(x);
+          }
+          pend = plan.ring;
+          more = true;
+        }
+        wave_lds_sync();
+      }
+      const bool fin = flush && !more;  // the wave's last pass: partial groups are scored too
+      uint32_t g0 = 0;
+      for (;;) {
+        const uint32_t n = min(pend - g0, kFastGroup);
+        if (n == 0 || (n < kFastGroup && !fin)) break;
+        if (!MGX_ABLATE(bt, 4u)) score_group(g0, n);  // (ablation: enumerate, do not score)
+        g0 += n;
+      }
+      if (fin && n_rare != 0u) {  // the last set-aside matches
+        score_rare(n_rare);
+        n_rare = 0;
+      }
+      if (g0 != 0) {  // move the (< kFastGroup) leftover to the front: sources sit at >= kFastGroup, destinations below
+        const uint32_t left = pend - g0;
+        uint32_t v[kFastPerLane];
+#pragma unroll
+        for (int m = 0; m < kFastPerLane; ++m) v[m] = m * 64 + lane < left ? ring[g0 + m * 64 + lane] : 0u;
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < kFastPerLane; ++m)
+          if (m * 64 + lane < left) ring[m * 64 + lane] = v[m];
+        pend = left;
+        wave_lds_sync();
+      }
+      if (!more) break;
+    }
+    if (flush) break;
+  }
+
+  {
+    uint32_t v[5] = {cnt0, cnt1, cnt2, cnt3, cnt_res};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      uint32_t x = v[s];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+      if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(it.query) * 8 + s], (unsigned long long)x);
+    }
+  }
+  wave_topk_flush(tk);
+  waves_to_item_list<kFastWaves>(bt, tk, needed, cap, reinterpret_cast<const uint64_t*>(smem + fo.tk_keys),
+                                 reinterpret_cast<const uint32_t*>(smem + fo.tk_docs), misc, it.list, tk.gbound_ptr);
+}
+
+// One kernel per number of scored terms (own register allocation each); a batch launches the ones it has items for.
+// OCC = waves per SIMD the register allocation is held to (6: 80 VGPRs, three workgroups per CU; 4: 128 VGPRs, two).
+template <int T, int OCC>
+__global__ __launch_bounds__(kFastBlock, OCC) void and_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
+  const DevItem it = bt.items[blockIdx.x];
+  and_score_body<T>(ix, bt, plan, bt.fast_queries + it.query, it);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1941,6 +2468,7 @@ __global__ __launch_bounds__(kBlock) void topk_scan_kernel(const uint64_t* __res
   WaveTopK tk;
   tk.cap = cap;
   tk.needed = needed;
+  tk.lds_sort = false;
   tk.keys = reinterpret_cast<uint64_t*>(smem) + static_cast<size_t>(wave) * 2 * cap;
   tk.docs = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(kBlock / 64) * 2 * cap * 8) +
             static_cast<size_t>(wave) * 2 * cap;
@@ -2077,6 +2605,40 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
   hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kWaveBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
+}
+
+template <int T, int OCC>
+static int LaunchAndScoreT(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
+  if (plan.bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&and_score_kernel<T, OCC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL((and_score_kernel<T, OCC>), dim3(bt.n_items), dim3(kFastBlock), plan.bytes, s, ix, bt, plan);
+  MGX_KCHECK();
+  return 0;
+}
+
+// bt.items: the fast-path items of the queries with `n_score` scored terms
+int LaunchAndScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
+  if (bt.n_items == 0) return 0;
+  static const int occ = std::getenv("MGX_FAST_OCC") ? atoi(std::getenv("MGX_FAST_OCC")) : 6;
+  if (occ == 4) {
+    switch (n_score) {
+      case 1: return LaunchAndScoreT<1, 4>(ix, bt, plan, s);
+      case 2: return LaunchAndScoreT<2, 4>(ix, bt, plan, s);
+      case 3: return LaunchAndScoreT<3, 4>(ix, bt, plan, s);
+      case 4: return LaunchAndScoreT<4, 4>(ix, bt, plan, s);
+      default: return static_cast<int>(hipErrorInvalidValue);
+    }
+  }
+  switch (n_score) {
+    case 1: return LaunchAndScoreT<1, 6>(ix, bt, plan, s);
+    case 2: return LaunchAndScoreT<2, 6>(ix, bt, plan, s);
+    case 3: return LaunchAndScoreT<3, 6>(ix, bt, plan, s);
+    case 4: return LaunchAndScoreT<4, 6>(ix, bt, plan, s);
+    default: return static_cast<int>(hipErrorInvalidValue);
+  }
 }
 
 // read-only streaming probe: the box's attainable HBM read bandwidth, the second roofline denominator of bench.py

@@ -15,6 +15,7 @@ int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uin
                        uint64_t* bitmaps, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
+int LaunchAndScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s);
 int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, bool text_df, hipStream_t s);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
