@@ -9,7 +9,9 @@ HIPFLAGS := --offload-arch=$(ARCH) $(CXXFLAGS)
 
 OBJS := $(CSRC)/mgx_kernels.o $(CSRC)/mgx_api.o $(CSRC)/mgx_columns.o $(CSRC)/mgx_tools.o
 
-all: $(LIB) oracle
+SHIM := mygram-db_amd/libmygram_shim.so
+
+all: $(LIB) $(SHIM) oracle
 
 $(CSRC)/mgx_kernels.o: $(CSRC)/mgx_kernels.hip $(CSRC)/mgx_internal.hpp $(CSRC)/mgx_launch.hpp
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -23,6 +25,10 @@ $(CSRC)/mgx_tools.o: $(CSRC)/mgx_tools.cpp include/mygram_tools.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
 
+# host C++17 layer (reference-signature classes, ExecuteBatch, BatchExecutor) + its C face for ctypes / cgo / JNI callers
+$(SHIM): $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp $(CSRC)/shim/mygram_shim.hpp include/mygram_shim_c.h include/mygram_gpu.h $(LIB)
+	g++ $(CXXFLAGS) -shared -o $@ $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp -Lmygram-db_amd -lmygram_gpu -Wl,-rpath,'$$ORIGIN' -pthread
+
 oracle:
 	$(MAKE) -s -C oracle
 
@@ -33,6 +39,6 @@ ablation:
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o mygram-db_amd/libmygram_gpu_ablation.so /tmp/mgx_kernels_abl.o /tmp/mgx_api_abl.o $(CSRC)/mgx_columns.o $(CSRC)/mgx_tools.o -pthread
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(SHIM)
 	$(MAKE) -C oracle clean
 .PHONY: all oracle clean ablation

@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — queries/sec + p50 latency of batched 3-term AND + BM25 top-10 on a 10M-doc bigram index (MI355X).
 
-One step = one batch of 1024 queries: tile kernel (set algebra + fused BM25 + per-workgroup top-k), merge kernel,
-(N > 1: one RCCL all-gather of per-shard top-k + merge kernel), results copied back to the host. The query batch and
-the index are resident in HBM before the timed region starts; four different batches are cycled.
+One step = one FRESH batch of 1024 queries, end to end, in C++ (search_pipeline::BatchExecutor behind
+libmygram_shim.so): per-query planning as ExecuteFullPipeline's regular branch does it (normalise, n-grams, dictionary
+lookup, estimated sizes, sort, idf — src/server/search_pipeline.cpp:2004-2014) -> query compilation + item scheduling
+(mgx_batch_reset) -> one asynchronous upload of the batch -> kernels (set algebra + fused BM25 + per-workgroup top-k,
+merge) -> results copied to pinned host memory -> BatchResult objects. Two batches are in flight: the host plans
+batch i+1 while the device runs batch i. 32 distinct batches are cycled; nothing of a batch is cached between steps.
+The index is resident in HBM; the query strings are resident in host memory (they are what a front end hands over).
+`value` is that end-to-end rate. The kernel-replay rate of round 1 (prepared batches re-executed) is reported beside it
+as `replay_qps`, and the dominant kernel's duration comes from HIP events around it in the replay loop.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-N > 1 is STRONG scaling: the same 10M-doc table is cut into N contiguous doc-range shards, one per rank.
-Environment knobs (for rehearsals only; the defaults are the benchmark): MGX_BENCH_DOCS, MGX_BENCH_BATCH,
-MGX_BENCH_CPU_SECONDS, MGX_BENCH_DENSE (dense_threshold; >=2 disables the bitmap form of dense lists).
+N > 1 is STRONG scaling: the same 10M-doc table is cut into N contiguous doc-range shards, one per rank; every rank
+runs the whole batch on its shard, per-shard top-k lists are exchanged (RCCL all-gather) and merged.
+Environment knobs (rehearsals only; the defaults are the benchmark): MGX_BENCH_DOCS, MGX_BENCH_BATCH,
+MGX_BENCH_CPU_SECONDS, MGX_BENCH_DENSE (dense_threshold; >=2 disables the bitmap form of dense lists),
+MGX_BENCH_DEPTH (batches in flight), MGX_BENCH_PLANNERS (host planner threads).
 """
 import argparse
 import json
@@ -27,15 +35,14 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X datasheet HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_DISTINCT_BATCHES = 32
 
 
 def make_queries(mg, table, n_batches, batch, seed=42, limit=10):
     """3 distinct letter-only bigrams per query, sampled proportionally to their (global) document frequency, among the
-    grams every shard knows."""
+    grams every shard knows. -> list of batches of term lists."""
     import torch.distributed as dist
-    from mygram_db_amd import dist as mdist
     keys, sizes = table.keys, table.global_sizes
-    # a gram is usable if it has no space and exists on every shard
     present = {k for k in keys}
     if table.world > 1:
         gathered = [None] * table.world
@@ -52,41 +59,101 @@ def make_queries(mg, table, n_batches, batch, seed=42, limit=10):
         qs = []
         for _ in range(batch):
             pick = rng.choice(len(cand), size=3, replace=False, p=p)
-            qs.append(mg.engine.Query([cand[i].decode() for i in pick], sort_score=True, limit=limit))
+            qs.append([cand[i].decode() for i in pick])
         out.append(qs)
     return out
 
 
-def cpu_baseline(mg, table, corpus, queries, gpu_results, seconds):
-    """The CPU oracle (oracle/mygram_oracle.c: a C restatement of the reference's per-query path, text scans and all)
-    timed single-threaded on a bounded sample of the same batch, and used to check the GPU results of that sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def physical_cores():
+    """Physical cores this process may run on (distinct (package, core) pairs of its affinity set)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen = set()
+    for cpu in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", str(cpu)))
+    return max(1, len(seen)), len(allowed)
+
+
+def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
+    """The CPU oracle (oracle/mygram_oracle.c: a C restatement of the reference's per-query path — df by text scan of
+    every term's candidates, Execute, ScoreDocuments with tf by text scan, SortByScore) on the host cores of this box:
+    first single-threaded, then one worker per physical core, each worker running whole queries.
+    The same queries check the GPU results (docids, totals, scores bit for bit)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     c = table.index.columns
     oidx = O.Index.from_csr(2, 0, True, c.key_bytes, c.key_off, c.offsets, c.docids)
     ostore = O.DocumentStore.from_arrays(corpus.text_bytes, corpus.text_off)
     n, avg = table.index.total_docs, table.index.avg_doc_length
-    done, t0 = 0, time.perf_counter()
-    mismatches = 0
-    while done < len(queries) and (done < 4 or time.perf_counter() - t0 < seconds):
-        q = queries[done]
-        total, docs, scores = O.search_scored(oidx, ostore, q.terms, n, avg, q.k1, q.b, q.descending, q.limit, q.offset)
-        g = gpu_results[done]
-        if g.total != total or g.docs.tolist() != docs.tolist() or not np.array_equal(g.scores, scores):
+    cores, logical = physical_cores()
+
+    def one(i):
+        t0 = time.perf_counter()
+        r = O.search_scored(oidx, ostore, term_lists[i], n, avg, 1.2, 0.75, True, 10, 0)  # (ctypes drops the GIL)
+        return i, r, time.perf_counter() - t0
+
+    # 1 thread: a few queries, bounded by time
+    lat1, done, t0 = [], 0, time.perf_counter()
+    mismatches = checked = 0
+
+    def check(i, r):
+        nonlocal mismatches, checked
+        total, docs, scores = r
+        g_total, g_docs, g_scores = gpu_rows(i)
+        checked += 1
+        if g_total != total or g_docs.tolist() != docs.tolist() or not np.array_equal(g_scores, scores):
             mismatches += 1
+
+    while done < len(term_lists) and (done < 4 or time.perf_counter() - t0 < seconds * 0.35):
+        i, r, dt = one(done)
+        lat1.append(dt)
+        check(i, r)
         done += 1
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": "first %d queries of batch 0 (same 10M-doc corpus, same BM25 top-10), %.1f s, 1 thread; "
-                      "per query: df by text scan of every term's candidates + Execute + ScoreDocuments + SortByScore"
-                      % (done, dt),
-            "parity_checked": done, "parity_mismatches": mismatches}
+    dt1 = time.perf_counter() - t0
+    qps1 = done / dt1
+    # all cores: enough queries for >= ~seconds*0.65 of wall time, at least 256 when they fit
+    budget = max(seconds * 0.65, 1.0)
+    want = int(min(len(term_lists) - done, max(4 * cores, min(256, qps1 * cores * budget))))
+    want = max(want, min(len(term_lists) - done, cores))
+    latn = []
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        for i, r, dt in pool.map(one, range(done, done + want)):
+            latn.append(dt)
+            check(i, r)
+    dtn = time.perf_counter() - t0
+    latn.sort()
+    return {"value": want / dtn, "unit": "queries/s", "cores": cores, "threads": cores, "logical_cpus": logical,
+            "cpu_model": cpu_model(), "kind": "port",
+            "value_1_thread": qps1, "queries_1_thread": done, "queries_all_cores": want,
+            "p50_ms_per_query": 1e3 * latn[len(latn) // 2], "p99_ms_per_query": 1e3 * latn[min(len(latn) - 1, int(len(latn) * 0.99))],
+            "p50_ms_per_query_1_thread": 1e3 * statistics.median(lat1),
+            "sample": "batch 0 of the benchmark (same 10M-doc corpus, same 3-term AND + BM25 top-10): %d queries on 1 "
+                      "thread (%.1f s), then %d queries on %d threads = one per physical core (%.1f s); per query: df "
+                      "by text scan of every term's candidates + Execute + ScoreDocuments (tf by text scan) + "
+                      "SortByScore, as search_pipeline.cpp:2004-2019 + search_handler.cpp:454-470 do" %
+                      (done, dt1, want, cores, dtn),
+            "parity_checked": checked, "parity_mismatches": mismatches}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -105,15 +172,20 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    entry.build() if not os.path.exists(os.path.join(ROOT, "mygram-db_amd", "libmygram_gpu.so")) else None
+    if not (os.path.exists(os.path.join(ROOT, "mygram-db_amd", "libmygram_gpu.so")) and
+            os.path.exists(os.path.join(ROOT, "mygram-db_amd", "libmygram_shim.so"))):
+        entry.build()
     mg = entry.load_package()
+    from mygram_db_amd import _shim_capi as S
     from mygram_db_amd import dist as mdist
 
     n_docs_total = int(os.environ.get("MGX_BENCH_DOCS", "10000000"))
     batch_size = int(os.environ.get("MGX_BENCH_BATCH", "1024"))
-    cpu_seconds = float(os.environ.get("MGX_BENCH_CPU_SECONDS", "15"))
+    cpu_seconds = float(os.environ.get("MGX_BENCH_CPU_SECONDS", "24"))
     dense = float(os.environ.get("MGX_BENCH_DENSE", "0"))
-    n_batches = 4
+    depth = int(os.environ.get("MGX_BENCH_DEPTH", "2"))
+    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, physical_cores()[0] - 1))
+    exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
 
     t_setup = time.perf_counter()
     before, mine = mdist.shard_range(n_docs_total, rank, world)
@@ -121,8 +193,7 @@ def main():
     table = mdist.ShardedTable(corpus, first_doc_id=1 + before, device=local_rank, ngram_size=2, kanji_ngram_size=0,
                                dense_threshold=dense)
     cols = table.index.columns
-    batches_q = make_queries(mg, table, n_batches, batch_size)
-    batches = [table.prepare(qs) for qs in batches_q]
+    term_batches = make_queries(mg, table, N_DISTINCT_BATCHES, batch_size)
     setup_s = time.perf_counter() - t_setup
 
     def sync():
@@ -130,38 +201,36 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def step(i):
-        b = batches[i % n_batches]
+    # ---------------------------------------------------------------------------------------------------------------
+    # (1) replay loop: 4 prepared batches re-executed — isolates the device side; the dominant kernel is timed by HIP
+    #     events on its launch stream, algorithmic bytes come from the fetched match counts
+    # ---------------------------------------------------------------------------------------------------------------
+    replay_q = [[mg.engine.Query(t, sort_score=True, limit=10) for t in tb] for tb in term_batches[:4]]
+    batches = [table.prepare(qs) for qs in replay_q]
+    replay_steps = max(8, min(args.steps, 40))
+
+    def replay(i):
+        b = batches[i % len(batches)]
         table.run(b)
         b.fetch_raw()
 
-    for i in range(args.warmup):
-        step(i)
+    for i in range(4):
+        replay(i)
     for b in batches:
         b.kernel_time_ms()  # start recording HIP events around the tile kernel from here on
     sync()
-    lat = []
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        s0 = time.perf_counter()
-        step(i)
-        lat.append(time.perf_counter() - s0)
+    for i in range(replay_steps):
+        replay(i)
     sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant kernel: average launch duration (HIP events on the launch stream) and algorithmic bytes per launch
-    k_ms, k_n, alg = 0.0, 0, [0, 0, 0]
+    replay_elapsed = time.perf_counter() - t0
+    k_ms, k_n = 0.0, 0
     for b in batches:
         ms, n = b.kernel_time_ms()
         if n:
             k_ms += ms * n
             k_n += n
     k_ms = k_ms / k_n if k_n else 0.0
-    # bytes of an average batch, this rank's shard (totals come from the last fetch of every batch)
     per_batch = []
     for b in batches:
         if world > 1:  # totals in h_results are table-wide after a merge; re-run locally for this shard's own counts
@@ -171,15 +240,68 @@ def main():
     alg = [sum(x[i] for x in per_batch) / len(per_batch) for i in range(3)]
     alg_total = sum(alg)
     achieved = alg_total / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    results0 = batches[0].fetch() if rank == 0 else None
 
-    # HBM bytes per launch from the committed PMC summary of this same command (profiles/pmc_traffic_current.json:
-    # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the gfx950 guide says)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")) as f:
-            traffic = json.load(f)["traffic_bytes_per_launch_dominant_kernels"] if world == 1 else None
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    # ---------------------------------------------------------------------------------------------------------------
+    # (2) the timed region: fresh batches end to end in C++ (N = 1); N > 1 keeps the exchange path of dist.py per step
+    # ---------------------------------------------------------------------------------------------------------------
+    lat, timings = [], []
+    if not exchange:
+        shim_table = S.Table(table.index)
+        ex = S.Executor(shim_table, depth=depth, planner_threads=planners)
+        qbs = [S.QueryBatch(tb) for tb in term_batches]
+        outs = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
+                 np.zeros((batch_size, 10), np.float64), np.zeros(4, np.float64)) for _ in range(depth)]
+
+        def run_steps(k, record):
+            """k steps with `depth` batches in flight: submit step i+depth-1, then wait for step i."""
+            pending = []
+            sub_t = {}
+            nxt = 0
+            for _ in range(min(depth - 1, k)):
+                sub_t[nxt] = time.perf_counter()
+                pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10)))
+                nxt += 1
+            for i in range(k):
+                if nxt < k:
+                    sub_t[nxt] = time.perf_counter()
+                    pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10)))
+                    nxt += 1
+                j, ticket = pending.pop(0)
+                out = ex.wait(ticket, outs[j % depth])
+                if record:
+                    lat.append(time.perf_counter() - sub_t[j])
+                    timings.append(out[4].copy())
+
+        run_steps(args.warmup, False)
+        sync()
+        t0 = time.perf_counter()
+        run_steps(args.steps, True)
+        sync()
+        elapsed = time.perf_counter() - t0
+    else:
+        ex_batches = batches
+
+        def step(i):
+            s0 = time.perf_counter()
+            b = ex_batches[i % len(ex_batches)]
+            table.run(b)
+            b.fetch_raw()
+            lat.append(time.perf_counter() - s0)
+
+        for i in range(args.warmup):
+            step(i)
+        lat.clear()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        sync()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
 
     # second denominator: this box's streaming-read bandwidth, measured in the same job (read-only kernel, 2 GiB)
     measured_peak = None
@@ -189,22 +311,34 @@ def main():
         if mg._capi.load().mgxt_measure_read_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(gbs)) == 0:
             measured_peak = gbs.value
 
-    results0 = None
     cpu = None
     if rank == 0 and world == 1 and cpu_seconds > 0:
-        table.run(batches[0])
-        results0 = batches[0].fetch()
-        cpu = cpu_baseline(mg, table, corpus, batches_q[0], results0, cpu_seconds)
+        def gpu_rows(i):
+            r = results0[i]
+            return r.total, r.docs, r.scores
+        cpu = cpu_baseline(mg, table, corpus, term_batches[0], gpu_rows, cpu_seconds)
 
     if rank == 0:
         qps = batch_size * args.steps / elapsed
-        sizes = np.diff(cols.offsets.astype(np.int64))
+        tm = np.asarray(timings) if timings else np.zeros((1, 4))
         line = {
             "metric": "queries/sec + p50 latency, 10M-doc bigram index, batch=1024 3-term AND",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "p50_ms": 1e3 * statistics.median(lat),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 set algebra + f64 BM25",
             "data": "synthetic",
+            "end_to_end": {
+                "what": ("fresh batch per step, in C++: plan (GenerateTermInfos, size sort, idf) -> compile + schedule "
+                         "(mgx_batch_reset) -> async upload -> kernels -> pinned results -> BatchResult; %d batches in "
+                         "flight, %d distinct batches cycled, %d host planner threads" % (depth, N_DISTINCT_BATCHES, planners))
+                        if not exchange else "prepared batches + per-step RCCL exchange (dist.ShardedTable.run)",
+                "end_to_end_qps": qps,
+                "prepare_ms": float(tm[:, 0].mean() + tm[:, 1].mean()), "plan_ms": float(tm[:, 0].mean()),
+                "compile_ms": float(tm[:, 1].mean()), "enqueue_ms": float(tm[:, 2].mean()),
+                "wait_ms": float(tm[:, 3].mean()),
+                "execute_ms": 1e3 * replay_elapsed / replay_steps,
+                "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
+                "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth},
             "config": {"workload": "10M-doc synthetic ASCII corpus (seed 42), bigram index, 3-term AND + BM25 top-10, "
                                    "batch=1024 (BASELINE.json configs[1])",
                        "n_docs": n_docs_total, "batch": batch_size, "limit": 10, "k1": 1.2, "b": 0.75,
@@ -214,9 +348,8 @@ def main():
                        "mean_list_len_of_queries": alg[0] / 4 / batch_size / 3,
                        "dense_threshold": dense if dense else 1.0 / 256, "setup_s": setup_s},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic and k_ms > 0 else None,
-                         "traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and k_ms > 0 else None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
                          "peak_measured_read": measured_peak,
                          "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
                          "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
@@ -226,10 +359,12 @@ def main():
                          "algorithmic_bytes_per_launch": alg_total,
                          "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1],
                                                    "topk_12B": alg[2]},
-                         "note": "achieved = algorithmic bytes (SURVEY.md 8d: 4*sum|L| + R*(T+4) + 12*min(k,R)) of "
-                                 "this rank's shard per launch / HIP-event kernel time; dense lists are read as "
-                                 "bitmaps and lists are shared between concurrent queries through L2/MALL, so "
-                                 "physical HBM traffic is far below the algorithmic figure (see DESIGN.md, profiles/)"},
+                         "note": "ALGORITHMIC figure: bytes the reference's full-scan semantics would move (SURVEY.md 8d: "
+                                 "4*sum|L| + R*(T+4) + 12*min(k,R)) per launch / HIP-event kernel time. Dense lists are "
+                                 "read as 1-bit-per-doc bitmaps and tiles are shared through L2/MALL, so it exceeds 1.0 "
+                                 "and is NOT a fraction of physical bandwidth; the counter-measured traffic of this "
+                                 "kernel (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes) is in "
+                                 "profiles/r02_*_summary.json with the build it was taken on, not replayed here"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

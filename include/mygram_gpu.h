@@ -240,7 +240,17 @@ typedef struct mgx_result_view {
 
 /* Compiles and uploads a batch; the batch can be executed any number of times. */
 int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queries, mgx_batch** out);
-/* Enqueues the whole batch on `hip_stream` (a hipStream_t; NULL = the default stream). Asynchronous. */
+/* Re-compiles `batch` in place for a NEW set of queries (a serving loop: every step is a fresh batch). Equivalent to
+ * mgx_batch_destroy + mgx_batch_prepare on the same index, but the object keeps its device arenas, pinned result
+ * block and events, so the steady state allocates nothing. The last execute of the old contents must have completed
+ * (mgx_batch_fetch returned, or its stream was synchronized). On failure the batch is empty but still usable. */
+int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queries);
+/* A non-blocking stream the batch object owns (created on first request, kept across mgx_batch_reset): batch objects
+ * are independent pipeline slots, and a host layer without HIP headers passes this to execute / export / merge. */
+int mgx_batch_stream(mgx_batch* batch, void** hip_stream);
+/* Enqueues the whole batch on `hip_stream` (a hipStream_t; NULL = the default stream). Asynchronous; ends with the copy
+ * of the result block to pinned host memory behind an event, so mgx_batch_fetch waits for THIS batch only. The batch's
+ * input arrays (built in pinned host memory by prepare/reset) are shipped by the first execute, on this stream. */
 int mgx_batch_execute(mgx_batch* batch, void* hip_stream);
 /* Waits for the last execute and copies the (small) results to host memory owned by the batch. */
 int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out);

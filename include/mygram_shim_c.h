@@ -1,0 +1,52 @@
+/*
+ * mygram_shim_c.h — C entry points of libmygram_shim.so: the host C++17 layer of this repository
+ * (mygram-db_amd/csrc/shim/: mygramdb::index::Index, search_pipeline::ExecuteBatch, BatchExecutor) made callable from
+ * a host language that is not C++ — this repository's bench.py and tests (ctypes); a cgo / JNI binding would use the
+ * same functions. NOT a reference interface: the reference's seam for this path is C++; what these
+ * wrap mirrors search_pipeline::ExecuteFullPipeline's regular branch (src/server/search_pipeline.cpp:2002-2030) +
+ * the BM25 glue of SearchHandler::HandleSearch (src/server/handlers/search_handler.cpp:405-470) for a batch.
+ * 0 = success, otherwise a mygram::utils::ErrorCode value; mgxs_last_error() is thread-local.
+ */
+#ifndef MYGRAM_SHIM_C_H_
+#define MYGRAM_SHIM_C_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mygram_gpu.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgxs_table mgxs_table;        /* a mygramdb::index::Index over adopted handles */
+typedef struct mgxs_executor mgxs_executor;  /* a search_pipeline::BatchExecutor */
+
+const char* mgxs_last_error(void);
+
+/* Index::Adopt: the handles stay the caller's and must outlive the table. */
+int mgxs_table_adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size, int kanji_ngram_size,
+                     int cross_boundary_ngrams, mgxs_table** out);
+/* Doc-range shards: the table-wide BM25Stats and per-gram posting sizes (by this shard's gram ids) every rank must
+ * agree on, so that idf — and every score — is identical on all ranks. */
+int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double avg_doc_length,
+                                const uint64_t* global_posting_sizes, uint64_t n_grams);
+void mgxs_table_destroy(mgxs_table* table);
+
+int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out);
+void mgxs_executor_destroy(mgxs_executor* ex);
+
+/* One batch of plain conjunctive queries (query::Query with search_text + and_terms): query i has n_terms[i] raw term
+ * strings, taken in order from `terms` (NUL-terminated UTF-8). All queries share limit / offset / sort / order
+ * (SORT _score DESC LIMIT 10 is the benchmark's shape). Plans on the host, compiles into a re-used batch object and
+ * enqueues; *ticket identifies the batch for mgxs_wait. Fails when all `depth` slots hold unfetched batches. */
+int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                uint32_t limit, uint32_t offset, int sort_by_score, int descending, uint64_t* ticket);
+/* Results of a submitted batch: per query its total (results.size() before pagination) and page length, pages packed
+ * `limit` entries apart in docs / scores (scores may be NULL). timing_ms (may be NULL) receives
+ * {plan, compile, enqueue, wait} host milliseconds of this batch. */
+int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_docs, uint32_t* docs, double* scores,
+              double* timing_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

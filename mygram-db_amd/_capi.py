@@ -20,7 +20,7 @@ EXPORTS = [
     "mgx_columns_build", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
-    "mgx_batch_prepare", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
+    "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
     "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth",
@@ -116,6 +116,8 @@ def load():
     L.mgx_index_memory_bytes.argtypes = [vp, C.POINTER(u64)]
     L.mgx_index_add_filter_bitmap.argtypes = [vp, vp, u64, C.POINTER(u32)]
     L.mgx_batch_prepare.argtypes = [vp, C.POINTER(Query), u32, C.POINTER(vp)]
+    L.mgx_batch_reset.argtypes = [vp, C.POINTER(Query), u32]
+    L.mgx_batch_stream.argtypes = [vp, C.POINTER(vp)]
     L.mgx_batch_execute.argtypes = [vp, vp]
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
     L.mgx_index_attach_text.argtypes = [vp, vp, vp]

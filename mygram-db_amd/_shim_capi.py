@@ -1,0 +1,115 @@
+"""ctypes bindings of libmygram_shim.so (include/mygram_shim_c.h): the C face of the C++17 host layer
+(mygram-db_amd/csrc/shim/). bench.py and the tests use it to run whole batches — planning, compilation, execution,
+fetch — in C++, pipelined by search_pipeline::BatchExecutor. Fails loudly when the library is missing."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
+EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
+           "mgxs_executor_create", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait"]
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make`" % LIB_PATH)
+    from . import _capi
+    _capi.load()  # libmygram_gpu.so first (the shim links against it)
+    L = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise ImportError("libmygram_shim.so does not export %s" % name)
+    vp, u32, u64, i32, f64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+    L.mgxs_last_error.restype = C.c_char_p
+    L.mgxs_table_adopt.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
+    L.mgxs_table_set_global_stats.argtypes = [vp, u64, f64, vp, u64]
+    L.mgxs_table_destroy.argtypes = [vp]
+    L.mgxs_table_destroy.restype = None
+    L.mgxs_executor_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.mgxs_executor_destroy.argtypes = [vp]
+    L.mgxs_executor_destroy.restype = None
+    L.mgxs_submit.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, C.POINTER(u64)]
+    L.mgxs_wait.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+class ShimError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise ShimError("mgxs error %d: %s" % (rc, load().mgxs_last_error().decode("utf-8", "replace")))
+
+
+class QueryBatch:
+    """A batch of conjunctive queries as the C arrays mgxs_submit takes (built once, outside any timed loop: these are
+    the request strings a front end would hand over)."""
+
+    def __init__(self, term_lists):
+        self.n = len(term_lists)
+        self.n_terms = np.asarray([len(t) for t in term_lists], dtype=np.uint32)
+        flat = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for t in term_lists for s in t]
+        self._bytes = flat  # keeps the strings alive
+        self.terms = (C.c_char_p * max(len(flat), 1))(*flat)
+
+
+class Table:
+    """mygramdb::index::Index adopted from an engine.Index's handles (Index::Adopt)."""
+
+    def __init__(self, index):
+        self._index = index  # keeps columns + device index alive
+        h = C.c_void_p()
+        _check(load().mgxs_table_adopt(index.columns._h, index.device_index._h, index.ngram_size,
+                                       index.kanji_ngram_size, int(index.cross_boundary), C.byref(h)))
+        self._h = h
+        if index._global_sizes is not None:
+            sizes = np.ascontiguousarray(index._global_sizes, dtype=np.uint64)
+            _check(load().mgxs_table_set_global_stats(self._h, int(index.total_docs), float(index.avg_doc_length),
+                                                      sizes.ctypes.data, len(sizes)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgxs_table_destroy(self._h)
+            self._h = None
+
+
+class Executor:
+    """search_pipeline::BatchExecutor: submit() plans + compiles + enqueues a fresh batch in C++, wait() fetches it."""
+
+    def __init__(self, table, depth=2, planner_threads=4):
+        self._table = table
+        h = C.c_void_p()
+        _check(load().mgxs_executor_create(table._h, depth, planner_threads, C.byref(h)))
+        self._h = h
+        self._shape = {}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgxs_executor_destroy(self._h)
+            self._h = None
+
+    def submit(self, qb, limit=10, offset=0, sort_by_score=True, descending=True):
+        t = C.c_uint64()
+        _check(load().mgxs_submit(self._h, qb.n, qb.n_terms.ctypes.data, C.cast(qb.terms, C.c_void_p), limit, offset,
+                                  int(sort_by_score), int(descending), C.byref(t)))
+        self._shape[t.value] = (qb.n, limit)
+        return t.value
+
+    def wait(self, ticket, out=None):
+        """-> (totals u64[n], n_docs u32[n], docs u32[n, limit], scores f64[n, limit], timing_ms f64[4])."""
+        n, limit = self._shape.pop(ticket)
+        if out is None:
+            out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, max(limit, 1)), np.uint32),
+                   np.zeros((n, max(limit, 1)), np.float64), np.zeros(4, np.float64))
+        totals, n_docs, docs, scores, timing = out
+        _check(load().mgxs_wait(self._h, ticket, totals.ctypes.data, n_docs.ctypes.data, docs.ctypes.data,
+                                scores.ctypes.data, timing.ctypes.data))
+        return out

@@ -50,19 +50,125 @@ int Fail(int code, const std::string& msg) {
                          std::string(#expr) + ": " + hipGetErrorString(static_cast<hipError_t>(e__)));      \
   } while (0)
 
-// Owning device buffer.
+// Device memory handed out in pieces that never move, optionally mirrored in pinned host memory. A batch builds all
+// of its (small) input arrays in the mirror and ships them with ONE asynchronous copy per chunk on the execute stream;
+// its device-only outputs come from a second arena. Chunks are kept when the arena is reset, so a serving loop that
+// re-prepares a batch object (mgx_batch_reset) allocates nothing in steady state.
+struct Arena {
+  struct Chunk {
+    char* dev = nullptr;
+    char* host = nullptr;  // pinned mirror (mirrored arenas only)
+    size_t cap = 0, used = 0;
+  };
+  std::vector<Chunk> chunks;
+  bool mirrored = false;
+  size_t chunk_bytes = 4u << 20;
+  explicit Arena(bool m) : mirrored(m) {}
+  Arena(const Arena&) = delete;
+  Arena& operator=(const Arena&) = delete;
+  ~Arena() {
+    for (Chunk& c : chunks) {
+      if (c.dev) (void)hipFree(c.dev);
+      if (c.host) (void)hipHostFree(c.host);
+    }
+  }
+  void Reset() {
+    for (Chunk& c : chunks) c.used = 0;
+  }
+  // 256-byte aligned piece of n bytes; *mirror receives its host twin (mirrored arenas)
+  hipError_t Alloc(size_t n, void** dev, void** mirror) {
+    n = (std::max<size_t>(n, 16) + 255) & ~static_cast<size_t>(255);
+    for (Chunk& c : chunks) {
+      if (c.cap - c.used >= n) {
+        *dev = c.dev + c.used;
+        if (mirror) *mirror = c.host ? c.host + c.used : nullptr;
+        c.used += n;
+        return hipSuccess;
+      }
+    }
+    Chunk c;
+    c.cap = std::max(n, chunk_bytes);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.dev), c.cap);
+    if (e != hipSuccess) return e;
+    if (mirrored) {
+      e = hipHostMalloc(reinterpret_cast<void**>(&c.host), c.cap, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        (void)hipFree(c.dev);
+        return e;
+      }
+    }
+    c.used = n;
+    *dev = c.dev;
+    if (mirror) *mirror = c.host;
+    chunks.push_back(c);
+    return hipSuccess;
+  }
+};
+
+// What a batch object keeps across mgx_batch_reset: its arenas, the pinned block its results are copied into, events.
+struct BatchResources {
+  Arena upload{true}, out{false};
+  bool uploaded = false;
+  void* h_down[2] = {nullptr, nullptr};  // pinned result blocks (score group, docid-page group)
+  size_t h_down_cap[2] = {0, 0};
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;  // fork/join of the side-stream launch
+  // A batch object is one pipeline slot: with a NULL stream argument it runs on its own non-blocking stream, and the
+  // copy of its (small) result block to pinned memory is part of the execute, fenced by done_ev — so fetching batch i
+  // waits for batch i alone while batch i+1 already runs.
+  hipStream_t stream = nullptr;
+  hipEvent_t done_ev = nullptr;
+  bool copy_issued = false;
+  ~BatchResources() {
+    if (stream) (void)hipStreamDestroy(stream);
+    if (done_ev) (void)hipEventDestroy(done_ev);
+    for (void* h : h_down)
+      if (h) (void)hipHostFree(h);
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    if (join_ev) (void)hipEventDestroy(join_ev);
+  }
+  hipError_t Pinned(int which, size_t bytes, void** out_ptr) {
+    if (h_down_cap[which] < bytes) {
+      if (h_down[which]) (void)hipHostFree(h_down[which]);
+      h_down[which] = nullptr;
+      h_down_cap[which] = 0;
+      const size_t cap = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+      hipError_t e = hipHostMalloc(&h_down[which], cap, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      h_down_cap[which] = cap;
+    }
+    *out_ptr = h_down[which];
+    return hipSuccess;
+  }
+  void Reset() {
+    upload.Reset();
+    out.Reset();
+    uploaded = false;
+    copy_issued = false;
+  }
+};
+// The resources DevBuf::Alloc / Upload draw from while a batch is being prepared on this thread (null: own hipMalloc).
+static thread_local BatchResources* tl_res = nullptr;
+struct ResourceScope {
+  BatchResources* prev;
+  explicit ResourceScope(BatchResources* r) : prev(tl_res) { tl_res = r; }
+  ~ResourceScope() { tl_res = prev; }
+};
+
+// Device buffer: owns its memory (hipMalloc), or is a piece of the current batch's arena.
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
     if (this != &o) {
       Free();
       p = o.p;
       bytes = o.bytes;
+      owned = o.owned;
       o.p = nullptr;
       o.bytes = 0;
     }
@@ -70,13 +176,18 @@ struct DevBuf {
   }
   ~DevBuf() { Free(); }
   void Free() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
   }
   hipError_t Alloc(size_t n) {
     Free();
     bytes = n;
+    if (tl_res) {
+      owned = false;
+      return tl_res->out.Alloc(n, &p, nullptr);
+    }
     return hipMalloc(&p, n ? n : 16);
   }
   template <typename T>
@@ -85,6 +196,17 @@ struct DevBuf {
 
 template <typename T>
 static hipError_t Upload(DevBuf& b, const T* host, size_t count, size_t pad_count = 0) {
+  if (tl_res) {  // into the batch's upload arena: shipped by the first execute
+    b.Free();
+    b.bytes = (count + pad_count) * sizeof(T);
+    b.owned = false;
+    void* mirror = nullptr;
+    hipError_t e = tl_res->upload.Alloc(b.bytes, &b.p, &mirror);
+    if (e != hipSuccess) return e;
+    if (count) std::memcpy(mirror, host, count * sizeof(T));
+    if (pad_count) std::memset(static_cast<char*>(mirror) + count * sizeof(T), 0xFF, pad_count * sizeof(T));
+    return hipSuccess;
+  }
   hipError_t e = b.Alloc((count + pad_count) * sizeof(T));
   if (e != hipSuccess) return e;
   if (pad_count) {
@@ -108,6 +230,7 @@ struct mgx_index {
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // the few queries the wave kernel cannot take run here, beside the main launch
   std::mutex mu;  // serialises the single-operator entry points and filter registration
+  std::unique_ptr<mgx::BatchResources> single_res;  // arenas of the single-operator batches (used under mu)
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
@@ -848,6 +971,8 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
 
 struct mgx_batch {
   mgx_index* idx = nullptr;
+  std::unique_ptr<mgx::BatchResources> res_owned;  // kept across mgx_batch_reset
+  mgx::BatchResources* res = nullptr;              // = res_owned.get(), or the index's single-operator resources
   uint32_t n_queries = 0;
   std::vector<mgx::QuerySpec> specs;
   // per mode: the queries of that mode, in batch order
@@ -897,7 +1022,7 @@ struct mgx_batch {
   // Everything mgx_batch_fetch needs from a score group sits in ONE device block, copied with one async memcpy into
   // pinned host memory: [counters n*9 u64 | total_override n u64 | page_scores n*L f64 | page_docs n*L u32 | page_n n u32]
   DevBuf d_score_out;
-  void* h_score_out = nullptr;  // hipHostMalloc
+  void* h_score_out = nullptr;  // pinned (BatchResources)
   size_t so_override = 0, so_scores = 0, so_docs = 0, so_n = 0, so_bytes = 0;
   unsigned long long* sc_counters() const { return d_score_out.as<unsigned long long>(); }
   uint64_t* sc_override() const { return reinterpret_cast<uint64_t*>(static_cast<char*>(d_score_out.p) + so_override); }
@@ -921,7 +1046,6 @@ struct mgx_batch {
   std::vector<double> h_scores;
   bool executed = false;
   hipStream_t last_stream = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;  // fork/join of the side-stream launch (owned by the batch)
   // kernel timing
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1137,7 +1261,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     b->so_n = b->so_docs + static_cast<size_t>(n) * max_limit * 4;
     b->so_bytes = b->so_n + static_cast<size_t>(n) * 4;
     MGX_HIP(b->d_score_out.Alloc(b->so_bytes));
-    MGX_HIP(hipHostMalloc(&b->h_score_out, b->so_bytes, hipHostMallocDefault));
+    MGX_HIP(b->res->Pinned(0, b->so_bytes, &b->h_score_out));
   } else if (page_mode) {
     uint32_t max_limit = 1;
     for (const DevQuery& q : dq) max_limit = std::max(max_limit, q.limit);
@@ -1146,7 +1270,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     b->po_docs = b->po_totals + static_cast<size_t>(n) * 8;
     b->po_bytes = b->po_docs + static_cast<size_t>(n) * max_limit * 4;
     MGX_HIP(b->d_page_out.Alloc(b->po_bytes));
-    MGX_HIP(hipHostMalloc(&b->h_page_out, b->po_bytes, hipHostMallocDefault));
+    MGX_HIP(b->res->Pinned(1, b->po_bytes, &b->h_page_out));
     const size_t tiles = b->idx->dev.n_tiles;
     MGX_HIP(b->d_ptile_cnt.Alloc(static_cast<size_t>(n) * tiles * 4));
     MGX_HIP(b->d_ptile_start.Alloc(static_cast<size_t>(n) * tiles * 8));
@@ -1337,8 +1461,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   return MGX_OK;
 }
 
-static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_batch** out) {
-  auto b = std::make_unique<mgx_batch>();
+// Compiles `specs` into batch object `b` (fresh, or just emptied by ResetBatch): every device array comes from the
+// batch's arenas, nothing is copied to the device here — the first execute ships the upload arena.
+static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& specs) {
+  ResourceScope scope(b->res);
   b->idx = idx;
   b->n_queries = static_cast<uint32_t>(specs.size());
   b->specs = std::move(specs);
@@ -1410,16 +1536,71 @@ static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_
       for (uint32_t i = 0; i < n_tt; ++i) b->textdf.qids.push_back(i);
     }
   }
-  int rc = UploadGroup(b.get(), b->score, kModeScore, b->specs);
+  int rc = UploadGroup(b, b->score, kModeScore, b->specs);
   if (rc) return rc;
-  rc = UploadGroup(b.get(), b->bitmap, kModeBitmap, b->specs);
+  rc = UploadGroup(b, b->bitmap, kModeBitmap, b->specs);
   if (rc) return rc;
-  rc = UploadGroup(b.get(), b->textdf, kModeTextDf, b->df_specs);
+  rc = UploadGroup(b, b->textdf, kModeTextDf, b->df_specs);
   if (rc) return rc;
-  rc = UploadGroup(b.get(), b->page, kModeDocPage, b->specs);
+  rc = UploadGroup(b, b->page, kModeDocPage, b->specs);
   if (rc) return rc;
   b->h_results.assign(b->n_queries, mgx_query_result{});
+  return MGX_OK;
+}
+
+static int PrepareFromSpecs(mgx_index* idx, std::vector<QuerySpec>&& specs, mgx_batch** out) {
+  auto b = std::make_unique<mgx_batch>();
+  b->res_owned = std::make_unique<BatchResources>();
+  b->res = b->res_owned.get();
+  int rc = PrepareInto(b.get(), idx, std::move(specs));
+  if (rc) return rc;
   *out = b.release();
+  return MGX_OK;
+}
+
+// Empties a batch object for re-use; its resources (arena chunks, pinned result blocks, events) stay.
+static void ResetBatch(mgx_batch* b) {
+  std::unique_ptr<BatchResources> owned = std::move(b->res_owned);
+  BatchResources* res = b->res;
+  for (auto& ev : b->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  const bool timing = b->timing;
+  b->~mgx_batch();
+  new (b) mgx_batch();
+  b->res_owned = std::move(owned);
+  b->res = res;
+  b->timing = timing;
+  if (res) res->Reset();
+}
+
+// Result blocks of the score / docid-page groups -> pinned host memory, fenced by the batch's done event.
+static int IssueResultCopy(mgx_batch* b, hipStream_t s) {
+  if (!b->res) return MGX_OK;
+  if (!b->page.qids.empty())
+    MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
+  if (!b->score.qids.empty())
+    MGX_HIP(hipMemcpyAsync(b->h_score_out, b->d_score_out.p, b->so_bytes, hipMemcpyDeviceToHost, s));
+  if (!b->res->done_ev) MGX_HIP(hipEventCreateWithFlags(&b->res->done_ev, hipEventDisableTiming));
+  MGX_HIP(hipEventRecord(b->res->done_ev, s));
+  b->res->copy_issued = true;
+  return MGX_OK;
+}
+
+// hip_stream as given by the caller (NULL = the default stream, as everywhere in HIP).
+static int BatchStream(mgx_batch* b, void* hip_stream, hipStream_t* out) {
+  (void)b;
+  *out = static_cast<hipStream_t>(hip_stream);
+  return MGX_OK;
+}
+
+// The batch's input arrays travel on the stream of its first execute (or df pass): one copy per arena chunk.
+static int EnsureUploaded(mgx_batch* b, hipStream_t s) {
+  if (!b->res || b->res->uploaded) return MGX_OK;
+  for (const Arena::Chunk& c : b->res->upload.chunks)
+    if (c.used) MGX_HIP(hipMemcpyAsync(c.dev, c.host, c.used, hipMemcpyHostToDevice, s));
+  b->res->uploaded = true;
   return MGX_OK;
 }
 
@@ -1429,6 +1610,10 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
   mgx_batch::Group& g = b->textdf;
   if (g.qids.empty()) return MGX_OK;
   MGX_HIP(hipSetDevice(idx->device));
+  {
+    int rc = EnsureUploaded(b, s);
+    if (rc) return rc;
+  }
   MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
   MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, true, s));
   MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s));
@@ -1441,6 +1626,10 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
 static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
   mgx_index* idx = b->idx;
   MGX_HIP(hipSetDevice(idx->device));
+  {
+    int rc = EnsureUploaded(b, s);
+    if (rc) return rc;
+  }
   b->merged_shards = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (b->timing) {
@@ -1482,12 +1671,12 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     if (main_work && side_work) {
       // fork: the (small) shares of the general kernel and of the list-operand plan run on the side stream while the
       // main launch fills the chip
-      if (!b->fork_ev) {
-        MGX_HIP(hipEventCreateWithFlags(&b->fork_ev, hipEventDisableTiming));
-        MGX_HIP(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
+      if (!b->res->fork_ev) {
+        MGX_HIP(hipEventCreateWithFlags(&b->res->fork_ev, hipEventDisableTiming));
+        MGX_HIP(hipEventCreateWithFlags(&b->res->join_ev, hipEventDisableTiming));
       }
-      MGX_HIP(hipEventRecord(b->fork_ev, s));
-      MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->fork_ev, 0));
+      MGX_HIP(hipEventRecord(b->res->fork_ev, s));
+      MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->res->fork_ev, 0));
       side = idx->side_stream;
     }
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
@@ -1496,8 +1685,8 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       MGX_LAUNCH(LaunchAndScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
     if (side != s) {
-      MGX_HIP(hipEventRecord(b->join_ev, side));
-      MGX_HIP(hipStreamWaitEvent(s, b->join_ev, 0));
+      MGX_HIP(hipEventRecord(b->res->join_ev, side));
+      MGX_HIP(hipStreamWaitEvent(s, b->res->join_ev, 0));
     }
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev1, s));
@@ -1551,6 +1740,10 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
       (void)hipEventDestroy(ev1);
     }
   }
+  {
+    int rc = IssueResultCopy(b, s);
+    if (rc) return rc;
+  }
   b->executed = true;
   b->last_stream = s;
   return MGX_OK;
@@ -1565,13 +1758,19 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   const uint32_t* page_docs = nullptr;
   const double* page_scores = nullptr;
   const unsigned long long* override_tot = nullptr;
-  if (!b->page.qids.empty())
-    MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
+  if (b->res && b->res->copy_issued) {
+    // the copies were enqueued behind the kernels: wait for THIS batch's event only (a later batch may be running)
+    MGX_HIP(hipEventSynchronize(b->res->done_ev));
+  } else {
+    if (!b->page.qids.empty())
+      MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
+    if (!b->score.qids.empty())
+      MGX_HIP(hipMemcpyAsync(b->h_score_out, b->d_score_out.p, b->so_bytes, hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+  }
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
     const size_t n = g.qids.size();
-    MGX_HIP(hipMemcpyAsync(b->h_score_out, b->d_score_out.p, b->so_bytes, hipMemcpyDeviceToHost, s));
-    MGX_HIP(hipStreamSynchronize(s));
     const char* h = static_cast<const char*>(b->h_score_out);
     const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(h);
     for (size_t i = 0; i < n * 8; ++i) g.h_counters[i] = hc[i];
@@ -1579,8 +1778,6 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     page_scores = reinterpret_cast<const double*>(h + b->so_scores);
     page_docs = reinterpret_cast<const uint32_t*>(h + b->so_docs);
     page_n = reinterpret_cast<const uint32_t*>(h + b->so_n);
-  } else {
-    MGX_HIP(hipStreamSynchronize(s));
   }
   // ---- bitmap group: totals -> page sizes -> expand ----
   std::vector<uint64_t> totals, take, out_off;
@@ -1588,6 +1785,7 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   if (!b->bitmap.qids.empty()) {
     mgx_batch::Group& g = b->bitmap;
     const size_t n = g.qids.size();
+    MGX_HIP(hipStreamSynchronize(s));  // (this group's sizes make a host round trip)
     totals.resize(n);
     take.resize(n);
     out_off.resize(n);
@@ -1698,10 +1896,44 @@ int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queri
   }
 }
 
+int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queries) {
+  if (!batch || (n_queries && !queries)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_reset: null argument");
+  try {
+    mgx_index* idx = batch->idx;
+    std::vector<mgx::QuerySpec> specs(n_queries);
+    for (uint32_t i = 0; i < n_queries; ++i) {
+      int rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
+      if (rc) {
+        mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
+        return rc;
+      }
+    }
+    MGX_HIP(hipSetDevice(idx->device));
+    mgx::ResetBatch(batch);
+    return mgx::PrepareInto(batch, idx, std::move(specs));
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_reset: ") + e.what());
+  }
+}
+
+int mgx_batch_stream(mgx_batch* batch, void** hip_stream) {
+  if (hip_stream) *hip_stream = nullptr;
+  if (!batch || !hip_stream || !batch->res) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_stream: null argument");
+  if (!batch->res->stream) {
+    MGX_HIP(hipSetDevice(batch->idx->device));
+    MGX_HIP(hipStreamCreateWithFlags(&batch->res->stream, hipStreamNonBlocking));
+  }
+  *hip_stream = batch->res->stream;
+  return MGX_OK;
+}
+
 int mgx_batch_execute(mgx_batch* batch, void* hip_stream) {
   if (!batch) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_execute: null batch");
   try {
-    return mgx::ExecuteImpl(batch, static_cast<hipStream_t>(hip_stream));
+    hipStream_t s = nullptr;
+    int rc = mgx::BatchStream(batch, hip_stream, &s);
+    if (rc) return rc;
+    return mgx::ExecuteImpl(batch, s);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_execute: ") + e.what());
   }
@@ -1721,7 +1953,10 @@ int mgx_batch_fetch(mgx_batch* batch, mgx_result_view* out) {
 int mgx_batch_count_df(mgx_batch* batch, void* hip_stream) {
   if (!batch) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_count_df: null batch");
   try {
-    int rc = mgx::CountDfImpl(batch, static_cast<hipStream_t>(hip_stream));
+    hipStream_t s = nullptr;
+    int rc = mgx::BatchStream(batch, hip_stream, &s);
+    if (rc) return rc;
+    rc = mgx::CountDfImpl(batch, s);
     if (rc) return rc;
     batch->df_ready = true;
     return MGX_OK;
@@ -1751,7 +1986,11 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
   if (!blob64 && !blob32) return MGX_OK;  // size query
   if (!blob64 || !blob32) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null blob");
   if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: not executed");
-  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  hipStream_t s = nullptr;
+  {
+    int rc_s = mgx::BatchStream(batch, hip_stream, &s);
+    if (rc_s) return rc_s;
+  }
   if (pages) {
     const mgx_batch::Group& g = batch->page;
     MGX_HIP(hipSetDevice(batch->idx->device));
@@ -1788,7 +2027,11 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
   if (!pages && (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty()))
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
                      "mgx_batch_merge_shards: the batch must be all MGX_SORT_SCORE or all docid-ordered pages");
-  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  hipStream_t s = nullptr;
+  {
+    int rc_s = mgx::BatchStream(batch, hip_stream, &s);
+    if (rc_s) return rc_s;
+  }
   if (pages) {
     // shards hold disjoint doc ranges, but the merge needs no such knowledge: pages are best-first lists by doc id
     mgx_batch::Group& g = batch->page;
@@ -1809,7 +2052,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                                     const_cast<uint64_t*>(g.dev.totals), s));
     batch->merged_shards = true;
     batch->last_stream = s;
-    return MGX_OK;
+    return mgx::IssueResultCopy(batch, s);  // (the merged page replaces the shard's own in the pinned block)
   }
   const uint32_t n = static_cast<uint32_t>(batch->score.qids.size());
   if (pitch64 == 0) pitch64 = static_cast<uint64_t>(n) * batch->top_stride + n;  // blobs laid rank after rank
@@ -1824,7 +2067,7 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
                                   batch->sc_override(), s));
   batch->merged_shards = true;
   batch->last_stream = s;
-  return MGX_OK;
+  return mgx::IssueResultCopy(batch, s);
 }
 
 int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes,
@@ -1878,10 +2121,6 @@ void mgx_batch_destroy(mgx_batch* batch) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
-  if (batch->fork_ev) (void)hipEventDestroy(batch->fork_ev);
-  if (batch->join_ev) (void)hipEventDestroy(batch->join_ev);
-  if (batch->h_score_out) (void)hipHostFree(batch->h_score_out);
-  if (batch->h_page_out) (void)hipHostFree(batch->h_page_out);
   delete batch;
 }
 
@@ -1895,10 +2134,14 @@ static int RunSingle(mgx_index* idx, mgx::QuerySpec&& spec, uint32_t** out_docs,
   std::lock_guard<std::mutex> lock(idx->mu);
   std::vector<mgx::QuerySpec> specs;
   specs.push_back(std::move(spec));
-  mgx_batch* b = nullptr;
-  int rc = mgx::PrepareFromSpecs(idx, std::move(specs), &b);
+  // single operators share one set of arenas per index (they run one at a time, under idx->mu): no allocation per call
+  if (!idx->single_res) idx->single_res = std::make_unique<mgx::BatchResources>();
+  idx->single_res->Reset();
+  mgx_batch batch_obj;
+  mgx_batch* b = &batch_obj;
+  b->res = idx->single_res.get();
+  int rc = mgx::PrepareInto(b, idx, std::move(specs));
   if (rc) return rc;
-  std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> guard(b, mgx_batch_destroy);
   rc = mgx::ExecuteImpl(b, idx->stream);
   if (rc) return rc;
   mgx_result_view v{};

@@ -3,11 +3,14 @@
 #include "mygram_shim.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <deque>
 #include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 
 namespace mygramdb {
 
@@ -183,9 +186,15 @@ struct Index::Impl {
   mutable bool has_gaps = false;       // ids inside [first, last] that were never added
   mutable uint32_t exists_bitmap = 0;  // filter bitmap of the ids that were (only when has_gaps)
 
+  bool owns_handles = true;  // false: adopted (Index::Adopt)
+  // doc-range shards: table-wide statistics (empty / 0: this index is the whole table)
+  std::vector<uint64_t> global_sizes;
+  uint64_t global_docs = 0;
+  double global_avgdl = 0.0;
+
   ~Impl() {
-    if (dev) mgx_index_destroy(dev);
-    if (cols) mgx_columns_destroy(cols);
+    if (dev && owns_handles) mgx_index_destroy(dev);
+    if (cols && owns_handles) mgx_columns_destroy(cols);
   }
   bool Lookup(std::string_view gram, uint32_t* id) const {
     int found = 0;
@@ -193,7 +202,10 @@ struct Index::Impl {
     mgx_columns_lookup(cols, reinterpret_cast<const uint8_t*>(gram.data()), gram.size(), id, &found);
     return found != 0;
   }
-  uint64_t Size(uint32_t id) const { return view.offsets[id + 1] - view.offsets[id]; }
+  // posting size the planner sees (EstimatePostingSize / df): table-wide when the index is one shard of a table
+  uint64_t Size(uint32_t id) const {
+    return global_sizes.empty() ? view.offsets[id + 1] - view.offsets[id] : global_sizes[id];
+  }
 };
 
 Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, bool cross_boundary_ngrams,
@@ -208,6 +220,18 @@ Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, boo
 }
 
 Index::~Index() = default;
+
+std::unique_ptr<Index> Index::Adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size,
+                                    int kanji_ngram_size, bool cross_boundary_ngrams) {
+  auto idx = std::make_unique<Index>(ngram_size, kanji_ngram_size, 0.0, cross_boundary_ngrams);
+  Impl* im = idx->impl_.get();
+  im->cols = columns;
+  im->dev = device_index;
+  im->owns_handles = false;
+  im->finalized = true;
+  if (mgx_columns_view_get(columns, &im->view) != MGX_OK) im->last_error = mgx_last_error();
+  return idx;
+}
 
 bool Index::AddDocument(DocId doc_id, std::string_view text) {
   std::lock_guard<std::mutex> lock(impl_->mu);
@@ -289,12 +313,22 @@ uint64_t Index::PostingSize(std::string_view term) const {  // index.cpp:580-584
 }
 uint64_t Index::EstimatePostingSize(std::string_view term) const { return PostingSize(term); }  // index.cpp:756-759
 
+std::string Index::SetGlobalStats(uint64_t total_docs, double avg_doc_length, std::vector<uint64_t> global_posting_sizes) {
+  Finalize();
+  if (global_posting_sizes.size() != impl_->view.n_grams) return "SetGlobalStats: one size per gram of this shard";
+  impl_->global_sizes = std::move(global_posting_sizes);
+  impl_->global_docs = total_docs;
+  impl_->global_avgdl = avg_doc_length;
+  return "";
+}
+
 uint64_t Index::Bm25DocCount() const {
   Finalize();
-  return impl_->view.bm25_doc_count;
+  return impl_->global_sizes.empty() ? impl_->view.bm25_doc_count : impl_->global_docs;
 }
 double Index::Bm25AvgDocLength() const {  // server_types.h:182-187
   Finalize();
+  if (!impl_->global_sizes.empty()) return impl_->global_avgdl;
   return impl_->view.bm25_doc_count
              ? static_cast<double>(impl_->view.bm25_total_len) / static_cast<double>(impl_->view.bm25_doc_count)
              : 0.0;
@@ -504,7 +538,7 @@ std::vector<DocId> ResultSorter::SortByScore(const index::Index& index, const st
 }  // namespace query
 
 // =================================================================================================================
-// search_pipeline::ExecuteBatch
+// search_pipeline::ExecuteBatch / BatchExecutor
 // =================================================================================================================
 
 namespace search_pipeline {
@@ -518,6 +552,195 @@ struct TermInfo {  // search_pipeline.h:44-55
   bool is_gram = false;  // the term is exactly one n-gram
   std::string normalized;
 };
+
+// One query planned on the host the way ExecuteFullPipeline's regular branch (search_pipeline.cpp:2002-2030) or its
+// boolean branch (:1842-1913) plans it: everything the C ABI's mgx_query points at lives in this object.
+struct PlannedQuery {
+  mgx_query q{};
+  bool on_device = false;          // false: resolved on the host (empty_term_detected) or failed
+  bool empty_term_detected = false;
+  ErrorCode error = ErrorCode::kSuccess;
+  std::string error_message;
+  std::vector<mgx_term> terms, not_terms;
+  std::vector<std::vector<uint32_t>> ids;
+  std::vector<mgx_filter> filters;
+  std::vector<mgx_expr_token> expr;
+  std::deque<std::string> texts;  // normalized text-level terms (addresses stay valid as the deque grows)
+};
+
+TermInfo MakeInfo(const index::Index& index, const index::Index::Impl* im, const std::string& raw) {
+  // GenerateTermInfos, search_pipeline.cpp:569-603
+  TermInfo ti;
+  ti.normalized = index.NormalizeText(raw);
+  auto grams = GenerateQueryNgrams(ti.normalized, index.GetNgramSize(), im->query_kanji, index.GetCrossBoundaryNgrams());
+  DeduplicateSorted(grams);
+  ti.n_grams = grams.size();
+  uint64_t mn = UINT64_MAX;
+  for (const auto& g : grams) {
+    uint32_t id = 0;
+    const uint64_t ps = im->Lookup(g, &id) ? im->Size(id) : 0;
+    if (ps > 0) {
+      mn = std::min(mn, ps);
+      ti.gram_ids.push_back(id);
+    } else {
+      mn = 0;
+      break;
+    }
+  }
+  ti.estimated_size = mn;
+  // a term that IS its one n-gram: df = |posting list|, tf = the gram's tf column; any other term is counted in the
+  // text on the device (PopulateTermDocumentFrequency / CountTermOccurrences)
+  ti.is_gram = grams.size() == 1 && grams[0] == ti.normalized;
+  ti.df = (ti.is_gram && mn != UINT64_MAX) ? mn : 0;
+  return ti;
+}
+
+void Fail(PlannedQuery* p, ErrorCode code, const char* msg) {
+  p->error = code;
+  p->error_message = msg;
+}
+
+void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_docs, double avgdl, PlannedQuery* p) {
+  const index::Index::Impl* im = index.impl();
+  auto finish = [&](uint32_t sort) {
+    mgx_query& m = p->q;
+    m.terms = p->terms.data();
+    m.n_terms = static_cast<uint32_t>(p->terms.size());
+    m.not_terms = p->not_terms.data();
+    m.n_not_terms = static_cast<uint32_t>(p->not_terms.size());
+    m.filters = p->filters.data();
+    m.n_filters = static_cast<uint32_t>(p->filters.size());
+    m.sort = sort;
+    m.limit = q.limit;
+    m.reverse = q.order == query::SortOrder::DESC ? 1 : 0;
+    m.k1 = q.bm25.k1;
+    m.b = q.bm25.b;
+    m.total_docs = total_docs;
+    m.avg_doc_length = avgdl;
+    p->on_device = true;
+  };
+  auto add_not_terms = [&]() -> bool {  // ApplyNotFilter :871-932
+    for (const auto& t : q.not_terms) {
+      TermInfo ti = MakeInfo(index, im, t);
+      if (ti.n_grams == 0) {
+        Fail(p, ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)");
+        return false;
+      }
+      if (ti.estimated_size == 0) continue;  // an unknown gram: the NOT term matches nothing
+      p->ids.push_back(ti.gram_ids);
+      p->not_terms.push_back(mgx_term{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0});
+    }
+    return true;
+  };
+  if (q.ast) {
+    // ---- boolean expression: distinct TERM leaves in first-use order, tree in postfix -----------------------------
+    if (!q.terms.empty() || q.sort_by_score)
+      return Fail(p, ErrorCode::kNotImplemented, "an expression query takes its terms from the tree and is not scored");
+    std::vector<std::string> leaves;
+    std::vector<TermInfo> tis;
+    bool bad = false;
+    std::function<void(const query::QueryNode&)> walk = [&](const query::QueryNode& nd) {
+      if (nd.type == query::NodeType::TERM) {
+        size_t k = 0;
+        while (k < leaves.size() && leaves[k] != nd.term) ++k;
+        if (k == leaves.size()) {
+          leaves.push_back(nd.term);
+          tis.push_back(MakeInfo(index, im, nd.term));
+        }
+        // a term with an unknown gram (or none at all) is an empty doc set inside the tree
+        const bool empty = tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX;
+        p->expr.push_back(empty ? mgx_expr_token{MGX_EXPR_EMPTY, 0} : mgx_expr_token{MGX_EXPR_TERM, static_cast<uint32_t>(k)});
+        return;
+      }
+      if (nd.children.empty() || (nd.type == query::NodeType::NOT && nd.children.size() != 1)) {
+        bad = true;
+        return;
+      }
+      for (const auto& c : nd.children) walk(*c);
+      const uint32_t op = nd.type == query::NodeType::AND ? MGX_EXPR_AND
+                          : nd.type == query::NodeType::OR ? MGX_EXPR_OR
+                                                           : MGX_EXPR_NOT;
+      p->expr.push_back(mgx_expr_token{op, static_cast<uint32_t>(nd.children.size())});
+    };
+    walk(*q.ast);
+    if (bad || leaves.empty() || leaves.size() > MGX_MAX_TERMS)
+      return Fail(p, ErrorCode::kInvalidArgument, "malformed expression tree");
+    p->ids.reserve(leaves.size() + q.not_terms.size());
+    for (auto& ti : tis) {
+      if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids = {0};  // placeholder of an EMPTY leaf
+      p->ids.push_back(ti.gram_ids);
+      p->terms.push_back(mgx_term{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0});
+    }
+    if (!add_not_terms()) return;
+    for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    if (im->has_gaps) p->filters.push_back(mgx_filter{im->exists_bitmap, 0u});  // NOT universe = added ids
+    finish(MGX_SORT_DOCID);
+    p->q.expr = p->expr.data();
+    p->q.n_expr = static_cast<uint32_t>(p->expr.size());
+    return;
+  }
+  if (q.terms.empty() || q.terms.size() > MGX_MAX_TERMS || q.not_terms.size() > MGX_MAX_TERMS)
+    return Fail(p, ErrorCode::kInvalidArgument, "query needs 1..64 terms");
+  std::vector<TermInfo> tis;
+  tis.reserve(q.terms.size());
+  for (const auto& t : q.terms) tis.push_back(MakeInfo(index, im, t));
+  // search_pipeline.cpp:2012-2014 (std::sort on <=16 elements is an insertion sort: equal keys keep their order)
+  std::stable_sort(tis.begin(), tis.end(),
+                   [](const TermInfo& a, const TermInfo& b) { return a.estimated_size < b.estimated_size; });
+  for (const auto& ti : tis)  // Execute :804-810
+    if ((ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) && (ti.n_grams != 0 || ti.normalized.empty())) {
+      p->empty_term_detected = true;
+      return;
+    }
+  for (const auto& ti : tis)
+    if (ti.n_grams == 0)
+      return Fail(p, ErrorCode::kNotImplemented,
+                  "a term shorter than one n-gram needs SearchNormalizedSubstring (host path)");
+  p->ids.reserve(q.terms.size() + q.not_terms.size());
+  // exact-text post-filter: the caller's verify_text decision, or a mixed-script term with an uncovered fragment
+  // (search_pipeline.cpp:856-866)
+  bool exact = q.verify_text;
+  for (const auto& ti : tis)
+    exact = exact || HasUncoveredHybridFragment(ti.normalized, index.GetNgramSize(), im->query_kanji,
+                                                index.GetCrossBoundaryNgrams());
+  for (const auto& ti : tis) {
+    p->ids.push_back(ti.gram_ids);
+    mgx_term mt{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0};
+    if (q.sort_by_score && ti.is_gram) mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
+    if (exact || (q.sort_by_score && !ti.is_gram)) {
+      p->texts.push_back(ti.normalized);
+      mt.text = reinterpret_cast<const uint8_t*>(p->texts.back().data());
+      mt.text_len = static_cast<uint32_t>(p->texts.back().size());
+    }
+    p->terms.push_back(mt);
+  }
+  if (!add_not_terms()) return;
+  for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+  finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
+  p->q.offset = q.offset;
+  p->q.exact_text = exact ? 1u : 0u;
+}
+
+// results of one fetched batch -> BatchResult objects, in the order the queries were given
+void Collect(const std::vector<PlannedQuery>& plans, const mgx_result_view& v, std::vector<BatchResult>* out) {
+  out->assign(plans.size(), BatchResult{});
+  size_t k = 0;
+  for (size_t qi = 0; qi < plans.size(); ++qi) {
+    BatchResult& o = (*out)[qi];
+    if (!plans[qi].on_device) {
+      o.empty_term_detected = plans[qi].empty_term_detected;
+      continue;
+    }
+    const mgx_query_result& r = v.queries[k++];
+    o.total = r.total;
+    o.total_candidates = r.total_candidates;
+    o.after_intersection = r.after_intersection;
+    o.after_not = r.after_not;
+    o.after_filters = r.after_filters;
+    o.results.assign(v.docs + r.docs_begin, v.docs + r.docs_begin + r.n_docs);
+    o.scores.assign(v.scores + r.docs_begin, v.scores + r.docs_begin + r.n_docs);
+  }
+}
 }  // namespace
 
 Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index,
@@ -527,215 +750,187 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
   const uint64_t total_docs = index.Bm25DocCount();
   const double avgdl = index.Bm25AvgDocLength();
-
-  std::vector<BatchResult> out(queries.size());
-  std::vector<size_t> device_slot;  // queries that reach the device, in order
+  std::vector<PlannedQuery> plans(queries.size());
   std::vector<mgx_query> mq;
-  // storage that must outlive mgx_batch_prepare
-  std::vector<std::vector<mgx_term>> term_store, not_store;
-  std::vector<std::vector<std::vector<uint32_t>>> id_store;
-  std::vector<std::vector<mgx_filter>> filter_store;
-  std::deque<std::string> text_store;  // normalized text-level terms (addresses stay valid as the deque grows)
-
-  auto make_info = [&](const std::string& raw) {  // GenerateTermInfos, search_pipeline.cpp:569-603
-    TermInfo ti;
-    ti.normalized = index.NormalizeText(raw);
-    auto grams = GenerateQueryNgrams(ti.normalized, index.GetNgramSize(), im->query_kanji,
-                                     index.GetCrossBoundaryNgrams());
-    DeduplicateSorted(grams);
-    ti.n_grams = grams.size();
-    uint64_t mn = UINT64_MAX;
-    for (const auto& g : grams) {
-      uint32_t id = 0;
-      const uint64_t ps = im->Lookup(g, &id) ? im->Size(id) : 0;
-      if (ps > 0) {
-        mn = std::min(mn, ps);
-        ti.gram_ids.push_back(id);
-      } else {
-        mn = 0;
-        break;
-      }
-    }
-    ti.estimated_size = mn;
-    // a term that IS its one n-gram: df = |posting list|, tf = the gram's tf column; any other term is counted in the
-    // text on the device (PopulateTermDocumentFrequency / CountTermOccurrences)
-    ti.is_gram = grams.size() == 1 && grams[0] == ti.normalized;
-    ti.df = (ti.is_gram && mn != UINT64_MAX) ? mn : 0;
-    return ti;
-  };
-
-  std::vector<std::vector<mgx_expr_token>> expr_store;
   for (size_t qi = 0; qi < queries.size(); ++qi) {
-    const BatchQuery& q = queries[qi];
-    if (q.ast) {
-      // ---- boolean expression: distinct TERM leaves in first-use order, tree in postfix ---------------------------
-      if (!q.terms.empty() || q.sort_by_score)
-        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
-                                        "an expression query takes its terms from the tree and is not scored"));
-      std::vector<std::string> leaves;
-      std::vector<TermInfo> tis;
-      std::vector<mgx_expr_token> toks;
-      bool bad = false;
-      std::function<void(const query::QueryNode&)> walk = [&](const query::QueryNode& nd) {
-        if (nd.type == query::NodeType::TERM) {
-          size_t k = 0;
-          while (k < leaves.size() && leaves[k] != nd.term) ++k;
-          if (k == leaves.size()) {
-            leaves.push_back(nd.term);
-            tis.push_back(make_info(nd.term));
-          }
-          // a term with an unknown gram (or none at all) is an empty doc set inside the tree
-          const bool empty = tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX;
-          toks.push_back(empty ? mgx_expr_token{MGX_EXPR_EMPTY, 0} : mgx_expr_token{MGX_EXPR_TERM, static_cast<uint32_t>(k)});
-          return;
-        }
-        if (nd.children.empty() || (nd.type == query::NodeType::NOT && nd.children.size() != 1)) {
-          bad = true;
-          return;
-        }
-        for (const auto& c : nd.children) walk(*c);
-        const uint32_t op = nd.type == query::NodeType::AND ? MGX_EXPR_AND
-                            : nd.type == query::NodeType::OR ? MGX_EXPR_OR
-                                                             : MGX_EXPR_NOT;
-        toks.push_back(mgx_expr_token{op, static_cast<uint32_t>(nd.children.size())});
-      };
-      walk(*q.ast);
-      if (bad || leaves.empty() || leaves.size() > MGX_MAX_TERMS)
-        return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "malformed expression tree"));
-      id_store.emplace_back();
-      term_store.emplace_back();
-      not_store.emplace_back();
-      filter_store.emplace_back();
-      auto& ids = id_store.back();
-      ids.reserve(leaves.size() + q.not_terms.size());
-      for (auto& ti : tis) {
-        if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids = {0};  // placeholder of an EMPTY leaf
-        ids.push_back(ti.gram_ids);
-        term_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
-      }
-      for (const auto& t : q.not_terms) {
-        TermInfo ti = make_info(t);
-        if (ti.n_grams == 0)
-          return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)"));
-        if (ti.estimated_size == 0) continue;
-        ids.push_back(ti.gram_ids);
-        not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
-      }
-      for (const auto& f : q.filters) filter_store.back().push_back(mgx_filter{f.first, f.second ? 1u : 0u});
-      if (im->has_gaps) filter_store.back().push_back(mgx_filter{im->exists_bitmap, 0u});  // NOT universe = added ids
-      expr_store.push_back(std::move(toks));
-      mgx_query m{};
-      m.terms = term_store.back().data();
-      m.n_terms = static_cast<uint32_t>(term_store.back().size());
-      m.not_terms = not_store.back().data();
-      m.n_not_terms = static_cast<uint32_t>(not_store.back().size());
-      m.filters = filter_store.back().data();
-      m.n_filters = static_cast<uint32_t>(filter_store.back().size());
-      m.sort = MGX_SORT_DOCID;
-      m.limit = q.limit;
-      m.reverse = q.order == query::SortOrder::DESC ? 1 : 0;
-      m.k1 = q.bm25.k1;
-      m.b = q.bm25.b;
-      m.total_docs = total_docs;
-      m.avg_doc_length = avgdl;
-      m.expr = expr_store.back().data();
-      m.n_expr = static_cast<uint32_t>(expr_store.back().size());
-      mq.push_back(m);
-      device_slot.push_back(qi);
-      continue;
-    }
-    if (q.terms.empty() || q.terms.size() > MGX_MAX_TERMS || q.not_terms.size() > MGX_MAX_TERMS)
-      return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "query needs 1..64 terms"));
-    std::vector<TermInfo> tis;
-    for (const auto& t : q.terms) tis.push_back(make_info(t));
-    // search_pipeline.cpp:2012-2014 (std::sort on <=16 elements is an insertion sort: equal keys keep their order)
-    std::stable_sort(tis.begin(), tis.end(),
-                     [](const TermInfo& a, const TermInfo& b) { return a.estimated_size < b.estimated_size; });
-    bool empty = false;
-    for (const auto& ti : tis)  // Execute :804-810
-      if ((ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) && (ti.n_grams != 0 || ti.normalized.empty()))
-        empty = true;
-    if (empty) {
-      out[qi].empty_term_detected = true;
-      continue;
-    }
-    for (const auto& ti : tis)
-      if (ti.n_grams == 0)
-        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
-                                        "a term shorter than one n-gram needs SearchNormalizedSubstring (host path)"));
-    id_store.emplace_back();
-    term_store.emplace_back();
-    not_store.emplace_back();
-    filter_store.emplace_back();
-    auto& ids = id_store.back();
-    ids.reserve(q.terms.size() + q.not_terms.size());
-    // exact-text post-filter: the caller's verify_text decision, or a mixed-script term with an uncovered fragment
-    // (search_pipeline.cpp:856-866)
-    bool exact = q.verify_text;
-    for (const auto& ti : tis)
-      exact = exact || HasUncoveredHybridFragment(ti.normalized, index.GetNgramSize(), im->query_kanji,
-                                                  index.GetCrossBoundaryNgrams());
-    for (const auto& ti : tis) {
-      ids.push_back(ti.gram_ids);
-      mgx_term mt{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0};
-      if (q.sort_by_score && ti.is_gram) mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
-      if (exact || (q.sort_by_score && !ti.is_gram)) {
-        text_store.push_back(ti.normalized);
-        mt.text = reinterpret_cast<const uint8_t*>(text_store.back().data());
-        mt.text_len = static_cast<uint32_t>(text_store.back().size());
-      }
-      term_store.back().push_back(mt);
-    }
-    for (const auto& t : q.not_terms) {  // ApplyNotFilter :871-932
-      TermInfo ti = make_info(t);
-      if (ti.n_grams == 0)
-        return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)"));
-      if (ti.estimated_size == 0) continue;  // an unknown gram: the NOT term matches nothing
-      ids.push_back(ti.gram_ids);
-      not_store.back().push_back(mgx_term{ids.back().data(), static_cast<uint32_t>(ids.back().size()), 0, 0.0, nullptr, 0});
-    }
-    for (const auto& f : q.filters) filter_store.back().push_back(mgx_filter{f.first, f.second ? 1u : 0u});
-    mgx_query m{};
-    m.terms = term_store.back().data();
-    m.n_terms = static_cast<uint32_t>(term_store.back().size());
-    m.not_terms = not_store.back().data();
-    m.n_not_terms = static_cast<uint32_t>(not_store.back().size());
-    m.filters = filter_store.back().data();
-    m.n_filters = static_cast<uint32_t>(filter_store.back().size());
-    m.sort = q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID;
-    m.limit = q.limit;
-    m.offset = q.offset;
-    m.reverse = q.order == query::SortOrder::DESC ? 1 : 0;
-    m.k1 = q.bm25.k1;
-    m.b = q.bm25.b;
-    m.total_docs = total_docs;
-    m.avg_doc_length = avgdl;
-    m.exact_text = exact ? 1u : 0u;
-    mq.push_back(m);
-    device_slot.push_back(qi);
+    PlanQuery(index, queries[qi], total_docs, avgdl, &plans[qi]);
+    if (plans[qi].error != ErrorCode::kSuccess)
+      return MakeUnexpected(MakeError(plans[qi].error, plans[qi].error_message));
+    if (plans[qi].on_device) mq.push_back(plans[qi].q);
   }
-  if (mq.empty()) return out;
+  std::vector<BatchResult> out;
+  mgx_result_view v{};
+  if (mq.empty()) {
+    Collect(plans, v, &out);
+    return out;
+  }
   mgx_batch* batch = nullptr;
   int rc = mgx_batch_prepare(im->dev, mq.data(), static_cast<uint32_t>(mq.size()), &batch);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> guard(batch, mgx_batch_destroy);
   rc = mgx_batch_execute(batch, nullptr);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
-  mgx_result_view v{};
   rc = mgx_batch_fetch(batch, &v);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
-  for (size_t k = 0; k < device_slot.size(); ++k) {
-    const mgx_query_result& r = v.queries[k];
-    BatchResult& o = out[device_slot[k]];
-    o.total = r.total;
-    o.total_candidates = r.total_candidates;
-    o.after_intersection = r.after_intersection;
-    o.after_not = r.after_not;
-    o.after_filters = r.after_filters;
-    o.results.assign(v.docs + r.docs_begin, v.docs + r.docs_begin + r.n_docs);
-    o.scores.assign(v.scores + r.docs_begin, v.scores + r.docs_begin + r.n_docs);
-  }
+  Collect(plans, v, &out);
   return out;
+}
+
+// ---- BatchExecutor ------------------------------------------------------------------------------------------------
+
+struct BatchExecutor::Impl {
+  const index::Index& index;
+  Options opt;
+  uint64_t total_docs = 0;
+  double avgdl = 0.0;
+  struct Slot {
+    mgx_batch* batch = nullptr;
+    std::vector<PlannedQuery> plans;
+    std::vector<mgx_query> mq;
+    uint64_t ticket = 0;  // 0 = free
+    Timing timing;
+  };
+  std::vector<Slot> slots;
+  uint64_t next_ticket = 1;
+  // planner pool: Submit hands out query ranges, the workers run PlanQuery on them
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  const std::vector<BatchQuery>* job_queries = nullptr;
+  std::vector<PlannedQuery>* job_plans = nullptr;
+  size_t job_next = 0, job_end = 0, job_pending = 0;
+  uint64_t job_generation = 0;
+  bool stop = false;
+
+  Impl(const index::Index& ix, Options o) : index(ix), opt(o) {}
+
+  void Work() {
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+      cv_work.wait(lock, [&] { return stop || job_next < job_end; });
+      if (stop) return;
+      const size_t chunk = 32;
+      const size_t a = job_next, b = std::min(job_end, a + chunk);
+      job_next = b;
+      const auto* queries = job_queries;
+      auto* plans = job_plans;
+      lock.unlock();
+      for (size_t i = a; i < b; ++i) PlanQuery(index, (*queries)[i], total_docs, avgdl, &(*plans)[i]);
+      lock.lock();
+      job_pending -= b - a;
+      if (job_pending == 0) cv_done.notify_all();
+    }
+  }
+  void PlanAll(const std::vector<BatchQuery>& queries, std::vector<PlannedQuery>* plans) {
+    plans->clear();
+    plans->resize(queries.size());
+    if (workers.empty() || queries.size() < 64) {
+      for (size_t i = 0; i < queries.size(); ++i) PlanQuery(index, queries[i], total_docs, avgdl, &(*plans)[i]);
+      return;
+    }
+    std::unique_lock<std::mutex> lock(mu);
+    job_queries = &queries;
+    job_plans = plans;
+    job_next = 0;
+    job_end = job_pending = queries.size();
+    cv_work.notify_all();
+    // the submitting thread plans too
+    while (job_next < job_end) {
+      const size_t a = job_next, b = std::min(job_end, a + 32);
+      job_next = b;
+      lock.unlock();
+      for (size_t i = a; i < b; ++i) PlanQuery(index, queries[i], total_docs, avgdl, &(*plans)[i]);
+      lock.lock();
+      job_pending -= b - a;
+    }
+    cv_done.wait(lock, [&] { return job_pending == 0; });
+    job_end = 0;
+  }
+};
+
+BatchExecutor::BatchExecutor(const index::Index& index, Options options) : impl_(std::make_unique<Impl>(index, options)) {
+  index.Finalize();
+  impl_->total_docs = index.Bm25DocCount();
+  impl_->avgdl = index.Bm25AvgDocLength();
+  impl_->slots.resize(static_cast<size_t>(std::max(1, options.depth)));
+  for (int t = 1; t < options.planner_threads; ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
+}
+
+BatchExecutor::~BatchExecutor() {
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    impl_->stop = true;
+  }
+  impl_->cv_work.notify_all();
+  for (auto& w : impl_->workers) w.join();
+  for (auto& s : impl_->slots)
+    if (s.batch) mgx_batch_destroy(s.batch);
+}
+
+Expected<uint64_t, Error> BatchExecutor::Submit(const std::vector<BatchQuery>& queries) {
+  index::Index::Impl* im = impl_->index.impl();
+  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  Impl::Slot* slot = nullptr;
+  for (auto& s : impl_->slots)
+    if (s.ticket == 0) {
+      slot = &s;
+      break;
+    }
+  if (!slot)
+    return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument,
+                                    "BatchExecutor: every slot holds an unfetched batch (Wait for one first)"));
+  using clock = std::chrono::steady_clock;
+  const auto t0 = clock::now();
+  impl_->PlanAll(queries, &slot->plans);
+  slot->mq.clear();
+  for (const auto& p : slot->plans) {
+    if (p.error != ErrorCode::kSuccess) return MakeUnexpected(MakeError(p.error, p.error_message));
+    if (p.on_device) slot->mq.push_back(p.q);
+  }
+  const auto t1 = clock::now();
+  int rc = MGX_OK;
+  if (!slot->mq.empty()) {
+    if (!slot->batch)
+      rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
+    else
+      rc = mgx_batch_reset(slot->batch, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()));
+    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  }
+  const auto t2 = clock::now();
+  if (!slot->mq.empty()) {
+    void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
+    rc = mgx_batch_stream(slot->batch, &stream);
+    if (rc == MGX_OK) rc = mgx_batch_execute(slot->batch, stream);  // asynchronous
+    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+  }
+  const auto t3 = clock::now();
+  slot->timing.plan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  slot->timing.compile_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  slot->ticket = impl_->next_ticket++;
+  return slot->ticket;
+}
+
+Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, Timing* timing) {
+  for (auto& s : impl_->slots) {
+    if (s.ticket != ticket || ticket == 0) continue;
+    std::vector<BatchResult> out;
+    mgx_result_view v{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s.mq.empty()) {
+      const int rc = mgx_batch_fetch(s.batch, &v);
+      if (rc != MGX_OK) {
+        s.ticket = 0;
+        return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+      }
+    }
+    Collect(s.plans, v, &out);
+    s.timing.wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (timing) *timing = s.timing;
+    s.ticket = 0;
+    return out;
+  }
+  return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "BatchExecutor::Wait: unknown ticket"));
 }
 
 }  // namespace search_pipeline

@@ -140,6 +140,15 @@ class Index {
   [[nodiscard]] mygram::utils::Expected<uint32_t, mygram::utils::Error> AddFilterBitmap(
       const std::vector<DocId>& docs) const;
 
+  // An Index over column arrays and a device index that already exist (built through the C ABI by the caller, e.g. a
+  // loader that read them from a dump): nothing is copied, the handles stay the caller's and must outlive the Index.
+  static std::unique_ptr<Index> Adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size,
+                                      int kanji_ngram_size, bool cross_boundary_ngrams);
+
+  // Doc-range shards (one Index per GPU): the table-wide BM25Stats and every gram's table-wide posting size, by this
+  // shard's gram ids — what idf must be computed from so that all ranks score identically. Returns "" or an error.
+  std::string SetGlobalStats(uint64_t total_docs, double avg_doc_length, std::vector<uint64_t> global_posting_sizes);
+
   // internals shared with BM25Scorer / ResultSorter / search_pipeline
   struct Impl;
   [[nodiscard]] Impl* impl() const { return impl_.get(); }
@@ -236,5 +245,33 @@ struct BatchResult {
 // Execute, BM25 + SortByScore) and run as ONE device batch.
 mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> ExecuteBatch(
     const index::Index& index, const std::vector<BatchQuery>& queries);
+
+// A serving loop over ExecuteBatch's work: every Submit plans a FRESH batch on the host (GenerateTermInfos, the size sort
+// and idf per term — on `planner_threads` threads, the way the reference plans each request on its own worker), compiles
+// it into one of `depth` re-used batch objects (mgx_batch_reset: no allocation in steady state) and enqueues it on that
+// object's own stream; Wait returns its results. With depth >= 2 the host plans batch i+1 while the device runs batch i.
+// Not thread-safe: one submitting thread (a micro-batching front end owns it).
+class BatchExecutor {
+ public:
+  struct Options {
+    int depth = 2;
+    int planner_threads = 4;
+  };
+  struct Timing {  // host milliseconds of one batch
+    double plan_ms = 0, compile_ms = 0, enqueue_ms = 0, wait_ms = 0;
+  };
+  BatchExecutor(const index::Index& index, Options options);
+  explicit BatchExecutor(const index::Index& index) : BatchExecutor(index, Options{}) {}
+  ~BatchExecutor();
+  BatchExecutor(const BatchExecutor&) = delete;
+  BatchExecutor& operator=(const BatchExecutor&) = delete;
+  // -> ticket. Fails (kInvalidArgument) when all `depth` slots hold unfetched batches.
+  mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(const std::vector<BatchQuery>& queries);
+  mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> Wait(uint64_t ticket, Timing* timing = nullptr);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
 
 }  // namespace mygramdb::search_pipeline

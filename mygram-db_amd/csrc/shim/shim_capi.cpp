@@ -1,0 +1,139 @@
+// shim_capi.cpp — extern "C" face of the C++17 shim (include/mygram_shim_c.h): what bench.py and the tests bind with
+// ctypes to drive search_pipeline::BatchExecutor, i.e. to plan, compile, run and fetch fresh batches entirely in C++.
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/mygram_shim_c.h"
+#include "mygram_shim.hpp"
+
+using mygramdb::index::Index;
+using mygramdb::search_pipeline::BatchExecutor;
+using mygramdb::search_pipeline::BatchQuery;
+
+struct mgxs_table {
+  std::unique_ptr<Index> index;
+};
+struct mgxs_executor {
+  std::unique_ptr<BatchExecutor> ex;
+  std::vector<BatchQuery> queries;  // re-used between submits
+  uint32_t limit = 0;
+};
+
+namespace {
+thread_local std::string g_err;
+int Fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+const char* mgxs_last_error(void) { return g_err.c_str(); }
+
+int mgxs_table_adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size, int kanji_ngram_size,
+                     int cross_boundary_ngrams, mgxs_table** out) {
+  if (out) *out = nullptr;
+  if (!columns || !device_index || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_adopt: null argument");
+  try {
+    auto t = std::make_unique<mgxs_table>();
+    t->index = Index::Adopt(columns, device_index, ngram_size, kanji_ngram_size, cross_boundary_ngrams != 0);
+    if (!t->index->LastError().empty()) return Fail(MGX_ERR_INTERNAL, t->index->LastError());
+    *out = t.release();
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double avg_doc_length,
+                                const uint64_t* global_posting_sizes, uint64_t n_grams) {
+  if (!table || (n_grams && !global_posting_sizes))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_set_global_stats: null argument");
+  try {
+    const std::string err = table->index->SetGlobalStats(
+        total_docs, avg_doc_length, std::vector<uint64_t>(global_posting_sizes, global_posting_sizes + n_grams));
+    return err.empty() ? MGX_OK : Fail(MGX_ERR_INVALID_ARGUMENT, err);
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+void mgxs_table_destroy(mgxs_table* table) { delete table; }
+
+int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out) {
+  if (out) *out = nullptr;
+  if (!table || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_executor_create: null argument");
+  try {
+    auto e = std::make_unique<mgxs_executor>();
+    BatchExecutor::Options o;
+    o.depth = depth > 0 ? depth : 2;
+    o.planner_threads = planner_threads > 0 ? planner_threads : 1;
+    e->ex = std::make_unique<BatchExecutor>(*table->index, o);
+    *out = e.release();
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+void mgxs_executor_destroy(mgxs_executor* ex) { delete ex; }
+
+int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                uint32_t limit, uint32_t offset, int sort_by_score, int descending, uint64_t* ticket) {
+  if (ticket) *ticket = 0;
+  if (!ex || !ticket || (n_queries && (!n_terms || !terms)))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_submit: null argument");
+  try {
+    ex->queries.resize(n_queries);
+    size_t at = 0;
+    for (uint32_t i = 0; i < n_queries; ++i) {
+      BatchQuery& q = ex->queries[i];
+      q.terms.clear();
+      for (uint32_t t = 0; t < n_terms[i]; ++t) q.terms.emplace_back(terms[at++]);
+      q.sort_by_score = sort_by_score != 0;
+      q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
+      q.limit = limit;
+      q.offset = offset;
+    }
+    ex->limit = limit;
+    auto r = ex->ex->Submit(ex->queries);
+    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
+    *ticket = *r;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_docs, uint32_t* docs, double* scores,
+              double* timing_ms) {
+  if (!ex || !totals || !n_docs || !docs) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_wait: null argument");
+  try {
+    BatchExecutor::Timing tm;
+    auto r = ex->ex->Wait(ticket, &tm);
+    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
+    const auto& res = *r;
+    for (size_t i = 0; i < res.size(); ++i) {
+      totals[i] = res[i].total;
+      const size_t n = res[i].results.size();
+      n_docs[i] = static_cast<uint32_t>(n);
+      for (size_t k = 0; k < n && k < ex->limit; ++k) {
+        docs[i * ex->limit + k] = res[i].results[k];
+        if (scores) scores[i * ex->limit + k] = k < res[i].scores.size() ? res[i].scores[k] : 0.0;
+      }
+    }
+    if (timing_ms) {
+      timing_ms[0] = tm.plan_ms;
+      timing_ms[1] = tm.compile_ms;
+      timing_ms[2] = tm.enqueue_ms;
+      timing_ms[3] = tm.wait_ms;
+    }
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+}  // extern "C"

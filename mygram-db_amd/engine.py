@@ -310,6 +310,19 @@ class PreparedBatch:
             load().mgx_batch_destroy(self._h)
             self._h = None
 
+    def reset(self, cqueries, keep, shells, orders):
+        """mgx_batch_reset: the same batch object (device arenas, pinned result block) for a new set of queries."""
+        self._keep, self._shells, self._orders = keep, shells, orders
+        self.n = len(cqueries)
+        self._exchange = self._df_view = None  # (views of the old contents' device memory)
+        arr = (_capi.Query * max(self.n, 1))(*cqueries)
+        if self._h is None:
+            h = C.c_void_p()
+            check(load().mgx_batch_prepare(self.index.device_index._h, arr, self.n, C.byref(h)))
+            self._h = h
+        else:
+            check(load().mgx_batch_reset(self._h, arr, self.n))
+
     def execute(self, stream=None):
         if self._h:
             check(load().mgx_batch_execute(self._h, stream))
@@ -582,9 +595,9 @@ class Index:
             ti.threshold = max(1, len(ti.grams) - fuzzy * n_eff)
         return ti
 
-    def prepare(self, queries):
+    def prepare(self, queries, into=None):
         """Compiles queries the way ExecuteFullPipeline's regular branch plans them (search_pipeline.cpp:2002-2030,
-        Execute :795-869) and uploads them as one batch."""
+        Execute :795-869) and uploads them as one batch. `into`: a PreparedBatch to re-use (mgx_batch_reset)."""
         cqueries, keep, shells, orders = [], [], [], []
         for q in queries:
             tis = [self.term_info(t, q.fuzzy) for t in q.terms]
@@ -680,6 +693,9 @@ class Index:
                     cq.universe_first, cq.universe_count = q.universe
             cqueries.append(cq)
             shells.append(None)
+        if into is not None:
+            into.reset(cqueries, keep, shells, orders)
+            return into
         return PreparedBatch(self, cqueries, keep, shells, orders)
 
     def search_batch(self, queries):

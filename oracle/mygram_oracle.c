@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* memmem */
 /*
  * mygram_oracle.c — CPU restatement of MygramDB's query hot path. TEST INFRASTRUCTURE ONLY (see mygram_oracle.h).
  *
@@ -158,11 +159,10 @@ size_t orc_count_code_points(const uint8_t* text, size_t len) {
 /* std::string_view::find(term, pos): first index >= pos where term occurs, or (size_t)-1. */
 static size_t bytes_find(const uint8_t* text, size_t text_len, const uint8_t* term, size_t term_len, size_t pos) {
   if (term_len == 0) return pos <= text_len ? pos : (size_t)-1;
-  if (term_len > text_len) return (size_t)-1;
-  for (size_t i = pos; i + term_len <= text_len; ++i) {
-    if (text[i] == term[0] && memcmp(text + i, term, term_len) == 0) return i;
-  }
-  return (size_t)-1;
+  if (term_len > text_len || pos > text_len - term_len) return (size_t)-1;
+  /* glibc memmem (two-way / SIMD first-byte scan): what libstdc++'s string_view::find does with memchr + memcmp */
+  const uint8_t* hit = (const uint8_t*)memmem(text + pos, text_len - pos, term, term_len);
+  return hit ? (size_t)(hit - text) : (size_t)-1;
 }
 
 /* src/index/bm25_scorer.cpp:27-45 */

@@ -417,3 +417,45 @@ def test_exact_text_filter_all_modes(score_kernel):
                              Query(["abc", "bc"], limit=10, verify_text=True)])
     assert g[0].docs.tolist() == [1, 2, 3, 4] and g[1].docs.tolist() == [1, 3] and g[1].after_filters == 4
     assert g[2].docs.tolist() == [3, 1] and g[2].total == 2
+
+
+def test_batch_object_reused_for_fresh_batches(pair60k):
+    """mgx_batch_reset: a serving loop re-prepares ONE batch object for every new set of queries (arenas and pinned
+    result blocks are kept, inputs travel with the execute). Shapes change from step to step — scored / docid pages /
+    NOT terms, batch sizes up and down — and every step is checked against the oracle."""
+    c, sizes, grams = _letter_grams(pair60k)
+    rng = np.random.default_rng(77)
+    batch = None
+    for step in range(8):
+        n = [5, 40, 3, 64, 1, 17, 33, 2][step]
+        queries = []
+        for i in range(n):
+            k = int(rng.integers(1, 4))
+            terms = [c.gram(int(g)).decode() for g in rng.choice(grams[:150], size=k, replace=False)]
+            if (step + i) % 3 == 0:
+                queries.append(Query(terms, limit=int(rng.choice([1, 10, 100])), descending=bool(i % 2)))
+            elif (step + i) % 3 == 1:
+                queries.append(Query(terms, sort_score=True, limit=int(rng.choice([1, 10, 50])), offset=i % 4))
+            else:
+                nt = [c.gram(int(rng.choice(grams[:300]))).decode()]
+                queries.append(Query(terms, nt, sort_score=True, limit=10))
+        batch = pair60k.dev.prepare(queries, into=batch)
+        for _ in range(2):  # a prepared batch still executes repeatedly
+            batch.execute()
+            got = batch.fetch()
+        for q, g in zip(queries, got):
+            total, page, scores, r = pair60k.oracle_query(q)
+            assert g.total == total and g.docs.tolist() == page.tolist(), (step, q.terms)
+            if scores is not None:
+                assert np.array_equal(g.scores, scores), (step, q.terms)
+
+
+def test_search_and_limit_max_u32_does_not_hang(pair60k):
+    """SearchAnd(terms, UINT32_MAX) must neither wrap the page size nor spin (index.cpp:356-367 semantics:
+    a limit beyond the result size returns everything)."""
+    c, sizes, grams = _letter_grams(pair60k)
+    terms = [c.gram(int(grams[3])).decode(), c.gram(int(grams[9])).decode()]
+    want = pair60k.oidx.search_and(terms, 0, False).tolist()
+    assert pair60k.dev.search_and(terms, 0xFFFFFFFF, False).tolist() == want
+    assert pair60k.dev.search_and(terms, 0xFFFFFFFF, True).tolist() == want[::-1]
+    assert pair60k.dev.search_and(terms, 1 << 40, False).tolist() == want

@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert L.mgx_abi_version() == mg._capi.ABI_VERSION
 
 
+def test_shim_library_exports_every_declared_symbol():
+    from mygram_db_amd import _shim_capi as S
+    L = S.load()
+    src = open(os.path.join(ROOT, "include", "mygram_shim_c.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"\b(mgxs_[a-z0-9_]+)\s*\(", src))
+    assert declared == set(S.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
 def test_no_cpu_fallback_without_device():
     L = mg._capi.load()
     if L.mgx_device_count() > 0:
