@@ -672,25 +672,49 @@ struct QuerySpec {
   uint64_t total_docs = 0;       // N of ComputeIDF for the text-level terms
   uint32_t pat_off = 0, pat_len = 0;  // kModeTextDf specs: the term in the batch's pattern pool
   uint32_t vt_begin = 0;              // first of the query's verify patterns in the batch-wide array
+  // back to the freshly constructed state, keeping the vectors' storage (a re-prepared batch object compiles its new
+  // queries into the specs of the old ones)
+  void Clear() {
+    leaves.clear();
+    prog.clear();
+    score.clear();
+    explicit_ids.clear();
+    text_terms.clear();
+    verify_patterns.clear();
+    mode = kModeBitmap;
+    limit = offset = reverse = stack_depth = 0;
+    k1 = 1.2;
+    b = 0.75;
+    avgdl = 0.0;
+    list_postings = 0;
+    wave_ok = flat = fast_score_ok = true;
+    est_density = 0.0;
+    total_docs = 0;
+    pat_off = pat_len = vt_begin = 0;
+  }
 };
 
 struct Compiler {
   const mgx_index* idx;
   QuerySpec* q;
-  std::unordered_map<uint32_t, uint32_t> gram_leaf;
   uint32_t sp = 0;
 
   uint32_t GramLeaf(uint32_t g) {
-    auto it = gram_leaf.find(g);
-    if (it != gram_leaf.end()) return it->second;
+    // (a query has a handful of operands: a scan beats a hash map and allocates nothing)
+    for (uint32_t i = 0; i < q->leaves.size(); ++i) {
+      const DevLeaf& l = q->leaves[i];
+      if (g == MGX_GRAM_ABSENT ? (l.kind == kLeafRange && l.row == kNoRow && l.a == 0 && l.b == 0 && l.score_slot == kAbsentMark)
+                               : ((l.kind == kLeafList || l.kind == kLeafGramBitmap) && l.a == g))
+        return i;
+    }
     DevLeaf lf{};
     lf.score_slot = kNoSlot;
     if (g == MGX_GRAM_ABSENT) {  // known to the table, no posting in this shard: the empty slot range
       lf.kind = kLeafRange;
       lf.row = kNoRow;
+      lf.score_slot = kAbsentMark;  // (tells this operand from the expression compiler's own empty ranges)
       const uint32_t id = static_cast<uint32_t>(q->leaves.size());
       q->leaves.push_back(lf);
-      gram_leaf[g] = id;
       return id;
     }
     lf.a = g;
@@ -703,7 +727,6 @@ struct Compiler {
     }
     const uint32_t id = static_cast<uint32_t>(q->leaves.size());
     q->leaves.push_back(lf);
-    gram_leaf[g] = id;
     q->list_postings += idx->h_offsets[g + 1] - idx->h_offsets[g];
     return id;
   }
@@ -753,7 +776,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   if (in.n_terms == 0 || !in.terms) return Fail(MGX_ERR_INVALID_ARGUMENT, "query without positive terms");
   if (in.n_terms > MGX_MAX_TERMS || in.n_not_terms > MGX_MAX_TERMS || in.n_filters > MGX_MAX_TERMS)
     return Fail(MGX_ERR_OUT_OF_RANGE, "more than 64 terms / NOT terms / filters (query_parser.h:270-272)");
-  Compiler c{idx, out, {}, 0};
+  Compiler c{idx, out, 0};
   for (uint32_t i = 0; i < in.n_terms; ++i) {
     int rc = ValidateTerm(idx, in.terms[i], "term");
     if (rc) return rc;
@@ -1307,14 +1330,15 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
     list_begin[n] = static_cast<uint32_t>(items.size());
     for (uint32_t k = 0; k < items.size(); ++k) items[k].list = k;  // candidate lists stay grouped by query
-    // launch order: by doc range (coarsely), then by query, so concurrent workgroups share operand tiles in L2
+    // Launch order: by doc band (kSortTiles tiles), so concurrent workgroups share operand tiles in L2/MALL; inside a
+    // band by the query's largest gram (its bitmap and tf column are the lines the band re-reads most), dealt so that
+    // workgroup j — which runs on XCD j % 8 under round-robin dispatch, every XCD with its own L2 — gets a contiguous
+    // eighth of that order. One bucket pass (counts, offsets, scatter): a fresh batch is scheduled per step, and two
+    // stable sorts of ~12,000 items were a third of the host's compile time.
     static const uint32_t kSortTiles = std::getenv("MGX_SORT_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_SORT_TILES"))) : 16u;
-    std::stable_sort(items.begin(), items.end(), [](const DevItem& a, const DevItem& c) {
-      return a.tile_begin / kSortTiles < c.tile_begin / kSortTiles;
-    });
-    // Inside a doc band, workgroup j runs on XCD j % 8 (round-robin dispatch) and every XCD has its own L2: give each
-    // XCD the queries that share their largest gram, whose tf column and bitmap are the lines the band re-reads most.
     static const bool kXcdAffinity = std::getenv("MGX_XCD_AFFINITY") ? atoi(std::getenv("MGX_XCD_AFFINITY")) != 0 : true;
+    std::vector<uint32_t> order(n);  // queries in the order they appear inside a band
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
     if (kXcdAffinity && score_mode) {
       std::vector<uint32_t> heavy(n, 0);
       for (uint32_t i = 0; i < n; ++i) {
@@ -1328,20 +1352,30 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
           }
         }
       }
-      std::vector<DevItem> band;
-      for (size_t lo = 0; lo < items.size();) {
-        size_t hi = lo;
-        while (hi < items.size() && items[hi].tile_begin / kSortTiles == items[lo].tile_begin / kSortTiles) ++hi;
-        std::stable_sort(items.begin() + lo, items.begin() + hi,
-                         [&](const DevItem& a, const DevItem& c) { return heavy[a.query] < heavy[c.query]; });
-        const size_t m = hi - lo, per = (m + 7) / 8;
-        band.assign(items.begin() + lo, items.begin() + hi);
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return heavy[x] < heavy[y]; });
+    }
+    const uint32_t n_bands = n_tiles / kSortTiles + 1;
+    std::vector<uint32_t> band_at(n_bands + 1, 0);
+    for (const DevItem& it : items) band_at[it.tile_begin / kSortTiles + 1]++;
+    for (uint32_t k = 0; k < n_bands; ++k) band_at[k + 1] += band_at[k];
+    std::vector<DevItem> sorted(items.size());
+    {
+      std::vector<uint32_t> cur(band_at.begin(), band_at.end() - 1);
+      for (uint32_t oi = 0; oi < n; ++oi) {
+        const uint32_t i = order[oi];
+        for (uint32_t k = list_begin[i]; k < list_begin[i + 1]; ++k) sorted[cur[items[k].tile_begin / kSortTiles]++] = items[k];
+      }
+    }
+    if (kXcdAffinity && score_mode) {
+      for (uint32_t k = 0; k < n_bands; ++k) {
+        const size_t lo = band_at[k], m = band_at[k + 1] - lo, per = (m + 7) / 8;
         size_t w = lo;
         for (size_t r = 0; r < per; ++r)
           for (size_t x = 0; x < 8; ++x)
-            if (x * per + r < m) items[w++] = band[x * per + r];
-        lo = hi;
+            if (x * per + r < m) items[w++] = sorted[lo + x * per + r];
       }
+    } else {
+      items.swap(sorted);
     }
   }
   const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
@@ -1498,7 +1532,7 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         ds.mode = kModeTextDf;
         ds.pat_off = d.pat_off;
         ds.pat_len = d.pat_len;
-        Compiler c{idx, &ds, {}, 0};
+        Compiler c{idx, &ds, 0};
         double dens = 1.0;
         uint64_t mn = ~0ull;
         c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
@@ -1900,16 +1934,17 @@ int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queri
   if (!batch || (n_queries && !queries)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_reset: null argument");
   try {
     mgx_index* idx = batch->idx;
-    std::vector<mgx::QuerySpec> specs(n_queries);
-    for (uint32_t i = 0; i < n_queries; ++i) {
-      int rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
-      if (rc) {
-        mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
-        return rc;
-      }
+    std::vector<mgx::QuerySpec> specs = std::move(batch->specs);  // (their vectors' storage is compiled into again)
+    specs.resize(n_queries);
+    int rc = MGX_OK;
+    for (uint32_t i = 0; i < n_queries && rc == MGX_OK; ++i) {
+      specs[i].Clear();
+      rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
+      if (rc) mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
     }
     MGX_HIP(hipSetDevice(idx->device));
     mgx::ResetBatch(batch);
+    if (rc) return rc;  // (the batch is empty but usable)
     return mgx::PrepareInto(batch, idx, std::move(specs));
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_reset: ") + e.what());
@@ -2179,7 +2214,7 @@ int mgx_and(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint64_t limit
   if (limit > 0xFFFFFFFFull) limit = 0;
   try {
     mgx::QuerySpec q;
-    mgx::Compiler c{idx, &q, {}, 0};
+    mgx::Compiler c{idx, &q, 0};
     c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
     for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpAnd, c.GramLeaf(gram_ids[i]));
     if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_and: more than 40 lists");
@@ -2196,7 +2231,7 @@ int mgx_or(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t** out_
   if (n == 0) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_or: no grams");
   try {
     mgx::QuerySpec q;
-    mgx::Compiler c{idx, &q, {}, 0};
+    mgx::Compiler c{idx, &q, 0};
     c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
     for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpOr, c.GramLeaf(gram_ids[i]));
     if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_or: more than 40 lists");
@@ -2213,7 +2248,7 @@ int mgx_not(mgx_index* idx, const uint32_t* all_docs, uint64_t n_all, const uint
   if (n_all > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_not: too many docs");
   try {
     mgx::QuerySpec q;
-    mgx::Compiler c{idx, &q, {}, 0};
+    mgx::Compiler c{idx, &q, 0};
     // ids outside the index range cannot be in any posting list: they pass through untouched, in order
     std::vector<uint32_t> below, above;
     const uint64_t lo = idx->dev.first_doc_id, hi = lo + idx->dev.n_docs;
@@ -2269,7 +2304,7 @@ int mgx_threshold(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t
   if (n > 127) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_threshold: more than 127 grams");
   try {
     mgx::QuerySpec q;
-    mgx::Compiler c{idx, &q, {}, 0};
+    mgx::Compiler c{idx, &q, 0};
     c.Emit(mgx::kOpThreshBegin);
     for (uint32_t i = 0; i < n; ++i) c.Emit(mgx::kOpThreshAdd, c.GramLeaf(gram_ids[i]));
     c.Emit(mgx::kOpThreshEnd, threshold);

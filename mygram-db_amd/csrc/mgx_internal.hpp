@@ -40,6 +40,7 @@ struct DevLeaf {
   uint32_t row;         // the gram's skip row (tile_off), or kNoRow; filled by the host so kernels need not chase it
 };
 constexpr uint32_t kNoSlot = 0xFFu;
+constexpr uint32_t kAbsentMark = 0xFEu;  // score_slot of the empty-range operand that stands for MGX_GRAM_ABSENT
 constexpr int kWaveScoreSlots = 3;   // scored terms the wave kernel handles
 constexpr int kWaveBlock = 512;      // threads per workgroup of the wave kernel (8 autonomous waves share one BM25 table)
 constexpr int kWavesPerBlock = kWaveBlock / 64;
