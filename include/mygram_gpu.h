@@ -320,7 +320,9 @@ int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_c
 int mgx_score_documents_text(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint8_t* term_bytes,
                              const uint32_t* term_off, const double* idfs, uint32_t n_terms, double avg_doc_length,
                              double k1, double b, double* scores_out);
-/* ResultSorter::SortByScore. Arrays longer than 65,536 entries need a bounded page (0 < offset+limit <= 1024). */
+/* ResultSorter::SortByScore, any length, any page (limit 0 = all): a bounded page (offset+limit <= 1024) of a long
+ * array is selected by per-wave top-k scans + a merge, everything else by a full device sort of the (score, docid)
+ * pairs (the reference is benchmarked with OFFSET 10000, docs/releases/v1.3.5.md:238). n < 2^32. */
 int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* scores, uint64_t n, int descending,
                       uint32_t limit, uint32_t offset, uint32_t** out_docs, uint64_t* out_n);
 

@@ -670,6 +670,11 @@ struct QuerySpec {
   std::vector<TextTerm> text_terms;
   std::vector<std::string> verify_patterns;  // kOpVerifyText: every positive term's text
   uint64_t total_docs = 0;       // N of ComputeIDF for the text-level terms
+  // SORT _score pages the fused top-k does not hold (offset + limit > kMaxNeeded, or limit 0 = all): every match is
+  // materialised, scored and fully sorted (ResultSorter::SortByScore's own shape, result_sorter.cpp:661-716)
+  bool deep_score = false;
+  std::vector<uint32_t> deep_grams;  // the scored terms' gram ids (kNoRow: a gram this shard lacks)
+  std::vector<double> deep_idfs;
   uint32_t pat_off = 0, pat_len = 0;  // kModeTextDf specs: the term in the batch's pattern pool
   uint32_t vt_begin = 0;              // first of the query's verify patterns in the batch-wide array
   // back to the freshly constructed state, keeping the vectors' storage (a re-prepared batch object compiles its new
@@ -681,6 +686,9 @@ struct QuerySpec {
     explicit_ids.clear();
     text_terms.clear();
     verify_patterns.clear();
+    deep_score = false;
+    deep_grams.clear();
+    deep_idfs.clear();
     mode = kModeBitmap;
     limit = offset = reverse = stack_depth = 0;
     k1 = 1.2;
@@ -931,10 +939,24 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   if (in.sort == MGX_SORT_SCORE) {
     if (!idx->can_score) return Fail(MGX_ERR_NOT_IMPLEMENTED, "index was created without tf/doc_len columns");
     const uint64_t needed = static_cast<uint64_t>(in.offset) + in.limit;
-    if (in.limit == 0 || needed > kMaxNeeded)
-      return Fail(MGX_ERR_NOT_IMPLEMENTED,
-                  "fused SORT _score handles 0 < offset+limit <= 1024; page deeper through mgx_score_documents + "
-                  "mgx_sort_by_score");
+    if (in.limit == 0 || needed > kMaxNeeded) {
+      // deep page (the reference is benchmarked with OFFSET 10000): the full-sort fallback. The matches are
+      // materialised like a docid-ordered result, then scored and sorted whole at fetch time.
+      for (uint32_t i = 0; i < in.n_terms; ++i) {
+        const mgx_term& t = in.terms[i];
+        if (t.text != nullptr || t.n_grams != 1)
+          return Fail(MGX_ERR_NOT_IMPLEMENTED,
+                      "SORT _score beyond offset+limit 1024 with a text-level term: score with "
+                      "mgx_score_documents_text and page with mgx_sort_by_score");
+        out->deep_grams.push_back(t.gram_ids[0] == MGX_GRAM_ABSENT ? kNoRow : t.gram_ids[0]);
+        out->deep_idfs.push_back(t.idf);
+      }
+      out->deep_score = true;
+      out->mode = kModeBitmap;
+      if (out->leaves.size() > kMaxLeaves)
+        return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct operand lists in one query");
+      return MGX_OK;
+    }
     if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 16 scored terms");
     out->mode = kModeScore;
     out->total_docs = in.total_docs;
@@ -1459,7 +1481,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     MGX_HIP(b->d_take.Alloc(static_cast<size_t>(n) * 8));
     MGX_HIP(b->d_out_off.Alloc(static_cast<size_t>(n) * 8));
     std::vector<uint32_t> rev(n);
-    for (uint32_t i = 0; i < n; ++i) rev[i] = specs[g.qids[i]].reverse;
+    for (uint32_t i = 0; i < n; ++i) rev[i] = specs[g.qids[i]].deep_score ? 0u : specs[g.qids[i]].reverse;
     MGX_HIP(Upload(b->d_reverse, rev.data(), n));
     d.rbits = b->d_rbits.as<uint64_t>();
     d.tile_cnt = b->d_tile_cnt.as<uint32_t>();
@@ -1816,6 +1838,8 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   // ---- bitmap group: totals -> page sizes -> expand ----
   std::vector<uint64_t> totals, take, out_off;
   std::vector<uint32_t> bm_docs;
+  std::vector<std::vector<uint32_t>> deep_docs;
+  std::vector<std::vector<double>> deep_scores;
   if (!b->bitmap.qids.empty()) {
     mgx_batch::Group& g = b->bitmap;
     const size_t n = g.qids.size();
@@ -1828,7 +1852,7 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     uint64_t at = 0;
     for (size_t i = 0; i < n; ++i) {
       const QuerySpec& sp = b->specs[g.qids[i]];
-      take[i] = sp.limit == 0 ? totals[i] : std::min<uint64_t>(totals[i], sp.limit);
+      take[i] = (sp.limit == 0 || sp.deep_score) ? totals[i] : std::min<uint64_t>(totals[i], sp.limit);
       out_off[i] = at;
       at += take[i];
     }
@@ -1843,6 +1867,44 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
                               static_cast<uint32_t>(n), idx->dev.n_tiles, idx->dev.first_doc_id,
                               b->d_out.as<uint32_t>(), s));
       MGX_HIP(hipMemcpyAsync(bm_docs.data(), b->d_out.p, at * 4, hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+    }
+    // deep SORT _score pages: BM25Scorer::ScoreDocuments over every match, ResultSorter::SortByScore by a full sort
+    deep_docs.assign(n, {});
+    deep_scores.assign(n, {});
+    for (size_t i = 0; i < n; ++i) {
+      const QuerySpec& sp = b->specs[g.qids[i]];
+      if (!sp.deep_score || take[i] == 0) continue;
+      const uint64_t m = take[i];
+      const uint32_t lo = static_cast<uint32_t>(std::min<uint64_t>(sp.offset, m));
+      const uint32_t hi = sp.limit == 0 ? static_cast<uint32_t>(m)
+                                        : static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(lo) + sp.limit, m));
+      if (hi == lo) continue;
+      uint64_t n2 = 2048;
+      while (n2 < m) n2 <<= 1;
+      const uint32_t* cand = b->d_out.as<uint32_t>() + out_off[i];
+      DevBuf d_g, d_i, d_sc, d_k, d_d, d_pd, d_ps;
+      MGX_HIP(Upload(d_g, sp.deep_grams.data(), sp.deep_grams.size()));
+      MGX_HIP(Upload(d_i, sp.deep_idfs.data(), sp.deep_idfs.size()));
+      MGX_HIP(d_sc.Alloc(m * 8));
+      MGX_HIP(d_k.Alloc(n2 * 8));
+      MGX_HIP(d_d.Alloc(n2 * 4));
+      MGX_HIP(d_pd.Alloc(static_cast<size_t>(hi - lo) * 4));
+      MGX_HIP(d_ps.Alloc(static_cast<size_t>(hi - lo) * 8));
+      MGX_LAUNCH(LaunchScoreCandidates(idx->dev, cand, m, d_g.as<uint32_t>(), d_i.as<double>(),
+                                       static_cast<uint32_t>(sp.deep_grams.size()), sp.k1, sp.b, sp.avgdl,
+                                       d_sc.as<double>(), s));
+      MGX_HIP(hipMemsetAsync(d_k.as<uint64_t>() + m, 0, (n2 - m) * 8, s));
+      MGX_HIP(hipMemsetAsync(d_d.as<uint32_t>() + m, 0, (n2 - m) * 4, s));
+      MGX_LAUNCH(LaunchMakeSortKeys(cand, d_sc.as<double>(), m, sp.reverse ? 1 : 0, d_k.as<uint64_t>(),
+                                    d_d.as<uint32_t>(), s));
+      MGX_LAUNCH(LaunchSortPairs(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n2, s));
+      MGX_LAUNCH(LaunchSortPage(d_k.as<uint64_t>(), d_d.as<uint32_t>(), lo, hi, sp.reverse ? 1 : 0,
+                                d_pd.as<uint32_t>(), d_ps.as<double>(), s));
+      deep_docs[i].resize(hi - lo);
+      deep_scores[i].resize(hi - lo);
+      MGX_HIP(hipMemcpyAsync(deep_docs[i].data(), d_pd.p, static_cast<size_t>(hi - lo) * 4, hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipMemcpyAsync(deep_scores[i].data(), d_ps.p, static_cast<size_t>(hi - lo) * 8, hipMemcpyDeviceToHost, s));
       MGX_HIP(hipStreamSynchronize(s));
     }
   }
@@ -1875,9 +1937,10 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
     r.total = c[4];
     if (sc && b->merged_shards) r.total = override_tot[gi];
     if (pg && b->merged_shards) r.total = dp_totals[gi];
-    r.n_docs = sc   ? page_n[gi]
-               : pg ? static_cast<uint32_t>(std::min<uint64_t>(r.total, b->specs[qi].limit))
-                    : static_cast<uint32_t>(take[gi]);
+    r.n_docs = sc                         ? page_n[gi]
+               : pg                       ? static_cast<uint32_t>(std::min<uint64_t>(r.total, b->specs[qi].limit))
+               : b->specs[qi].deep_score ? static_cast<uint32_t>(deep_docs[gi].size())
+                                          : static_cast<uint32_t>(take[gi]);
     r.docs_begin = static_cast<uint32_t>(n_out);
     n_out += r.n_docs;
   }
@@ -1896,6 +1959,9 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
                   r.n_docs * sizeof(double));
     } else if (mode == kModeDocPage) {
       std::memcpy(dst, dp_docs + static_cast<size_t>(gi) * b->doc_page_stride, r.n_docs * sizeof(uint32_t));
+    } else if (b->specs[qi].deep_score) {
+      std::memcpy(dst, deep_docs[gi].data(), r.n_docs * sizeof(uint32_t));
+      std::memcpy(b->h_scores.data() + r.docs_begin, deep_scores[gi].data(), r.n_docs * sizeof(double));
     } else {
       std::memcpy(dst, bm_docs.data() + out_off[gi], r.n_docs * sizeof(uint32_t));
     }
@@ -2414,6 +2480,7 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
   if (out_n) *out_n = 0;
   if (!idx || !out_docs || !out_n || (n && (!results || !scores)))
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_sort_by_score: null argument");
+  if (n > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_sort_by_score: more than 2^32 - 1 entries");
   const uint64_t start = std::min<uint64_t>(offset, n);
   const uint64_t end = limit == 0 ? n : std::min<uint64_t>(start + limit, n);
   // (owned here until the call has succeeded: out-parameters stay NULL/0 on every failure path)
@@ -2428,9 +2495,33 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
   };
   if (end == start) return succeed();
   const bool bounded_page = limit != 0 && static_cast<uint64_t>(offset) + limit <= mgx::kMaxNeeded;
-  if (n > 65536 && !bounded_page) {
-    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED,
-                     "mgx_sort_by_score: more than 65536 entries need a bounded page (0 < offset+limit <= 1024)");
+  if (n > 4096 && !(bounded_page && n > 65536)) {
+    // the full-sort fallback (result_sorter.cpp:661-716 sorts whatever it is given; deep OFFSETs are benchmarked,
+    // docs/releases/v1.3.5.md:238): every pair sorted best first by the bitonic network, then the page is cut out
+    try {
+      std::lock_guard<std::mutex> lock(idx->mu);
+      MGX_HIP(hipSetDevice(idx->device));
+      uint64_t n2 = 2048;
+      while (n2 < n) n2 <<= 1;
+      DevBuf d_r, d_s, d_k, d_d, d_o;
+      MGX_HIP(mgx::Upload(d_r, results, n));
+      MGX_HIP(mgx::Upload(d_s, scores, n));
+      MGX_HIP(d_k.Alloc(n2 * 8));
+      MGX_HIP(d_d.Alloc(n2 * 4));
+      MGX_HIP(d_o.Alloc((end - start) * 4));
+      MGX_HIP(hipMemsetAsync(d_k.as<uint64_t>() + n, 0, (n2 - n) * 8, idx->stream));
+      MGX_HIP(hipMemsetAsync(d_d.as<uint32_t>() + n, 0, (n2 - n) * 4, idx->stream));
+      MGX_LAUNCH(mgx::LaunchMakeSortKeys(d_r.as<uint32_t>(), d_s.as<double>(), n, descending, d_k.as<uint64_t>(),
+                                         d_d.as<uint32_t>(), idx->stream));
+      MGX_LAUNCH(mgx::LaunchSortPairs(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n2, idx->stream));
+      MGX_LAUNCH(mgx::LaunchSortPage(d_k.as<uint64_t>(), d_d.as<uint32_t>(), static_cast<uint32_t>(start),
+                                     static_cast<uint32_t>(end), descending, d_o.as<uint32_t>(), nullptr, idx->stream));
+      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
+      MGX_HIP(hipStreamSynchronize(idx->stream));
+      return succeed();
+    } catch (const std::exception& e) {
+      return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
+    }
   }
   if (n > 65536) {
     // long arrays: per-wave top-(offset+limit) over strided shares, then the merge kernel of the batch path

@@ -2453,6 +2453,83 @@ __global__ void rank_count_kernel(const uint64_t* __restrict__ keys, const uint3
   if (rank >= lo && rank < hi) out[rank - lo] = descending ? d : ~d;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// full sort of (key, docid') pairs, best first: ResultSorter::SortByScore without a bound on offset + limit
+// ---------------------------------------------------------------------------------------------------------------
+//
+// The reference sorts (partial_sort / sort) whatever it is given (result_sorter.cpp:661-716) and is benchmarked with
+// OFFSET 10000 (docs/releases/v1.3.5.md:238); the fused top-k stops at offset+limit = 1024. Past that, and for
+// unbounded pages, the pairs are sorted whole by a bitonic network: runs of kSortRun elements in LDS (every stage
+// with j < kSortRun), the wider stages one compare-exchange per thread in HBM. O(n log^2 n) traffic — a fallback, not
+// a hot path (a 1M-entry sort moves ~5 GB). The comparator is better(): key, then docid'; padding entries (0,0) lose
+// to every real entry and end up at the tail.
+constexpr uint32_t kSortRun = 2048;  // elements sorted / merged per workgroup in LDS (24 KB)
+
+__device__ __forceinline__ void sort_cmpxchg(uint64_t* k, uint32_t* d, uint32_t i, uint32_t l, bool best_first) {
+  const uint64_t ki = k[i], kl = k[l];
+  const uint32_t di = d[i], dl = d[l];
+  const bool swap = best_first ? better(kl, dl, ki, di) : better(ki, di, kl, dl);
+  if (swap) {
+    k[i] = kl; d[i] = dl;
+    k[l] = ki; d[l] = di;
+  }
+}
+
+// Stages (k = kfirst..klast doubling, j = min(k/2, kSortRun/2)..1) of the network on this block's run, in LDS.
+// kfirst == 2: sorts the run from scratch; kfirst == klast >= kSortRun * 2... : finishes a wide stage's small strides.
+__global__ __launch_bounds__(kBlock) void sort_local_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ docs,
+                                                            uint64_t kfirst, uint64_t klast) {
+  __shared__ uint64_t sk[kSortRun];
+  __shared__ uint32_t sd[kSortRun];
+  const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kSortRun;
+  for (uint32_t e = threadIdx.x; e < kSortRun; e += kBlock) {
+    sk[e] = keys[base + e];
+    sd[e] = docs[base + e];
+  }
+  __syncthreads();
+  for (uint64_t k = kfirst; k <= klast; k <<= 1) {
+    for (uint32_t j = static_cast<uint32_t>(k / 2 < kSortRun / 2 ? k / 2 : kSortRun / 2); j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < kSortRun / 2; t += kBlock) {
+        const uint32_t i = 2 * t - (t & (j - 1));  // the lower index of pair t at stride j
+        const bool best_first = ((base + i) & k) == 0;
+        sort_cmpxchg(sk, sd, i, i + j, best_first);
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t e = threadIdx.x; e < kSortRun; e += kBlock) {
+    keys[base + e] = sk[e];
+    docs[base + e] = sd[e];
+  }
+}
+
+// One compare-exchange per thread at stride j >= kSortRun of stage k, in HBM.
+__global__ void sort_global_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ docs, uint64_t n_pairs,
+                                   uint64_t k, uint64_t j) {
+  const uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n_pairs) return;
+  const uint64_t i = 2 * t - (t & (j - 1));
+  const uint64_t l = i + j;
+  const uint64_t ki = keys[i], kl = keys[l];
+  const uint32_t di = docs[i], dl = docs[l];
+  const bool best_first = (i & k) == 0;
+  const bool swap = best_first ? better(kl, dl, ki, di) : better(ki, di, kl, dl);
+  if (swap) {
+    keys[i] = kl; docs[i] = dl;
+    keys[l] = ki; docs[l] = di;
+  }
+}
+
+// page[i] = docid of rank lo + i, scores likewise (scores may be null)
+__global__ void sort_page_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ dprime, uint32_t lo,
+                                 uint32_t hi, int descending, uint32_t* __restrict__ out_docs,
+                                 double* __restrict__ out_scores) {
+  const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  out_docs[i - lo] = descending ? dprime[i] : ~dprime[i];
+  if (out_scores) out_scores[i - lo] = key_score(keys[i], descending != 0);
+}
+
 // SortByScore over an arbitrarily long (key, docid') array when only a bounded page is wanted: every wave keeps the
 // best `needed` of a strided share of the array (WaveTopK, as in the scoring kernels) and leaves them as one sorted
 // candidate list; merge_topk_kernel then merges the lists like the per-workgroup lists of a query.
@@ -2759,6 +2836,34 @@ int LaunchTopKScan(const uint64_t* keys, const uint32_t* dprime, uint64_t n, uin
   }
   hipLaunchKernelGGL(topk_scan_kernel, dim3(n_blocks), dim3(kBlock), lds, s, keys, dprime, n, needed, cap, descending,
                      cand_keys, cand_docs, cand_n);
+  MGX_KCHECK();
+  return 0;
+}
+
+// Sorts the first n_pow2 (a power of two >= kSortRun, padding = (0,0)) pairs best first, in place.
+int LaunchSortPairs(uint64_t* keys, uint32_t* dprime, uint64_t n_pow2, hipStream_t s) {
+  if (n_pow2 < kSortRun || (n_pow2 & (n_pow2 - 1)) != 0) return static_cast<int>(hipErrorInvalidValue);
+  const uint32_t runs = static_cast<uint32_t>(n_pow2 / kSortRun);
+  hipLaunchKernelGGL(sort_local_kernel, dim3(runs), dim3(kBlock), 0, s, keys, dprime, 2ull, static_cast<uint64_t>(kSortRun));
+  MGX_KCHECK();
+  for (uint64_t k = 2ull * kSortRun; k <= n_pow2; k <<= 1) {
+    for (uint64_t j = k / 2; j >= kSortRun; j >>= 1) {
+      const uint64_t pairs = n_pow2 / 2;
+      hipLaunchKernelGGL(sort_global_kernel, dim3(static_cast<uint32_t>((pairs + 255) / 256)), dim3(256), 0, s, keys,
+                         dprime, pairs, k, j);
+      MGX_KCHECK();
+    }
+    hipLaunchKernelGGL(sort_local_kernel, dim3(runs), dim3(kBlock), 0, s, keys, dprime, k, k);
+    MGX_KCHECK();
+  }
+  return 0;
+}
+
+int LaunchSortPage(const uint64_t* keys, const uint32_t* dprime, uint32_t lo, uint32_t hi, int descending,
+                   uint32_t* out_docs, double* out_scores, hipStream_t s) {
+  if (hi <= lo) return 0;
+  hipLaunchKernelGGL(sort_page_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, s, keys, dprime, lo, hi, descending,
+                     out_docs, out_scores);
   MGX_KCHECK();
   return 0;
 }

@@ -46,6 +46,9 @@ int LaunchScoreCandidatesText(const DevIndex& ix, const uint32_t* cand, uint64_t
 int LaunchTopKScan(const uint64_t* keys, const uint32_t* dprime, uint64_t n, uint32_t needed, uint32_t cap,
                    int descending, uint32_t n_blocks, uint64_t* cand_keys, uint32_t* cand_docs, uint32_t* cand_n,
                    hipStream_t s);
+int LaunchSortPairs(uint64_t* keys, uint32_t* dprime, uint64_t n_pow2, hipStream_t s);
+int LaunchSortPage(const uint64_t* keys, const uint32_t* dprime, uint32_t lo, uint32_t hi, int descending,
+                   uint32_t* out_docs, double* out_scores, hipStream_t s);
 int LaunchMakeSortKeys(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint64_t* keys,
                        uint32_t* dprime, hipStream_t s);
 int LaunchSortByScore(const uint32_t* docs, const double* scores, uint64_t n, int descending, uint32_t lo,

@@ -459,3 +459,38 @@ def test_search_and_limit_max_u32_does_not_hang(pair60k):
     assert pair60k.dev.search_and(terms, 0xFFFFFFFF, False).tolist() == want
     assert pair60k.dev.search_and(terms, 0xFFFFFFFF, True).tolist() == want[::-1]
     assert pair60k.dev.search_and(terms, 1 << 40, False).tolist() == want
+
+
+def test_deep_offset_pages_full_sort(pair60k):
+    """R15 beyond the fused top-k: OFFSET 10000 LIMIT 100 (the reference's own deep-paging benchmark,
+    docs/releases/v1.3.5.md:238), offset+limit just past 1024, an unbounded page, ASC order — through the batched entry:
+    every match scored, ResultSorter::SortByScore by a full device sort. Bit-exact docids and scores."""
+    c, sizes, grams = _letter_grams(pair60k)
+    top = [c.gram(int(g)).decode() for g in grams[:6]]
+    queries = [
+        Query([top[0], top[1]], sort_score=True, limit=100, offset=10000),
+        Query([top[0], top[2]], sort_score=True, limit=100, offset=10000, descending=False),
+        Query([top[1], top[3], top[4]], sort_score=True, limit=1000, offset=25),       # 1025 > kMaxNeeded
+        Query([top[2], top[5]], sort_score=True, limit=0, offset=0),                   # every match, ranked
+        Query([top[0]], [top[1]], sort_score=True, limit=50, offset=3000),             # with a NOT term
+        Query([top[3], top[4]], sort_score=True, limit=10, offset=10_000_000),         # past the end: empty page
+        Query([top[0], top[1]], sort_score=True, limit=10),                            # a fused page in the same batch
+    ]
+    got = pair60k.check(queries)
+    assert len(got[0].docs) == 100 and got[0].total > 10100
+    assert len(got[3].docs) == got[3].total
+    assert len(got[5].docs) == 0 and got[5].total > 0
+
+
+def test_sort_by_score_any_length(pair60k):
+    """ResultSorter::SortByScore stand-alone (result_sorter.cpp:661-716) on arrays the old path refused: 200,000 and
+    70,000 entries with many ties, deep offsets and unbounded pages, both orders."""
+    rng = np.random.default_rng(12)
+    for n in (200_000, 70_000, 5_000, 4_097):
+        docs = rng.permutation(np.arange(1, n + 1, dtype=np.uint32))
+        scores = np.round(rng.random(n) * 50) / 7.0  # ~50 distinct values: ties everywhere
+        for desc, limit, offset in [(True, 100, 10000), (False, 0, 0), (True, 0, n - 10), (False, 1000, 1500),
+                                    (True, 10, 0), (True, 5, n + 3)]:
+            want = O.sort_by_score(docs, scores, desc, limit, offset)
+            got = pair60k.dev.sort_by_score(docs, scores, desc, limit, offset)
+            assert got.tolist() == want.tolist(), (n, desc, limit, offset)
