@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 1U
+#define MGX_ABI_VERSION 2U
 
 /* Values of mygram::utils::ErrorCode used on this path (src/utils/error.h:37-48,100). */
 #define MGX_OK 0
@@ -79,13 +79,19 @@ typedef struct mgx_columns_view {
   const uint32_t* key_off;   /* n_grams+1 */
   const uint64_t* offsets;   /* n_grams+1, CSR into docids/tf */
   const uint32_t* docids;    /* ascending per gram */
-  const uint8_t* tf;         /* non-overlapping occurrence count of the gram's bytes in the doc text, saturated at 255 */
+  const uint8_t* tf;         /* non-overlapping occurrence count of the gram's bytes in the doc text; 255 = "255 or more,
+                              * see tf_overflow" */
   uint64_t n_postings;
   uint32_t first_doc_id;     /* doc d has local slot d - first_doc_id */
   uint64_t n_docs;           /* slots */
   const uint32_t* doc_len;   /* n_docs: CountCodePoints(text) (string_utils.cpp:655-669); 0 for empty text */
   uint64_t bm25_doc_count;   /* docs with non-empty text (server_types.h:157-193) */
   uint64_t bm25_total_len;   /* sum of their doc_len */
+  /* postings whose count does not fit the byte column: their index into docids/tf (ascending) and the true count, so
+   * that BM25 sees exactly what CountTermOccurrences (bm25_scorer.cpp:27-45) returns for any document */
+  const uint64_t* tf_overflow_pos;
+  const uint32_t* tf_overflow_val;
+  uint64_t n_tf_overflow;
 } mgx_columns_view;
 
 /* Docs are first_doc_id, first_doc_id+1, ...; doc i's normalized text is text_bytes[text_off[i] .. text_off[i+1]). */
@@ -121,6 +127,11 @@ typedef struct mgx_index_desc {
    * 0 => default (1/256: at most 8x the bytes of the u32 list, bought for latency: bitmap operands need no scatter
    * and BM25 runs on the wave-autonomous kernel); >= 2 => disabled. */
   double dense_threshold;
+  /* side table of the tf bytes that read 255 (mgx_columns_view.tf_overflow_*): posting indices ascending; may be
+   * NULL / 0 (then 255 is taken literally) */
+  const uint64_t* tf_overflow_pos;
+  const uint32_t* tf_overflow_val;
+  uint64_t n_tf_overflow;
 } mgx_index_desc;
 
 /* Host arrays are copied; the caller keeps ownership. */

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MGX_LIBRARY: tools only (e.g. the -DMGX_ABLATION build of `make ablation`); the product is libmygram_gpu.so
 LIB_PATH = os.environ.get("MGX_LIBRARY") or os.path.join(_HERE, "libmygram_gpu.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 GRAM_ABSENT = 0xFFFFFFFF
 SORT_DOCID, SORT_SCORE = 0, 1
 
@@ -36,14 +36,16 @@ class ColumnsView(C.Structure):
     _fields_ = [("n_grams", C.c_uint64), ("key_bytes", C.c_void_p), ("key_off", C.c_void_p),
                 ("offsets", C.c_void_p), ("docids", C.c_void_p), ("tf", C.c_void_p), ("n_postings", C.c_uint64),
                 ("first_doc_id", C.c_uint32), ("n_docs", C.c_uint64), ("doc_len", C.c_void_p),
-                ("bm25_doc_count", C.c_uint64), ("bm25_total_len", C.c_uint64)]
+                ("bm25_doc_count", C.c_uint64), ("bm25_total_len", C.c_uint64),
+                ("tf_overflow_pos", C.c_void_p), ("tf_overflow_val", C.c_void_p), ("n_tf_overflow", C.c_uint64)]
 
 
 class IndexDesc(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32), ("device", C.c_int32),
                 ("tile_shift", C.c_uint32), ("first_doc_id", C.c_uint32), ("n_docs", C.c_uint64),
                 ("n_grams", C.c_uint64), ("offsets", C.c_void_p), ("docids", C.c_void_p), ("tf", C.c_void_p),
-                ("doc_len", C.c_void_p), ("dense_threshold", C.c_double)]
+                ("doc_len", C.c_void_p), ("dense_threshold", C.c_double),
+                ("tf_overflow_pos", C.c_void_p), ("tf_overflow_val", C.c_void_p), ("n_tf_overflow", C.c_uint64)]
 
 
 class Term(C.Structure):

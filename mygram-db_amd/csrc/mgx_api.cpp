@@ -234,7 +234,7 @@ struct mgx_index {
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
-  DevBuf d_dl8, d_tfnib;
+  DevBuf d_dl8, d_tfnib, d_tf_ovf_pos, d_tf_ovf_val;
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -437,6 +437,17 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   MGX_HIP(mgx::Upload(idx->d_docids, d->docids, P, 4));
   uint32_t max_doc_len = 0;
   if (idx->can_score) {
+    if (d->n_tf_overflow) {
+      if (!d->tf_overflow_pos || !d->tf_overflow_val || d->n_tf_overflow > 0xFFFFFFFFull)
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_create: bad tf overflow table");
+      for (uint64_t i = 0; i < d->n_tf_overflow; ++i)
+        if (d->tf_overflow_pos[i] >= P || (i && d->tf_overflow_pos[i] <= d->tf_overflow_pos[i - 1]) ||
+            d->tf[d->tf_overflow_pos[i]] != 255 || d->tf_overflow_val[i] < 255)
+          return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
+                           "mgx_index_create: tf overflow entries must ascend, point at tf bytes of 255 and hold counts >= 255");
+      MGX_HIP(mgx::Upload(idx->d_tf_ovf_pos, d->tf_overflow_pos, d->n_tf_overflow));
+      MGX_HIP(mgx::Upload(idx->d_tf_ovf_val, d->tf_overflow_val, d->n_tf_overflow));
+    }
     MGX_HIP(mgx::Upload(idx->d_tf, d->tf, P, 4));
     MGX_HIP(mgx::Upload(idx->d_doc_len, d->doc_len, n_docs));
     for (uint64_t i = 0; i < n_docs; ++i) max_doc_len = std::max(max_doc_len, d->doc_len[i]);
@@ -513,6 +524,9 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.offsets = idx->d_offsets.as<uint64_t>();
   v.docids = idx->d_docids.as<uint32_t>();
   v.tf = idx->d_tf.as<uint8_t>();
+  v.tf_ovf_pos = idx->d_tf_ovf_pos.as<uint64_t>();
+  v.tf_ovf_val = idx->d_tf_ovf_val.as<uint32_t>();
+  v.n_tf_ovf = idx->can_score ? static_cast<uint32_t>(d->n_tf_overflow) : 0u;
   v.doc_len = idx->d_doc_len.as<uint32_t>();
   v.dl8 = idx->d_dl8.as<uint8_t>();
   v.tfnib = idx->d_tfnib.as<uint8_t>();

@@ -195,6 +195,9 @@ struct Columns {
   std::vector<uint64_t> offsets;
   std::vector<uint32_t> docids;
   std::vector<uint8_t> tf;
+  // postings whose count does not fit the byte column (tf >= 255): (posting index, true tf), ascending by index
+  std::vector<uint64_t> tf_ovf_pos;
+  std::vector<uint32_t> tf_ovf_val;
   std::vector<uint32_t> doc_len;
   uint32_t first_doc_id = 0;
   uint64_t n_docs = 0, bm25_doc_count = 0, bm25_total_len = 0;
@@ -293,6 +296,8 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
   struct ChunkOut {
     std::vector<uint32_t> ids;      // concatenated per doc, ascending gram id
     std::vector<uint8_t> tfs;
+    std::vector<uint32_t> big;      // true tf of the entries whose byte saturated (255), in entry order
+    std::vector<std::pair<uint64_t, uint32_t>> ovf;  // (posting index, true tf) once the lists are laid out
     std::vector<uint32_t> per_doc;  // number of entries per doc
     std::vector<uint32_t> counts;   // per gram
   };
@@ -330,7 +335,8 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
           }
         }
         o.ids.push_back(id);
-        o.tfs.push_back(static_cast<uint8_t>(tf > 255 ? 255 : tf));
+        o.tfs.push_back(static_cast<uint8_t>(tf >= 255 ? 255 : tf));
+        if (tf >= 255) o.big.push_back(tf);
         o.counts[id]++;
         ++emitted;
         i = j;
@@ -360,7 +366,7 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
   run_chunks([&](uint64_t c, DocScratch&) {
     ChunkOut& o = outs[c];
     const uint64_t d0 = c * chunk_docs;
-    size_t at = 0;
+    size_t at = 0, big_at = 0;
     for (size_t di = 0; di < o.per_doc.size(); ++di) {
       const uint32_t doc = first_doc_id + static_cast<uint32_t>(d0 + di);
       for (uint32_t e = 0; e < o.per_doc[di]; ++e, ++at) {
@@ -368,11 +374,21 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
         const uint64_t pos = cols->offsets[id] + o.counts[id]++;
         cols->docids[pos] = doc;
         cols->tf[pos] = o.tfs[at];
+        if (o.tfs[at] == 255) o.ovf.emplace_back(pos, o.big[big_at++]);
       }
     }
     ChunkOut().ids.swap(o.ids);
     ChunkOut().tfs.swap(o.tfs);
   });
+  {
+    std::vector<std::pair<uint64_t, uint32_t>> all;
+    for (const ChunkOut& o : outs) all.insert(all.end(), o.ovf.begin(), o.ovf.end());
+    std::sort(all.begin(), all.end());
+    for (const auto& e : all) {
+      cols->tf_ovf_pos.push_back(e.first);
+      cols->tf_ovf_val.push_back(e.second);
+    }
+  }
   *out = cols.release();
   return MGX_OK;
 }
@@ -390,6 +406,9 @@ void ColumnsView(const Columns* c, mgx_columns_view* v) {
   v->doc_len = c->doc_len.data();
   v->bm25_doc_count = c->bm25_doc_count;
   v->bm25_total_len = c->bm25_total_len;
+  v->tf_overflow_pos = c->tf_ovf_pos.data();
+  v->tf_overflow_val = c->tf_ovf_val.data();
+  v->n_tf_overflow = c->tf_ovf_pos.size();
 }
 
 bool ColumnsLookup(const Columns* c, const uint8_t* gram, size_t len, uint32_t* id) {

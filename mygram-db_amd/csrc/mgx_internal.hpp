@@ -110,6 +110,9 @@ struct DevIndex {
   const uint64_t* offsets;
   const uint32_t* docids;
   const uint8_t* tf;
+  const uint64_t* tf_ovf_pos;  // postings whose tf byte is saturated (255): index, ascending ...
+  const uint32_t* tf_ovf_val;  // ... and true count
+  uint32_t n_tf_ovf;
   const uint32_t* doc_len;
   const uint8_t* dl8;         // [n_docs] min(doc_len, 255)
   const uint8_t* tfnib;       // [bitmap rows][nib_row_stride] min(tf,15) by doc slot, two docs per byte (0 = absent)

@@ -74,6 +74,21 @@ __device__ __forceinline__ uint64_t lower_bound_u32(const uint32_t* __restrict__
   return lo;
 }
 
+// tf of posting p: the byte column, or — where the byte is saturated — the side table of true counts
+// (CountTermOccurrences has no ceiling, bm25_scorer.cpp:27-45; a doc that repeats a gram 300 times must score as such)
+__device__ __forceinline__ uint32_t posting_tf(const DevIndex& ix, uint64_t p) {
+  uint32_t v = ix.tf[p];
+  if (v == 255u && ix.n_tf_ovf != 0) {
+    uint32_t lo = 0, hi = ix.n_tf_ovf;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (ix.tf_ovf_pos[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    if (lo < ix.n_tf_ovf && ix.tf_ovf_pos[lo] == p) v = ix.tf_ovf_val[lo];
+  }
+  return v;
+}
+
 __device__ __forceinline__ uint64_t score_key(double s, bool descending) {
   uint64_t u = static_cast<uint64_t>(__double_as_longlong(s));
   u = (u >> 63) ? ~u : (u | 0x8000000000000000ull);  // total order of IEEE doubles as unsigned integers
@@ -860,7 +875,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
               const uint64_t wbits = bm64[st.leaf * kBlock + word];
               if ((wbits >> bit) & 1ull) {
                 const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
-                tf = static_cast<double>(ix.tf[seg_lo[st.leaf] + rank]);
+                tf = static_cast<double>(posting_tf(ix, seg_lo[st.leaf] + rank));
               }
             }
             if (tf > 0.0) {
@@ -1095,7 +1110,7 @@ __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uin
   }
   const uint32_t d = ix.first_doc_id + slot;
   const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
-  return (p < hi && ix.docids[p] == d) ? ix.tf[p] : 0u;
+  return (p < hi && ix.docids[p] == d) ? posting_tf(ix, p) : 0u;
 }
 
 __device__ __forceinline__ void wave_score_body(const DevIndex ix, const DevBatch bt, const WavePlan plan) {
@@ -2386,7 +2401,7 @@ __global__ void score_candidates_kernel(DevIndex ix, const uint32_t* __restrict_
         }
         const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
         if (p < hi && ix.docids[p] == d) {
-          const double tf = static_cast<double>(ix.tf[p]);
+          const double tf = static_cast<double>(posting_tf(ix, p));
           const double numerator = tf * k1_plus_1;
           const double denominator = tf + k1 * length_norm;
           score += idfs[t] * numerator / denominator;

@@ -281,7 +281,8 @@ std::string Index::Finalize() const {
   mgx_columns_view_get(impl_->cols, &impl_->view);
   const auto& v = impl_->view;
   mgx_index_desc d{sizeof(mgx_index_desc), MGX_ABI_VERSION, impl_->device, 0, v.first_doc_id, v.n_docs, v.n_grams,
-                   v.offsets,               v.docids,        v.tf,          v.doc_len, impl_->dense_threshold};
+                   v.offsets,               v.docids,        v.tf,          v.doc_len, impl_->dense_threshold,
+                   v.tf_overflow_pos,       v.tf_overflow_val, v.n_tf_overflow};
   if (mgx_index_create(&d, &impl_->dev) != MGX_OK) {
     impl_->last_error = mgx_last_error();
     impl_->dev = nullptr;

@@ -180,6 +180,8 @@ class Columns:
         self.docids = _np_view(v.docids, self.n_postings, np.uint32)
         self.tf = _np_view(v.tf, self.n_postings, np.uint8)
         self.doc_len = _np_view(v.doc_len, self.n_docs, np.uint32)
+        self.tf_overflow_pos = _np_view(v.tf_overflow_pos, int(v.n_tf_overflow), np.uint64)
+        self.tf_overflow_val = _np_view(v.tf_overflow_val, int(v.n_tf_overflow), np.uint32)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -208,7 +210,9 @@ class DeviceIndex:
         v = columns.view
         d = _capi.IndexDesc(C.sizeof(_capi.IndexDesc), _capi.ABI_VERSION, device, 0, v.first_doc_id, v.n_docs,
                             v.n_grams, v.offsets, v.docids, v.tf if with_scoring else None,
-                            v.doc_len if with_scoring else None, dense_threshold)
+                            v.doc_len if with_scoring else None, dense_threshold,
+                            v.tf_overflow_pos if with_scoring else None, v.tf_overflow_val if with_scoring else None,
+                            v.n_tf_overflow if with_scoring else 0)
         h = C.c_void_p()
         check(L.mgx_index_create(C.byref(d), C.byref(h)))
         self._h = h

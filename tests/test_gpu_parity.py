@@ -358,7 +358,7 @@ def test_saturated_tf_and_long_docs(score_kernel):
 
 def test_sort_by_score_long_arrays():
     # ResultSorter::SortByScore over more entries than the rank-by-counting kernel takes: bounded pages go through the
-    # per-wave top-k scan + merge; an unbounded sort of a long array is refused
+    # per-wave top-k scan + merge, an unbounded sort through the full device sort
     idx = mg.Index(texts=["x"], ngram_size=1)
     rng = np.random.default_rng(31)
     n = 300_000
@@ -368,8 +368,7 @@ def test_sort_by_score_long_arrays():
         got = idx.sort_by_score(docs, scores, desc, limit, offset)
         want = O.sort_by_score(docs, scores, desc, limit, offset)
         assert got.tolist() == want.tolist(), (desc, limit, offset)
-    with pytest.raises(mg._capi.MgxError):
-        idx.sort_by_score(docs, scores, True, 0, 0)
+    assert idx.sort_by_score(docs, scores, True, 0, 0).tolist() == O.sort_by_score(docs, scores, True, 0, 0).tolist()
 
 
 # ---- exact-text post-filter (PostFilterByText) ------------------------------------------------------------------------
@@ -494,3 +493,29 @@ def test_sort_by_score_any_length(pair60k):
             want = O.sort_by_score(docs, scores, desc, limit, offset)
             got = pair60k.dev.sort_by_score(docs, scores, desc, limit, offset)
             assert got.tolist() == want.tolist(), (n, desc, limit, offset)
+
+
+@pytest.mark.parametrize("dense", DENSE)
+def test_tf_beyond_the_byte_column(dense, monkeypatch):
+    """A document that repeats an n-gram 300 times (tf byte saturated at 255, doc length past the dl8 escape) scores as
+    the reference scores it: the true count comes from the overflow table — fused wave kernel, general kernel, stand-alone
+    ScoreDocuments."""
+    rng = np.random.default_rng(5)
+    words = ["ab", "cd", "abcd", "xy", "cdab", "zz"]
+    texts = [" ".join(rng.choice(words, size=int(rng.integers(2, 9)))) for _ in range(3000)]
+    texts[17] = "ab" * 300 + " cd"
+    texts[1234] = "cd " + "ab" * 255
+    texts[2000] = "ab" * 254 + " cd cd"
+    texts[2999] = "cd" * 400 + "ab"
+    pair = Pair(docs=list(enumerate(texts, start=1)), dense_threshold=dense)
+    qs = [Query(["ab", "cd"], sort_score=True, limit=20), Query(["ab"], sort_score=True, limit=5),
+          Query(["cd", "ab"], sort_score=True, limit=20, descending=False), Query(["ab", "cd"], sort_score=True, limit=50, offset=2000)]
+    got = pair.check(qs)
+    assert {18, 1235, 2001, 3000} & set(got[2].docs.tolist())  # (the long docs rank last: they lead the ASC page)
+    monkeypatch.setenv("MGX_FORCE_BLOCK_KERNEL", "1")
+    pair.check(qs)
+    monkeypatch.delenv("MGX_FORCE_BLOCK_KERNEL")
+    cand = np.asarray([17, 18, 1235, 2001, 3000, 5], dtype=np.uint32)
+    dfs = [pair.dev.posting_size("ab"), pair.dev.posting_size("cd")]
+    want = O.score_documents(pair.ostore, cand, ["ab", "cd"], dfs, pair.N, pair.avgdl)
+    assert np.array_equal(pair.dev.score_documents(cand, ["ab", "cd"], dfs, pair.N, pair.avgdl), want)

@@ -63,9 +63,12 @@ def _check_columns_against_oracle(texts, first_doc_id, ngram, kanji, cross):
         lo, hi = int(cols.offsets[g]), int(cols.offsets[g + 1])
         want = oidx.search_and([key])
         assert cols.docids[lo:hi].tolist() == want.tolist(), key
+        ovf = dict(zip(cols.tf_overflow_pos.tolist(), cols.tf_overflow_val.tolist()))
         for p in range(lo, hi):
             text = texts[int(cols.docids[p]) - first_doc_id]
-            assert cols.tf[p] == min(255, O.count_term_occurrences(text, key)), (key, text)
+            want = O.count_term_occurrences(text, key)
+            assert cols.tf[p] == min(255, want), (key, text)
+            assert (ovf.get(p) == want) if want >= 255 else (p not in ovf), (key, want)
         assert cols.lookup(key) == g
     assert cols.lookup("\x01\x02") is None
     for i, t in enumerate(texts):
@@ -149,3 +152,14 @@ def test_index_create_checks_its_contract_before_any_device_write(first, n_docs,
     rc = mg._capi.load().mgx_index_create(C.byref(d), C.byref(h))
     assert rc == code and h.value is None
     assert what in mg._capi.load().mgx_last_error().decode()
+
+
+def test_columns_tf_overflow_table():
+    """CountTermOccurrences has no ceiling (bm25_scorer.cpp:27-45): counts of 255 and more keep their true value in the
+    side table next to the saturated byte column."""
+    texts = ["ab" * 300, "ab" * 255 + " x", "ab" * 254, "xyab", "a" * 700, ""]
+    _check_columns_against_oracle(texts, 1, 2, 0, True)
+    cols = mg.Columns(mg.Corpus.from_texts(texts), 1, 2, 0, True)
+    # "ab" x255, "ba" inside "ab" x300, "ab" x300, "aa" in 700 a's
+    assert sorted(cols.tf_overflow_val.tolist()) == [255, 299, 300, 350]
+    assert np.all(np.diff(cols.tf_overflow_pos.astype(np.int64)) > 0)
