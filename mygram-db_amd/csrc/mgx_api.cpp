@@ -968,10 +968,10 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
       out->deep_score = true;
       out->mode = kModeBitmap;
       if (out->leaves.size() > kMaxLeaves)
-        return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct operand lists in one query");
+        return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 192 distinct operands in one query");
       return MGX_OK;
     }
-    if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 16 scored terms");
+    if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 64 scored terms");
     out->mode = kModeScore;
     out->total_docs = in.total_docs;
     for (uint32_t i = 0; i < in.n_terms; ++i) {
@@ -1018,7 +1018,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     return Fail(MGX_ERR_INVALID_ARGUMENT, "unknown sort");
   }
   if (out->leaves.size() > kMaxLeaves)
-    return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct operand lists in one query");
+    return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 192 distinct operands in one query");
   return MGX_OK;
 }
 
@@ -1122,7 +1122,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   std::vector<uint32_t> prog;
   std::vector<DevScoreTerm> score;
   std::vector<uint32_t> expl;
-  uint32_t max_leaves = 0, max_score = 0, max_stack = 0, max_instr = 0, max_cap = 64;
+  uint32_t max_leaves = 0, max_lds_leaves = 0, max_score = 0, max_stack = 0, max_instr = 0, max_cap = 64;
   for (uint32_t i = 0; i < n; ++i) {
     const QuerySpec& s = specs[g.qids[i]];
     DevQuery& q = dq[i];
@@ -1156,10 +1156,21 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     q.k1_plus_1 = s.k1 + 1.0;
     q.avgdl_clamped = std::max(s.avgdl, 1.0);  // bm25_scorer.cpp:81
     const uint32_t ebase = static_cast<uint32_t>(expl.size());
-    for (DevLeaf lf : s.leaves) {
+    // LDS residency (general kernel): sorted-list operands are scattered into an LDS bitmap, scored operands are
+    // probed there by other threads; bitmap-form operands are read straight from HBM and take no LDS
+    uint32_t n_lds = 0;
+    for (size_t li = 0; li < s.leaves.size(); ++li) {
+      DevLeaf lf = s.leaves[li];
       if (lf.kind == kLeafExplicit) lf.a += ebase;
+      bool resident = lf.kind == kLeafList || lf.kind == kLeafExplicit;
+      for (const DevScoreTerm& st : s.score) resident = resident || st.leaf == li;
+      lf.lds = resident ? n_lds++ : kNoRow;
       leaves.push_back(lf);
     }
+    if (n_lds > kMaxLdsLeaves)
+      return Fail(MGX_ERR_NOT_IMPLEMENTED,
+                  "query " + std::to_string(g.qids[i]) + ": more than 64 sorted-list / scored operands in one query");
+    max_lds_leaves = std::max(max_lds_leaves, n_lds);
     prog.insert(prog.end(), s.prog.begin(), s.prog.end());
     score.insert(score.end(), s.score.begin(), s.score.end());
     expl.insert(expl.end(), s.explicit_ids.begin(), s.explicit_ids.end());
@@ -1171,7 +1182,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     max_cap = std::max(max_cap, q.cap);
     if (!df_mode) b->list_bytes += 4 * s.list_postings;
   }
-  g.plan = PlanLds(max_leaves, max_score, max_stack, max_instr, max_cap, score_mode || df_mode);
+  g.plan = PlanLds(max_leaves, max_lds_leaves, max_score, max_stack, max_instr, max_cap, score_mode || df_mode);
   std::vector<uint8_t> on_wave(n, 0);  // 0 general kernel, 1 wave kernel, 2 wave kernel with list operands, 3 fast path
   std::vector<DevFastQuery> fastq;
   std::vector<uint64_t> wave_tables;
@@ -1578,7 +1589,7 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         dens = static_cast<double>(mn) / static_cast<double>(std::max<uint32_t>(idx->dev.n_docs, 1));
         ds.est_density = dens;
         if (ds.leaves.size() > kMaxLeaves)
-          return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 40 distinct n-grams in one text-level term");
+          return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 192 distinct n-grams in one text-level term");
         b->df_specs.push_back(std::move(ds));
       }
     }
@@ -2297,7 +2308,7 @@ int mgx_and(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint64_t limit
     mgx::Compiler c{idx, &q, 0};
     c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
     for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpAnd, c.GramLeaf(gram_ids[i]));
-    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_and: more than 40 lists");
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_and: more than 192 lists");
     q.limit = static_cast<uint32_t>(limit);
     q.reverse = reverse ? 1 : 0;
     return RunSingle(idx, std::move(q), out_docs, out_n);
@@ -2314,7 +2325,7 @@ int mgx_or(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t** out_
     mgx::Compiler c{idx, &q, 0};
     c.Emit(mgx::kOpLoad, c.GramLeaf(gram_ids[0]));
     for (uint32_t i = 1; i < n; ++i) c.Emit(mgx::kOpOr, c.GramLeaf(gram_ids[i]));
-    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_or: more than 40 lists");
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_or: more than 192 lists");
     return RunSingle(idx, std::move(q), out_docs, out_n);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_or: ") + e.what());
@@ -2348,7 +2359,7 @@ int mgx_not(mgx_index* idx, const uint32_t* all_docs, uint64_t n_all, const uint
     q.leaves.push_back(lf);
     c.Emit(mgx::kOpLoad, 0);
     for (uint32_t i = 0; i < n; ++i) c.Emit(mgx::kOpAndNot, c.GramLeaf(gram_ids[i]));
-    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_not: more than 40 lists");
+    if (q.leaves.size() > mgx::kMaxLeaves) return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_not: more than 192 lists");
     uint32_t* mid = nullptr;
     uint64_t n_mid = 0;
     int rc = RunSingle(idx, std::move(q), &mid, &n_mid);
@@ -2390,7 +2401,7 @@ int mgx_threshold(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t
     c.Emit(mgx::kOpThreshEnd, threshold);
     if (q.leaves.size() != n) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_threshold: grams must be distinct");
     if (q.leaves.size() > mgx::kMaxLeaves)
-      return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_threshold: more than 40 lists");
+      return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED, "mgx_threshold: more than 192 lists");
     return RunSingle(idx, std::move(q), out_docs, out_n);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_threshold: ") + e.what());

@@ -20,8 +20,9 @@ constexpr uint32_t kTileDocs = 1u << kTileShift;  // = kBlock * 64 bits: one u64
 constexpr int kWordsPerTile = kTileDocs / 64;     // 256
 constexpr int kMaxTilesPerItem = 64;              // most tiles one workgroup walks (cheap queries)
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
-constexpr uint32_t kMaxLeaves = 40;               // operand bitmaps resident in LDS at once
-constexpr uint32_t kMaxScoreTerms = 16;
+constexpr uint32_t kMaxLeaves = 192;              // distinct operands of one query (64 terms/NOT terms/filters, query_parser.h:270-272)
+constexpr uint32_t kMaxLdsLeaves = 64;            // of them resident in LDS at once: sorted-list and scored operands
+constexpr uint32_t kMaxScoreTerms = 64;           // scored terms (= the 64 AND terms of query_parser.h:270)
 constexpr uint32_t kMaxNeeded = 1024;             // offset+limit handled by the fused top-k
 constexpr uint32_t kMatchBuf = 2048;              // matches enumerated per scoring round
 
@@ -38,6 +39,8 @@ struct DevLeaf {
   uint32_t kind, a, b;
   uint32_t score_slot;  // index of the scored term whose tf column this operand carries, or kNoSlot
   uint32_t row;         // the gram's skip row (tile_off), or kNoRow; filled by the host so kernels need not chase it
+  uint32_t lds;         // general kernel: the operand's tile bitmap in LDS (sorted lists are scattered there, scored
+                        // operands are probed there), or kNoRow: a bitmap-form operand read straight from HBM
 };
 constexpr uint32_t kNoSlot = 0xFFu;
 constexpr uint32_t kAbsentMark = 0xFEu;  // score_slot of the empty-range operand that stands for MGX_GRAM_ABSENT
@@ -223,10 +226,11 @@ struct DevBatch {
 // LDS bytes the tile kernel needs for a launch whose queries have at most these shapes.
 struct LdsPlan {
   uint32_t max_leaves, max_score, max_stack, max_instr, max_cap;
+  uint32_t max_lds_leaves;  // operand bitmaps resident in LDS
   uint32_t bytes;
 };
-LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr, uint32_t max_cap,
-                bool score_mode);
+LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_lds_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr,
+                uint32_t max_cap, bool score_mode);
 
 // LDS plan of the wave-autonomous scoring kernel (flat programs, <= kWaveScoreSlots scored terms).
 struct WavePlan {

@@ -118,7 +118,7 @@ __host__ __device__ inline uint32_t align8(uint32_t x) { return (x + 7u) & ~7u; 
 __host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
   LdsOffsets o;
   uint32_t at = 0;
-  o.bm = at;        at += p.max_leaves * kBlock * 8;
+  o.bm = at;        at += p.max_lds_leaves * kBlock * 8;
   o.stack = at;     at += p.max_stack * kBlock * 8;
   o.seg_lo = at;    at += align8(p.max_leaves * 8);
   o.seg_hi = at;    at += align8(p.max_leaves * 8);
@@ -142,9 +142,10 @@ __host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
   return o;
 }
 
-LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr, uint32_t max_cap,
-                bool score_mode) {
-  LdsPlan p{max_leaves ? max_leaves : 1, max_score, max_stack, max_instr ? max_instr : 1, max_cap, 0};
+LdsPlan PlanLds(uint32_t max_leaves, uint32_t max_lds_leaves, uint32_t max_score, uint32_t max_stack, uint32_t max_instr,
+                uint32_t max_cap, bool score_mode) {
+  LdsPlan p{max_leaves ? max_leaves : 1, max_score, max_stack, max_instr ? max_instr : 1, max_cap,
+            max_lds_leaves ? max_lds_leaves : 1, 0};
   p.bytes = carve(p, score_mode).total;
   return p;
 }
@@ -640,23 +641,26 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       seg_lo[tid] = a;
       seg_hi[tid] = b;
     }
-    for (uint32_t l = 0; l < n_leaves; ++l) {
-      const DevLeaf lf = leaf[l];
-      uint64_t w = 0;
-      if (lf.kind == kLeafGramBitmap) {
-        w = ix.gram_bitmaps[tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + tid];
-      } else if (lf.kind == kLeafFilterBitmap) {
-        w = ix.filter_bitmaps[tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + tid];
-      } else if (lf.kind == kLeafRange) {
+    // this thread's 64-bit word of a bitmap-form operand (dense gram, filter, slot range), straight from HBM
+    auto direct_word = [&](const DevLeaf lf) -> uint64_t {
+      if (lf.kind == kLeafGramBitmap) return ix.gram_bitmaps[tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + tid];
+      if (lf.kind == kLeafFilterBitmap) return ix.filter_bitmaps[tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + tid];
+      if (lf.kind == kLeafRange) {
         // slots [a, b) of the shard; this thread's word covers slots [s0, s0+64)
         const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs + static_cast<uint64_t>(tid) * 64;
         const uint64_t ra = lf.a > s0 ? lf.a - s0 : 0;
         const uint64_t rb = lf.b > s0 ? lf.b - s0 : 0;
         const uint64_t hi_mask = rb >= 64 ? ~0ull : ((1ull << rb) - 1ull);
         const uint64_t lo_mask = ra >= 64 ? ~0ull : ((1ull << ra) - 1ull);
-        w = hi_mask & ~lo_mask;
+        return hi_mask & ~lo_mask;
       }
-      bm64[l * kBlock + tid] = w;
+      return 0;
+    };
+    // Only operands that need it live in LDS: sorted lists (scattered there) and scored operands (probed by other
+    // threads); every other operand is one global load per thread at the instruction that uses it.
+    for (uint32_t l = 0; l < n_leaves; ++l) {
+      const DevLeaf lf = leaf[l];
+      if (lf.lds != kNoRow) bm64[lf.lds * kBlock + tid] = direct_word(lf);
     }
     __syncthreads();
 
@@ -665,10 +669,10 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       const uint32_t kind = leaf[l].kind;
       if (kind == kLeafList) {
         scatter_segment(ix.docids, seg_lo[l], seg_hi[l], static_cast<uint32_t>(tile_first),
-                        reinterpret_cast<uint32_t*>(bm64 + l * kBlock));
+                        reinterpret_cast<uint32_t*>(bm64 + leaf[l].lds * kBlock));
       } else if (kind == kLeafExplicit) {
         scatter_segment(bt.explicit_pool, seg_lo[l], seg_hi[l], static_cast<uint32_t>(tile_first),
-                        reinterpret_cast<uint32_t*>(bm64 + l * kBlock));
+                        reinterpret_cast<uint32_t*>(bm64 + leaf[l].lds * kBlock));
       }
     }
     __syncthreads();
@@ -678,14 +682,18 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     {
       uint32_t sp = 0;
       uint64_t cs[7] = {0, 0, 0, 0, 0, 0, 0};  // bit-sliced per-doc counters (one bit lane per doc slot)
+      auto W = [&](uint32_t l) -> uint64_t {
+        const DevLeaf lf = leaf[l];
+        return lf.lds != kNoRow ? bm64[lf.lds * kBlock + tid] : direct_word(lf);
+      };
       for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
         const uint32_t ins = prog[pc];
         const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
         switch (op) {
-          case kOpLoad: acc = bm64[arg * kBlock + tid]; break;
-          case kOpAnd: acc &= bm64[arg * kBlock + tid]; break;
-          case kOpOr: acc |= bm64[arg * kBlock + tid]; break;
-          case kOpAndNot: acc &= ~bm64[arg * kBlock + tid]; break;
+          case kOpLoad: acc = W(arg); break;
+          case kOpAnd: acc &= W(arg); break;
+          case kOpOr: acc |= W(arg); break;
+          case kOpAndNot: acc &= ~W(arg); break;
           case kOpPush: stack[sp * kBlock + tid] = acc; ++sp; break;
           case kOpPopAnd: --sp; acc = stack[sp * kBlock + tid] & acc; break;
           case kOpPopOr: --sp; acc = stack[sp * kBlock + tid] | acc; break;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
             for (int b = 0; b < 7; ++b) cs[b] = 0;
             break;
           case kOpThreshAdd: {
-            uint64_t carry = bm64[arg * kBlock + tid];
+            uint64_t carry = W(arg);
 #pragma unroll
             for (int b = 0; b < 7; ++b) {
               const uint64_t t = cs[b] & carry;
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     uint32_t excl_res = 0;
     auto operand_pop = [&](uint32_t term) -> uint32_t {
       const uint32_t lf = bt.score_terms[q.score_begin + term].leaf;
-      return lf == kNoLeaf ? 0u : static_cast<uint32_t>(__popcll(bm64[lf * kBlock + tid]));
+      return lf == kNoLeaf ? 0u : static_cast<uint32_t>(__popcll(bm64[leaf[lf].lds * kBlock + tid]));
     };
     for (uint32_t pk = 0; pk < n_packed; ++pk) {
       const uint32_t qa = 2 * pk, qb = 2 * pk + 1;
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
               tf = static_cast<double>(text_count_occurrences(ix.text, t0, t1, tpat[i], false));
               idf = bt.text_idf[st.text_term];
             } else {
-              const uint64_t wbits = bm64[st.leaf * kBlock + word];
+              const uint64_t wbits = bm64[leaf[st.leaf].lds * kBlock + word];
               if ((wbits >> bit) & 1ull) {
                 const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
                 tf = static_cast<double>(posting_tf(ix, seg_lo[st.leaf] + rank));

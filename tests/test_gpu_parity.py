@@ -519,3 +519,22 @@ def test_tf_beyond_the_byte_column(dense, monkeypatch):
     dfs = [pair.dev.posting_size("ab"), pair.dev.posting_size("cd")]
     want = O.score_documents(pair.ostore, cand, ["ab", "cd"], dfs, pair.N, pair.avgdl)
     assert np.array_equal(pair.dev.score_documents(cand, ["ab", "cd"], dfs, pair.N, pair.avgdl), want)
+
+
+def test_many_operands_and_many_scored_terms(pair60k, monkeypatch):
+    """The reference takes 64 AND terms / 64 NOT terms / 64 filters per query (query_parser.h:270-272) and terms of
+    ~127 n-grams: a 60-gram term (one conjunction of 60 lists), 20 scored terms, 30 NOT terms. Only sorted-list and
+    scored operands occupy LDS in the general kernel, so these shapes run instead of being refused."""
+    c, sizes, grams = _letter_grams(pair60k)
+    docs = [pair60k.corpus.text(i).decode() for i in range(0, 60_000, 601)]
+    long_terms = [d[:61] for d in docs if len(d) >= 61][:3]          # 60 bigrams each, matches at least its doc
+    many = [c.gram(int(g)).decode() for g in grams[:24]]
+    qs = [Query([t], limit=10) for t in long_terms]
+    qs += [Query([long_terms[0][:40]], sort_score=True, limit=5)]       # text-level term of 39 grams
+    qs += [Query(many[:20], sort_score=True, limit=10),                 # 20 scored single-gram terms
+           Query(many[:5], sort_score=True, limit=10),                  # 5 scored terms
+           Query(many[:2], [c.gram(int(g)).decode() for g in grams[200:230]], limit=20),  # 30 NOT terms
+           Query(many[:4], sort_score=True, limit=10)]
+    pair60k.check(qs)
+    monkeypatch.setenv("MGX_FAST_PATH", "1")   # the 4-term query on and_score_kernel<4>
+    pair60k.check(qs[-3:])
