@@ -17,7 +17,7 @@ $(CSRC)/mgx_kernels.o: $(CSRC)/mgx_kernels.hip $(CSRC)/mgx_internal.hpp $(CSRC)/
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(CSRC)/mgx_api.o: $(CSRC)/mgx_api.cpp $(CSRC)/mgx_internal.hpp $(CSRC)/mgx_launch.hpp $(CSRC)/mgx_host.hpp include/mygram_gpu.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-$(CSRC)/mgx_columns.o: $(CSRC)/mgx_columns.cpp $(CSRC)/mgx_host.hpp include/mygram_gpu.h
+$(CSRC)/mgx_columns.o: $(CSRC)/mgx_columns.cpp $(CSRC)/mgx_host.hpp $(CSRC)/mgx_text.hpp include/mygram_gpu.h
 	g++ $(CXXFLAGS) -pthread -c $< -o $@
 $(CSRC)/mgx_tools.o: $(CSRC)/mgx_tools.cpp include/mygram_tools.h
 	g++ $(CXXFLAGS) -pthread -c $< -o $@
@@ -26,7 +26,7 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
 
 # host C++17 layer (reference-signature classes, ExecuteBatch, BatchExecutor) + its C face for ctypes / cgo / JNI callers
-$(SHIM): $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp $(CSRC)/shim/mygram_shim.hpp include/mygram_shim_c.h include/mygram_gpu.h $(LIB)
+$(SHIM): $(CSRC)/mgx_text.hpp $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp $(CSRC)/shim/mygram_shim.hpp include/mygram_shim_c.h include/mygram_gpu.h $(LIB)
 	g++ $(CXXFLAGS) -shared -o $@ $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp -Lmygram-db_amd -lmygram_gpu -Wl,-rpath,'$$ORIGIN' -pthread
 
 oracle:

@@ -27,6 +27,11 @@ void mgxt_corpus_destroy(mgxt_corpus* c);
  * as the measured roofline denominator. */
 int mgxt_measure_read_bandwidth(int device, uint64_t bytes, int iters, double* gb_per_s);
 
+/* Test hook (the counterpart of the reference's MYGRAMDB_INDEX_TEST_HOOKS allocation-failure injection,
+ * src/index/posting_list.h:217-246): after `after` more successful device allocations, the next `count` allocations of
+ * the library fail with an out-of-memory error. count <= 0 switches the hook off. Process-wide. */
+void mgxt_fail_device_allocs(int after, int count);
+
 #ifdef __cplusplus
 }
 #endif

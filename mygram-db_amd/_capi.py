@@ -23,7 +23,7 @@ EXPORTS = [
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
-    "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth",
+    "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth", "mgxt_fail_device_allocs",
 ]
 
 
@@ -146,6 +146,8 @@ def load():
     L.mgxt_corpus_destroy.argtypes = [vp]
     L.mgxt_corpus_destroy.restype = None
     L.mgxt_measure_read_bandwidth.argtypes = [i32, u64, i32, C.POINTER(C.c_double)]
+    L.mgxt_fail_device_allocs.argtypes = [i32, i32]
+    L.mgxt_fail_device_allocs.restype = None
     _lib = L
     return L
 

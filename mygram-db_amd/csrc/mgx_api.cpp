@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <cstdio>
@@ -50,6 +51,28 @@ int Fail(int code, const std::string& msg) {
                          std::string(#expr) + ": " + hipGetErrorString(static_cast<hipError_t>(e__)));      \
   } while (0)
 
+// Every device allocation of the library goes through here. The test hook (include/mygram_tools.h,
+// mgxt_fail_device_allocs) makes chosen allocations fail, the way the reference injects Roaring allocation failures
+// (MYGRAMDB_INDEX_TEST_HOOKS, posting_list.h:217-246): the failure must surface as an error code, never as an empty
+// result.
+static std::atomic<int> g_fail_after{-1};  // allocations still to succeed before the injected failures; -1 = hook off
+static std::atomic<int> g_fail_count{0};   // how many allocations then fail
+static hipError_t DeviceMalloc(void** p, size_t n) {
+  if (g_fail_after.load(std::memory_order_relaxed) >= 0) {
+    if (g_fail_after.load() == 0) {
+      if (g_fail_count.fetch_sub(1) > 0) {
+        if (g_fail_count.load() <= 0) g_fail_after.store(-1);
+        *p = nullptr;
+        return hipErrorOutOfMemory;
+      }
+      g_fail_after.store(-1);
+    } else {
+      g_fail_after.fetch_sub(1);
+    }
+  }
+  return hipMalloc(p, n);
+}
+
 // Device memory handed out in pieces that never move, optionally mirrored in pinned host memory. A batch builds all
 // of its (small) input arrays in the mirror and ships them with ONE asynchronous copy per chunk on the execute stream;
 // its device-only outputs come from a second arena. Chunks are kept when the arena is reset, so a serving loop that
@@ -88,7 +111,7 @@ struct Arena {
     }
     Chunk c;
     c.cap = std::max(n, chunk_bytes);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.dev), c.cap);
+    hipError_t e = DeviceMalloc(reinterpret_cast<void**>(&c.dev), c.cap);
     if (e != hipSuccess) return e;
     if (mirrored) {
       e = hipHostMalloc(reinterpret_cast<void**>(&c.host), c.cap, hipHostMallocDefault);
@@ -188,7 +211,7 @@ struct DevBuf {
       owned = false;
       return tl_res->out.Alloc(n, &p, nullptr);
     }
-    return hipMalloc(&p, n ? n : 16);
+    return DeviceMalloc(&p, n ? n : 16);
   }
   template <typename T>
   T* as() const { return static_cast<T*>(p); }
@@ -2615,6 +2638,11 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
 }
 
 }  // extern "C"
+
+extern "C" void mgxt_fail_device_allocs(int after, int count) {
+  mgx::g_fail_count.store(count > 0 ? count : 0);
+  mgx::g_fail_after.store(count > 0 && after >= 0 ? after : -1);
+}
 
 extern "C" int mgxt_measure_read_bandwidth(int device, uint64_t bytes, int iters, double* gb_per_s) {
   if (!gb_per_s || bytes < (1ull << 20) || iters < 1) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "read probe: bad arguments");

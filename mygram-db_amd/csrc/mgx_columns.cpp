@@ -20,6 +20,7 @@
 
 #include "../../include/mygram_gpu.h"
 #include "mgx_host.hpp"
+#include "mgx_text.hpp"
 
 namespace mgx {
 
@@ -73,62 +74,9 @@ struct KeyTable {
   }
 };
 
-// src/utils/string_utils.cpp:94-164 (TryParseUtf8Char)
-inline int ParseUtf8(const uint8_t* d, size_t avail, uint32_t* cp) {
-  uint8_t b0 = d[0];
-  if (b0 < 0x80) {
-    *cp = b0;
-    return 1;
-  }
-  if ((b0 & 0xE0) == 0xC0) {
-    if (b0 < 0xC2 || avail < 2 || (d[1] & 0xC0) != 0x80) return -1;
-    *cp = ((b0 & 0x1Fu) << 6) | (d[1] & 0x3Fu);
-    return 2;
-  }
-  if ((b0 & 0xF0) == 0xE0) {
-    if (avail < 3 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80) return -1;
-    uint32_t c = ((b0 & 0x0Fu) << 12) | ((d[1] & 0x3Fu) << 6) | (d[2] & 0x3Fu);
-    if (c < 0x800 || (c >= 0xD800 && c <= 0xDFFF)) return -1;
-    *cp = c;
-    return 3;
-  }
-  if ((b0 & 0xF8) == 0xF0) {
-    if (b0 > 0xF4 || avail < 4 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80 || (d[3] & 0xC0) != 0x80) return -1;
-    uint32_t c = ((b0 & 0x07u) << 18) | ((d[1] & 0x3Fu) << 12) | ((d[2] & 0x3Fu) << 6) | (d[3] & 0x3Fu);
-    if (c < 0x10000 || c > 0x10FFFF) return -1;
-    *cp = c;
-    return 4;
-  }
-  return -1;
-}
-
-inline bool IsCjkIdeograph(uint32_t c) {  // string_utils.cpp:441-448
-  return (c >= 0x4E00 && c <= 0x9FFF) || (c >= 0x3400 && c <= 0x4DBF) || (c >= 0x20000 && c <= 0x2A6DF) ||
-         (c >= 0x2A700 && c <= 0x2B73F) || (c >= 0x2B740 && c <= 0x2B81F) || (c >= 0xF900 && c <= 0xFAFF);
-}
-
-inline size_t EncodeUtf8(uint32_t c, uint8_t* o) {  // string_utils.cpp:241-272
-  if (c <= 0x7F) {
-    o[0] = static_cast<uint8_t>(c);
-    return 1;
-  }
-  if (c <= 0x7FF) {
-    o[0] = static_cast<uint8_t>(0xC0 | (c >> 6));
-    o[1] = static_cast<uint8_t>(0x80 | (c & 0x3F));
-    return 2;
-  }
-  if (c <= 0xFFFF) {
-    o[0] = static_cast<uint8_t>(0xE0 | (c >> 12));
-    o[1] = static_cast<uint8_t>(0x80 | ((c >> 6) & 0x3F));
-    o[2] = static_cast<uint8_t>(0x80 | (c & 0x3F));
-    return 3;
-  }
-  o[0] = static_cast<uint8_t>(0xF0 | (c >> 18));
-  o[1] = static_cast<uint8_t>(0x80 | ((c >> 12) & 0x3F));
-  o[2] = static_cast<uint8_t>(0x80 | ((c >> 6) & 0x3F));
-  o[3] = static_cast<uint8_t>(0x80 | (c & 0x3F));
-  return 4;
-}
+using text::EncodeUtf8;
+using text::IsCjkIdeograph;
+using text::ParseUtf8;
 
 struct DocScratch {
   std::vector<uint32_t> cps;
@@ -141,19 +89,8 @@ struct DocScratch {
 // Decodes the text and produces one key per window position. Returns false if a gram exceeds 15 bytes.
 inline bool DocWindows(const uint8_t* text, size_t len, int ascii_n, int kanji_n, bool cross, DocScratch& s,
                        uint32_t* doc_len) {
-  s.cps.clear();
   s.cplen.clear();
-  size_t i = 0;
-  while (i < len) {
-    uint32_t cp = 0;
-    int k = ParseUtf8(text + i, len - i, &cp);
-    if (k > 0) {
-      s.cps.push_back(cp);
-      i += static_cast<size_t>(k);
-    } else {
-      ++i;
-    }
-  }
+  text::Decode(text, len, &s.cps);
   const size_t n = s.cps.size();
   *doc_len = static_cast<uint32_t>(n);
   s.keys.assign(n, 0);
@@ -161,18 +98,8 @@ inline bool DocWindows(const uint8_t* text, size_t len, int ascii_n, int kanji_n
   if (ascii_n <= 0 || kanji_n <= 0) return true;
   uint8_t buf[64];
   for (size_t p = 0; p < n; ++p) {
-    const bool cjk = IsCjkIdeograph(s.cps[p]);
-    const int w = cjk ? kanji_n : ascii_n;
-    if (p + static_cast<size_t>(w) > n) continue;
-    if (!cross) {
-      bool crossed = false;
-      for (int j = 1; j < w; ++j)
-        if (IsCjkIdeograph(s.cps[p + j]) != cjk) {
-          crossed = true;
-          break;
-        }
-      if (crossed) continue;
-    }
+    const int w = text::WindowAt(s.cps, p, ascii_n, kanji_n, cross);
+    if (w == 0) continue;
     size_t nb = 0;
     for (int j = 0; j < w; ++j) {
       if (nb + 4 > sizeof(buf)) return false;

@@ -2,6 +2,8 @@
 // Host-side rules are cited from the reference (paths relative to its tree); all posting work goes to the device.
 #include "mygram_shim.hpp"
 
+#include "../mgx_text.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -22,35 +24,8 @@ using mygram::utils::MakeUnexpected;
 
 namespace {
 
-// ---- src/utils/string_utils.cpp: UTF-8 decode (:94-164), IsCJKIdeograph (:441-448), n-gram windows (:382-509) -----
-
-int ParseUtf8(const unsigned char* d, size_t avail, uint32_t* cp) {
-  const unsigned char b0 = d[0];
-  if (b0 < 0x80) {
-    *cp = b0;
-    return 1;
-  }
-  if ((b0 & 0xE0) == 0xC0) {
-    if (b0 < 0xC2 || avail < 2 || (d[1] & 0xC0) != 0x80) return -1;
-    *cp = ((b0 & 0x1Fu) << 6) | (d[1] & 0x3Fu);
-    return 2;
-  }
-  if ((b0 & 0xF0) == 0xE0) {
-    if (avail < 3 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80) return -1;
-    const uint32_t c = ((b0 & 0x0Fu) << 12) | ((d[1] & 0x3Fu) << 6) | (d[2] & 0x3Fu);
-    if (c < 0x800 || (c >= 0xD800 && c <= 0xDFFF)) return -1;
-    *cp = c;
-    return 3;
-  }
-  if ((b0 & 0xF8) == 0xF0) {
-    if (b0 > 0xF4 || avail < 4 || (d[1] & 0xC0) != 0x80 || (d[2] & 0xC0) != 0x80 || (d[3] & 0xC0) != 0x80) return -1;
-    const uint32_t c = ((b0 & 0x07u) << 18) | ((d[1] & 0x3Fu) << 12) | ((d[2] & 0x3Fu) << 6) | (d[3] & 0x3Fu);
-    if (c < 0x10000 || c > 0x10FFFF) return -1;
-    *cp = c;
-    return 4;
-  }
-  return -1;
-}
+// ---- n-gram rules over the shared text implementation (../mgx_text.hpp: UTF-8 decode string_utils.cpp:94-218,
+//      IsCJKIdeograph :441-448, window rule :452-509) -------------------------------------------------------------------
 
 struct CodePoints {
   std::vector<uint32_t> cp;
@@ -59,31 +34,14 @@ struct CodePoints {
 
 CodePoints Decode(std::string_view text) {
   CodePoints out;
-  const auto* d = reinterpret_cast<const unsigned char*>(text.data());
-  size_t i = 0;
-  while (i < text.size()) {
-    uint32_t c = 0;
-    const int k = ParseUtf8(d + i, text.size() - i, &c);
-    if (k > 0) {
-      out.cp.push_back(c);
-      out.span.emplace_back(static_cast<uint32_t>(i), static_cast<uint32_t>(i + k));
-      i += static_cast<size_t>(k);
-    } else {
-      ++i;  // invalid byte skipped (Utf8ToCodepoints :199-218)
-    }
-  }
+  mgx::text::Decode(reinterpret_cast<const uint8_t*>(text.data()), text.size(), &out.cp, &out.span);
   return out;
 }
 
-bool IsCjkIdeograph(uint32_t c) {
-  return (c >= 0x4E00 && c <= 0x9FFF) || (c >= 0x3400 && c <= 0x4DBF) || (c >= 0x20000 && c <= 0x2A6DF) ||
-         (c >= 0x2A700 && c <= 0x2B73F) || (c >= 0x2B740 && c <= 0x2B81F) || (c >= 0xF900 && c <= 0xFAFF);
-}
+using mgx::text::IsCjkIdeographPipeline;
 
-// src/server/search_pipeline.cpp:70-78 (knows one more extension block than the string_utils predicate above) and
-// :80-136 HasUncoveredHybridFragment: a mixed-script term with a code point that no query n-gram covers
-bool IsCjkIdeographPipeline(uint32_t c) { return IsCjkIdeograph(c) || (c >= 0x2B820 && c <= 0x2CEAF); }
-
+// src/server/search_pipeline.cpp:80-136 HasUncoveredHybridFragment: a mixed-script term with a code point that no
+// query n-gram covers (windows here follow the pipeline's own, wider ideograph predicate)
 bool HasUncoveredHybridFragment(std::string_view normalized, int ngram_size, int kanji_ngram_size, bool cross) {
   if (normalized.empty() || kanji_ngram_size <= 0) return false;
   const int ascii_n = ngram_size > 0 ? ngram_size : 2;
@@ -130,19 +88,8 @@ std::vector<std::string> GenerateHybridNgrams(std::string_view text, int ascii_n
   if (ascii_n <= 0 || kanji_n <= 0) return out;
   const CodePoints cps = Decode(text);
   for (size_t i = 0; i < cps.cp.size(); ++i) {
-    const bool cjk = IsCjkIdeograph(cps.cp[i]);
-    const size_t n = static_cast<size_t>(cjk ? kanji_n : ascii_n);
-    if (i + n > cps.cp.size()) continue;
-    if (!cross) {
-      bool crossed = false;
-      for (size_t j = 1; j < n; ++j)
-        if (IsCjkIdeograph(cps.cp[i + j]) != cjk) {
-          crossed = true;
-          break;
-        }
-      if (crossed) continue;
-    }
-    out.push_back(Window(text, cps, i, i + n));
+    const int w = mgx::text::WindowAt(cps.cp, i, ascii_n, kanji_n, cross);  // the builder's own window rule
+    if (w != 0) out.push_back(Window(text, cps, i, i + static_cast<size_t>(w)));
   }
   return out;
 }
@@ -171,6 +118,16 @@ std::vector<storage::DocId> Take(uint32_t* p, uint64_t n) {
 // =================================================================================================================
 
 namespace index {
+
+namespace {
+thread_local std::string tl_device_error;
+// every std::vector-returning method: cleared on entry ...
+void ClearDeviceError() { tl_device_error.clear(); }
+}  // namespace
+const std::string& LastDeviceError() { return tl_device_error; }
+// ... and set where the C ABI (or the index build) reports a failure
+static void SetDeviceError(const std::string& msg) { tl_device_error = msg.empty() ? "device failure" : msg; }
+void ClearDeviceErrorForSorter() { ClearDeviceError(); }
 
 struct Index::Impl {
   int device = 0;
@@ -345,9 +302,13 @@ Expected<uint32_t, Error> Index::AddFilterBitmap(const std::vector<DocId>& docs)
 }
 
 std::vector<DocId> Index::SearchAnd(const std::vector<std::string>& terms, size_t limit, bool reverse) const {
+  ClearDeviceError();
   if (terms.empty()) return {};  // index.cpp:203
   Finalize();
-  if (!impl_->dev) return {};
+  if (!impl_->dev) {
+    SetDeviceError(impl_->last_error);
+    return {};
+  }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -358,15 +319,20 @@ std::vector<DocId> Index::SearchAnd(const std::vector<std::string>& terms, size_
   uint64_t n = 0;
   if (mgx_and(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), limit, reverse ? 1 : 0, &out, &n) != MGX_OK) {
     impl_->last_error = mgx_last_error();
+    SetDeviceError(impl_->last_error);
     return {};
   }
   return Take(out, n);
 }
 
 std::vector<DocId> Index::SearchOr(const std::vector<std::string>& terms) const {  // index.cpp:418-448
+  ClearDeviceError();
   if (terms.empty()) return {};
   Finalize();
-  if (!impl_->dev) return {};
+  if (!impl_->dev) {
+    SetDeviceError(impl_->last_error);
+    return {};
+  }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -379,15 +345,20 @@ std::vector<DocId> Index::SearchOr(const std::vector<std::string>& terms) const 
   uint64_t n = 0;
   if (mgx_or(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) != MGX_OK) {
     impl_->last_error = mgx_last_error();
+    SetDeviceError(impl_->last_error);
     return {};
   }
   return Take(out, n);
 }
 
 std::vector<DocId> Index::SearchNot(const std::vector<DocId>& all_docs, const std::vector<std::string>& terms) const {
+  ClearDeviceError();
   if (terms.empty()) return all_docs;  // index.cpp:451-453
   Finalize();
-  if (!impl_->dev) return {};
+  if (!impl_->dev) {
+    SetDeviceError(impl_->last_error);
+    return {};
+  }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -401,19 +372,24 @@ std::vector<DocId> Index::SearchNot(const std::vector<DocId>& all_docs, const st
   if (mgx_not(impl_->dev, all_docs.data(), all_docs.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) !=
       MGX_OK) {
     impl_->last_error = mgx_last_error();
+    SetDeviceError(impl_->last_error);
     return {};
   }
   return Take(out, n);
 }
 
 std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& terms, size_t threshold) const {
+  ClearDeviceError();
   if (terms.empty() || threshold == 0) return {};  // index.cpp:489-491
   std::vector<std::string> uniq = terms;
   DeduplicateSorted(uniq);                         // :496-497
   if (threshold > uniq.size()) return {};          // :499-501
   if (threshold == uniq.size()) return SearchAnd(uniq);  // :504-506
   Finalize();
-  if (!impl_->dev) return {};
+  if (!impl_->dev) {
+    SetDeviceError(impl_->last_error);
+    return {};
+  }
   std::vector<uint32_t> ids;
   for (const auto& t : uniq) {
     uint32_t id = 0;
@@ -425,6 +401,7 @@ std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& term
   if (mgx_threshold(impl_->dev, ids.data(), static_cast<uint32_t>(ids.size()), static_cast<uint32_t>(threshold), &out,
                     &n) != MGX_OK) {
     impl_->last_error = mgx_last_error();
+    SetDeviceError(impl_->last_error);
     return {};
   }
   return Take(out, n);
@@ -432,10 +409,14 @@ std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& term
 
 std::vector<DocId> Index::FilterByNgrams(const std::vector<DocId>& candidates,
                                          const std::vector<std::string>& terms) const {
+  ClearDeviceError();
   if (candidates.empty()) return {};  // index.cpp:372-374
   if (terms.empty()) return candidates;  // :378-380
   Finalize();
-  if (!impl_->dev) return {};
+  if (!impl_->dev) {
+    SetDeviceError(impl_->last_error);
+    return {};
+  }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -447,6 +428,7 @@ std::vector<DocId> Index::FilterByNgrams(const std::vector<DocId>& candidates,
   if (mgx_retain(impl_->dev, candidates.data(), candidates.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out,
                  &n) != MGX_OK) {
     impl_->last_error = mgx_last_error();
+    SetDeviceError(impl_->last_error);
     return {};
   }
   return Take(out, n);
@@ -522,15 +504,20 @@ namespace query {
 std::vector<DocId> ResultSorter::SortByScore(const index::Index& index, const std::vector<DocId>& results,
                                              const std::vector<double>& scores, SortOrder order, uint32_t limit,
                                              uint32_t offset) {
+  index::ClearDeviceErrorForSorter();
   if (results.empty()) return {};  // result_sorter.cpp:663-665
   index.Finalize();
   index::Index::Impl* im = index.impl();
-  if (!im->dev) return {};
+  if (!im->dev) {
+    index::SetDeviceError(im->last_error);
+    return {};
+  }
   uint32_t* out = nullptr;
   uint64_t n = 0;
   if (mgx_sort_by_score(im->dev, results.data(), scores.data(), results.size(), order == SortOrder::DESC ? 1 : 0, limit,
                         offset, &out, &n) != MGX_OK) {
     im->last_error = mgx_last_error();
+    index::SetDeviceError(im->last_error);
     return {};
   }
   return Take(out, n);
@@ -682,6 +669,45 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
   }
   if (q.terms.empty() || q.terms.size() > MGX_MAX_TERMS || q.not_terms.size() > MGX_MAX_TERMS)
     return Fail(p, ErrorCode::kInvalidArgument, "query needs 1..64 terms");
+  if (q.fuzzy_max_distance > 0) {
+    // ---- ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): no size sort; theta per term; unknown grams are skipped by
+    // Index::SearchByThreshold (index.cpp:512-523) unless theta asks for every gram (then it is SearchAnd) ------------
+    if (q.sort_by_score || q.verify_text)
+      return Fail(p, ErrorCode::kNotImplemented, "FUZZY with SORT _score / verify_text is a host path (edit distance over texts)");
+    p->ids.reserve(q.terms.size() + q.not_terms.size());
+    for (const auto& raw : q.terms) {
+      const std::string normalized = index.NormalizeText(raw);
+      auto grams = GenerateQueryNgrams(normalized, index.GetNgramSize(), im->query_kanji, index.GetCrossBoundaryNgrams());
+      DeduplicateSorted(grams);
+      if (grams.empty()) {  // :1676-1682
+        p->empty_term_detected = true;
+        return;
+      }
+      size_t n_eff = index.GetNgramSize() > 0 ? static_cast<size_t>(index.GetNgramSize()) : 2;  // :1685-1698
+      if (im->query_kanji > 0) {
+        size_t short_count = 0;
+        for (const auto& g : grams) short_count += g.size() <= 3 ? 1 : 0;
+        if (short_count > grams.size() / 2) n_eff = static_cast<size_t>(im->query_kanji);
+      }
+      const size_t drop = static_cast<size_t>(q.fuzzy_max_distance) * n_eff;  // :1700-1703
+      const size_t theta = grams.size() > drop ? grams.size() - drop : 1;
+      std::vector<uint32_t> known;
+      for (const auto& g : grams) {
+        uint32_t id = 0;
+        if (im->Lookup(g, &id) && im->Size(id) > 0) known.push_back(id);
+      }
+      const bool empty = theta == grams.size() ? known.size() != grams.size() : known.size() < theta;
+      if (empty || known.empty()) known.assign(1, MGX_GRAM_ABSENT);  // the empty doc set, as an operand
+      p->ids.push_back(std::move(known));
+      const auto& ids = p->ids.back();
+      const uint32_t thr = (empty || theta >= ids.size()) ? 0u : static_cast<uint32_t>(theta);
+      p->terms.push_back(mgx_term{ids.data(), static_cast<uint32_t>(ids.size()), thr, 0.0, nullptr, 0});
+    }
+    if (!add_not_terms()) return;
+    for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    finish(MGX_SORT_DOCID);
+    return;
+  }
   std::vector<TermInfo> tis;
   tis.reserve(q.terms.size());
   for (const auto& t : q.terms) tis.push_back(MakeInfo(index, im, t));

@@ -97,6 +97,15 @@ namespace mygramdb::index {
 
 using DocId = storage::DocId;
 
+// Failure reporting for the methods that keep the reference's signatures (std::vector results, no Expected): a device
+// failure cannot travel in the return value, and an empty vector would read as "no hits". Every such method clears
+// this thread's error on entry and sets it on failure; a call site checks it after the call and treats the result as
+// valid only if it is empty (SearchHandler would answer with an error instead of an empty page):
+//     auto hits = index.SearchAnd(terms);
+//     if (!mygramdb::index::LastDeviceError().empty()) return MakeUnexpected(MakeError(kInternalError, ...));
+// (the reference has the same shape of contract around its Roaring fallback, posting_list.cpp:676-689)
+const std::string& LastDeviceError();
+
 class Index {
  public:
   // src/index/index.h:58-60 (roaring_threshold becomes the dense-bitmap density threshold of the device index;
@@ -223,6 +232,10 @@ struct BatchQuery {
   std::shared_ptr<const query::QueryNode> ast;
   std::vector<std::string> not_terms;
   std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
+  uint32_t fuzzy_max_distance = 0;     // FUZZY d (query_parser_clauses.cpp:454: 1 or 2); 0 = not a fuzzy query.
+                                       // ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): per term "at least theta of
+                                       // its n-grams", AND across terms in the order given. Not combined with
+                                       // SORT _score or verify_text here (edit-distance verification reads the texts)
   bool sort_by_score = false;          // SORT _score
   bool verify_text = false;            // the caller's ShouldApplyVerifyText(memory.verify_text, terms) decision
                                        // (search_pipeline.cpp:42-66); mixed-script fragments force it (:858-866)

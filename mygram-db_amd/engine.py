@@ -274,7 +274,8 @@ class Query:
 
 class TermInfo:
     """search_pipeline::SearchTermInfo (src/server/search_pipeline.h:44-55)."""
-    __slots__ = ("term", "normalized", "grams", "gram_ids", "estimated_size", "df", "threshold")
+    __slots__ = ("term", "normalized", "grams", "gram_ids", "estimated_size", "df", "threshold", "fuzzy_ids",
+                 "fuzzy_empty")
 
 
 class SearchResult:
@@ -593,10 +594,21 @@ class Index:
         ti.df = size if (len(ti.grams) == 1 and size and ti.grams[0] == ti.normalized.encode("utf-8")) else None
         ti.threshold = 0
         if fuzzy and ti.grams:
-            # ExecuteWithFuzzy, search_pipeline.cpp:1697-1700
-            short = sum(1 for g in ti.grams if len(g) <= 3)
-            n_eff = (self.kanji_ngram_size or self.ngram_size) if short * 2 > len(ti.grams) else self.ngram_size
-            ti.threshold = max(1, len(ti.grams) - fuzzy * n_eff)
+            # ExecuteWithFuzzy, search_pipeline.cpp:1685-1703: theta = |grams| - d * n_eff, at least 1; n_eff = the kanji
+            # size when more than half of the grams are at most 3 bytes long
+            n_eff = self.ngram_size if self.ngram_size > 0 else 2
+            if self.kanji_ngram_size > 0 and sum(1 for g in ti.grams if len(g) <= 3) > len(ti.grams) // 2:
+                n_eff = self.kanji_ngram_size
+            drop = fuzzy * n_eff
+            ti.threshold = len(ti.grams) - drop if len(ti.grams) > drop else 1
+            # Index::SearchByThreshold (index.cpp:488-578) over the DISTINCT grams: theta == all of them -> SearchAnd
+            # (an unknown gram empties it); otherwise unknown grams are skipped and fewer than theta known ones -> {}
+            known = [g for g in ti.grams if self.posting_size(g) > 0]
+            ti.fuzzy_ids = [(_capi.GRAM_ABSENT if self.columns.lookup(g) is None else self.columns.lookup(g)) for g in known]
+            if ti.threshold == len(ti.grams):
+                ti.fuzzy_empty = len(known) != len(ti.grams)
+            else:
+                ti.fuzzy_empty = len(known) < ti.threshold
         return ti
 
     def prepare(self, queries, into=None):
@@ -605,6 +617,49 @@ class Index:
         cqueries, keep, shells, orders = [], [], [], []
         for q in queries:
             tis = [self.term_info(t, q.fuzzy) for t in q.terms]
+            if q.fuzzy:
+                # ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): terms in the order given (no size sort); a term
+                # without n-grams ends the query; per term "at least theta of its known grams", AND across terms
+                order = list(range(len(tis)))
+                shell = SearchResult()
+                shell.term_order = order
+                orders.append(order)
+                if not tis or any(not t.grams for t in tis):
+                    shell.empty_term_detected = True
+                    shells.append(shell)
+                    continue
+                cterms = (_capi.Term * len(tis))()
+                for j, t in enumerate(tis):
+                    ids_list = [_capi.GRAM_ABSENT] if (t.fuzzy_empty or not t.fuzzy_ids) else t.fuzzy_ids
+                    ids = np.asarray(ids_list, dtype=np.uint32)
+                    keep.append(ids)
+                    thr = 0 if (t.fuzzy_empty or t.threshold >= len(ids)) else t.threshold
+                    cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, 0.0, None, 0)
+                nts = []
+                for nt in q.not_terms:
+                    ti = self.term_info(nt)
+                    if not ti.grams:
+                        raise _capi.MgxError(4, "NOT term shorter than one n-gram is not on the device path")
+                    if ti.estimated_size == 0:
+                        continue
+                    nts.append(ti)
+                cnots = (_capi.Term * max(len(nts), 1))()
+                for j, t in enumerate(nts):
+                    ids = np.asarray(t.gram_ids, dtype=np.uint32)
+                    keep.append(ids)
+                    cnots[j] = _capi.Term(ids.ctypes.data, len(ids), 0, 0.0, None, 0)
+                cf = (_capi.Filter * max(len(q.filters), 1))()
+                for j, (bid, negate) in enumerate(q.filters):
+                    cf[j] = _capi.Filter(bid, int(negate))
+                keep.extend([cterms, cnots, cf])
+                if q.sort_score:
+                    raise _capi.MgxError(4, "FUZZY with SORT _score is not on the device path")
+                cq = _capi.Query(C.cast(cterms, C.c_void_p), len(tis), C.cast(cnots, C.c_void_p), len(nts),
+                                 C.cast(cf, C.c_void_p), len(q.filters), _capi.SORT_DOCID, q.limit, q.offset,
+                                 int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
+                cqueries.append(cq)
+                shells.append(None)
+                continue
             if q.expr is not None:
                 order = list(range(len(tis)))  # expression leaves keep their first-use order
             else:

@@ -1202,6 +1202,237 @@ done:
   return 0;
 }
 
+/* ---- fuzzy search (FUZZY d) ----------------------------------------------------------------------------------- */
+
+/* src/utils/edit_distance.cpp:75-127 ComputeDistanceImpl over code points (bytes of ASCII strings are their code
+ * points): Levenshtein distance, max_distance + 1 once it cannot come back under max_distance. */
+static uint32_t levenshtein_cp(const uint32_t* a, uint32_t na, const uint32_t* b, uint32_t nb, uint32_t max_distance) {
+  if (na > nb) {
+    const uint32_t* t = a; a = b; b = t;
+    uint32_t tn = na; na = nb; nb = tn;
+  }
+  if (nb - na > max_distance) return max_distance + 1;
+  if (na == 0) return nb;
+  uint32_t* dp = (uint32_t*)malloc((na + 1) * sizeof(uint32_t));
+  for (uint32_t j = 0; j <= na; ++j) dp[j] = j;
+  for (uint32_t i = 0; i < nb; ++i) {
+    uint32_t prev = dp[0];
+    dp[0] = i + 1;
+    uint32_t row_min = dp[0];
+    for (uint32_t j = 0; j < na; ++j) {
+      uint32_t cost = a[j] == b[i] ? 0u : 1u;
+      uint32_t ins = dp[j + 1] + 1, del = dp[j] + 1, rep = prev + cost;
+      prev = dp[j + 1];
+      uint32_t m = ins < del ? ins : del;
+      dp[j + 1] = m < rep ? m : rep;
+      if (dp[j + 1] < row_min) row_min = dp[j + 1];
+    }
+    if (row_min > max_distance) {
+      free(dp);
+      return max_distance + 1;
+    }
+  }
+  uint32_t r = dp[na] <= max_distance ? dp[na] : max_distance + 1;
+  free(dp);
+  return r;
+}
+
+/* src/utils/edit_distance.cpp:129-156 ContainsFuzzyCodepointWindow */
+static int contains_fuzzy_window(const uint32_t* word, uint32_t word_len, const uint32_t* term, uint32_t term_len,
+                                 uint32_t max_distance) {
+  uint64_t min_len = term_len > max_distance ? term_len - max_distance : 1;
+  uint64_t max_len = (uint64_t)term_len + max_distance;
+  if (max_len > word_len) max_len = word_len;
+  if (min_len > max_len) return 0;
+  for (uint32_t start = 0; start < word_len; ++start) {
+    uint64_t remaining = word_len - start;
+    uint64_t last = max_len < remaining ? max_len : remaining;
+    for (uint64_t cl = min_len; cl <= last; ++cl)
+      if (levenshtein_cp(word + start, (uint32_t)cl, term, term_len, max_distance) <= max_distance) return 1;
+  }
+  return 0;
+}
+
+static int all_ascii(const uint8_t* s, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (s[i] >= 0x80) return 0;
+  return 1;
+}
+
+/* src/utils/edit_distance.cpp:199-296 ContainsFuzzyMatch: some whitespace-delimited word of the text (U+3000 and U+00A0
+ * count as spaces) is within max_distance of the term; a non-ASCII word is also searched by term-sized code-point
+ * windows, because CJK text has no spaces between words. */
+int orc_contains_fuzzy_match(const uint8_t* text, size_t text_len, const uint8_t* term, size_t term_len,
+                             uint32_t max_distance) {
+  if (term_len == 0) return 1;
+  if (text_len == 0) return 0;
+  uint8_t* nt = (uint8_t*)malloc(text_len + 1); /* NormalizeUnicodeWhitespace :24-47 */
+  size_t nl = 0;
+  for (size_t i = 0; i < text_len;) {
+    if (text[i] == 0xE3 && i + 2 < text_len && text[i + 1] == 0x80 && text[i + 2] == 0x80) {
+      nt[nl++] = ' ';
+      i += 3;
+    } else if (text[i] == 0xC2 && i + 1 < text_len && text[i + 1] == 0xA0) {
+      nt[nl++] = ' ';
+      i += 2;
+    } else {
+      nt[nl++] = text[i++];
+    }
+  }
+  size_t tn = 0;
+  uint32_t* tcp = utf8_to_codepoints(term, term_len, &tn);
+  int term_ascii = all_ascii(term, term_len);
+  int found = 0;
+  size_t pos = 0;
+  while (!found && pos < nl) {
+    while (pos < nl && (nt[pos] == ' ' || nt[pos] == '\t' || nt[pos] == '\r' || nt[pos] == '\n')) ++pos;
+    if (pos >= nl) break;
+    size_t end = pos;
+    while (end < nl && !(nt[end] == ' ' || nt[end] == '\t' || nt[end] == '\r' || nt[end] == '\n')) ++end;
+    size_t wn = 0;
+    uint32_t* wcp = utf8_to_codepoints(nt + pos, end - pos, &wn);
+    int word_ascii = all_ascii(nt + pos, end - pos);
+    if (!word_ascii && !(term_ascii && word_ascii) &&
+        contains_fuzzy_window(wcp, (uint32_t)wn, tcp, (uint32_t)tn, max_distance)) {
+      found = 1;
+    } else {
+      uint32_t diff = wn > tn ? (uint32_t)(wn - tn) : (uint32_t)(tn - wn);
+      if (diff <= max_distance && levenshtein_cp(wcp, (uint32_t)wn, tcp, (uint32_t)tn, max_distance) <= max_distance)
+        found = 1;
+    }
+    free(wcp);
+    pos = end;
+  }
+  free(tcp);
+  free(nt);
+  return found;
+}
+
+/* src/server/search_pipeline.cpp:1659-1744 ExecuteWithFuzzy (no synonyms): per term theta = |grams| - d * n_eff
+ * (at least 1), n_eff = the kanji size when more than half of the term's grams are at most 3 bytes long;
+ * Index::SearchByThreshold(grams, theta); AND across terms in the order given; NOT terms and filters; then — only
+ * when the caller's verify_text decision says so (:1722-1732) — PostFilterByFuzzyText: every term fuzzily contained in
+ * the text; then the exact-text rule for mixed-script fragments (:1733-1741). thetas[] (may be NULL) receives the
+ * threshold of every term. */
+int orc_execute_fuzzy(const orc_index* idx, const orc_docstore* ds, const uint8_t* tb, const uint32_t* toff,
+                      size_t n_terms, uint32_t max_distance, const uint8_t* nb, const uint32_t* noff, size_t n_not,
+                      const orc_filter* filters, size_t n_filters, int ngram_size, int kanji_ngram_size,
+                      int cross_boundary, int verify_text, orc_pipeline_result* out, uint64_t* thetas) {
+  memset(out, 0, sizeof(*out));
+  if (n_terms > 64) return 11;
+  u32vec results = {0};
+  if (n_terms == 0) {
+    out->empty_term_detected = 1;
+    goto done;
+  }
+  term_info* tis = (term_info*)calloc(n_terms, sizeof(term_info));
+  for (size_t i = 0; i < n_terms; ++i)
+    make_term_info(idx, ds, tb + toff[i], toff[i + 1] - toff[i], ngram_size, kanji_ngram_size, cross_boundary, 0,
+                   &tis[i]);
+  int first = 1;
+  for (size_t i = 0; i < n_terms; ++i) {
+    const term_info* ti = &tis[i];
+    if (ti->ngrams.count == 0) { /* :1676-1682 */
+      free(results.v);
+      results.v = NULL;
+      results.n = 0;
+      out->empty_term_detected = 1;
+      first = 0;
+      break;
+    }
+    int n_eff = ngram_size > 0 ? ngram_size : 2; /* :1685-1698 */
+    if (kanji_ngram_size > 0) {
+      size_t short_count = 0;
+      for (size_t g = 0; g < ti->ngrams.count; ++g)
+        if (ti->ngrams.off[g + 1] - ti->ngrams.off[g] <= 3) ++short_count;
+      if (short_count > ti->ngrams.count / 2) n_eff = kanji_ngram_size;
+    }
+    size_t drop = (size_t)max_distance * (size_t)n_eff; /* :1700-1703 */
+    size_t theta = ti->ngrams.count > drop ? ti->ngrams.count - drop : 1;
+    if (thetas) thetas[i] = theta;
+    u32vec tr = {0};
+    tr.v = orc_search_by_threshold(idx, ti->ngrams.bytes, ti->ngrams.off, ti->ngrams.count, theta, &tr.n);
+    if (first) { /* IntersectSorted(results, term_results, first_term) :421-436 */
+      out->total_candidates = tr.n;
+      results = tr;
+      first = 0;
+    } else {
+      u32vec inter = set_intersection_u32(results.v, results.n, tr.v, tr.n);
+      free(tr.v);
+      free(results.v);
+      results = inter;
+    }
+  }
+  out->after_intersection = results.n;
+  /* ApplyNotAndFilters */
+  if (n_not > 0 && results.n > 0) {
+    u32vec excluded = {0};
+    for (size_t i = 0; i < n_not; ++i) {
+      term_info nti;
+      make_term_info(idx, ds, nb + noff[i], noff[i + 1] - noff[i], ngram_size, kanji_ngram_size, cross_boundary, 0,
+                     &nti);
+      u32vec td = search_term_documents(idx, ds, &nti);
+      u32vec u = set_union_u32(excluded.v, excluded.n, td.v, td.n);
+      free(td.v);
+      free(excluded.v);
+      excluded = u;
+      free_term_info(&nti);
+    }
+    if (excluded.n > 0) {
+      u32vec d = set_difference_u32(results.v, results.n, excluded.v, excluded.n);
+      free(results.v);
+      results = d;
+    }
+    free(excluded.v);
+  }
+  out->after_not = results.n;
+  for (size_t f = 0; f < n_filters; ++f) {
+    u32vec r2 = filters[f].negate ? set_difference_u32(results.v, results.n, filters[f].docs, filters[f].n_docs)
+                                  : set_intersection_u32(results.v, results.n, filters[f].docs, filters[f].n_docs);
+    free(results.v);
+    results = r2;
+  }
+  out->after_filters = results.n;
+  if (verify_text && results.n > 0 && ds != NULL) { /* PostFilterByFuzzyText :1746-1757 */
+    size_t w = 0;
+    for (size_t r = 0; r < results.n; ++r) {
+      size_t tl;
+      const uint8_t* tx = docstore_text(ds, results.v[r], &tl);
+      int all = tx != NULL;
+      for (size_t i = 0; all && i < n_terms; ++i)
+        all = orc_contains_fuzzy_match(tx, tl, tis[i].normalized, tis[i].normalized_len, max_distance);
+      if (all) results.v[w++] = results.v[r];
+    }
+    results.n = w;
+  }
+  {
+    int exact = 0; /* RequiresExactTextForHybridFragments :1733-1741 */
+    for (size_t i = 0; i < n_terms; ++i)
+      exact = exact || orc_has_uncovered_hybrid_fragment(tis[i].normalized, tis[i].normalized_len, ngram_size,
+                                                         kanji_ngram_size, cross_boundary);
+    out->exact_text_applied = exact;
+    if (exact && results.n > 0 && ds != NULL) {
+      size_t w = 0;
+      for (size_t r = 0; r < results.n; ++r) {
+        size_t tl;
+        const uint8_t* tx = docstore_text(ds, results.v[r], &tl);
+        int all = tx != NULL;
+        for (size_t i = 0; all && i < n_terms; ++i)
+          all = bytes_find(tx, tl, tis[i].normalized, tis[i].normalized_len, 0) != (size_t)-1;
+        if (all) results.v[w++] = results.v[r];
+      }
+      results.n = w;
+    }
+  }
+  for (size_t i = 0; i < n_terms; ++i) free_term_info(&tis[i]);
+  free(tis);
+done:
+  out->results = results.v ? results.v : u32_dup(NULL, 0);
+  out->n_results = results.n;
+  out->n_terms = n_terms;
+  return 0;
+}
+
 /* PostFilterByText, src/server/search_pipeline.cpp:1239-1246: candidates whose stored text contains every
  * (already normalized) term; order kept. */
 uint32_t* orc_post_filter_by_text(const orc_docstore* ds, const uint32_t* cand, size_t nc, const uint8_t* tb,

@@ -160,6 +160,16 @@ int orc_execute(const orc_index* idx, const orc_docstore* ds, const uint8_t* ter
                 size_t n_terms, const uint8_t* not_bytes, const uint32_t* not_off, size_t n_not,
                 const orc_filter* filters, size_t n_filters, int ngram_size, int kanji_ngram_size, int cross_boundary,
                 size_t filter_threshold, int compute_df, int verify_text, orc_pipeline_result* out);
+/* src/utils/edit_distance.cpp:199-296 ContainsFuzzyMatch. */
+int orc_contains_fuzzy_match(const uint8_t* text, size_t text_len, const uint8_t* term, size_t term_len,
+                             uint32_t max_distance);
+/* src/server/search_pipeline.cpp:1659-1744 ExecuteWithFuzzy: theta / n_eff per term, SearchByThreshold, AND across terms
+ * in the order given, NOT terms, filters, PostFilterByFuzzyText when verify_text (the caller's ShouldApplyVerifyText
+ * decision). thetas (may be NULL): the threshold of every term. */
+int orc_execute_fuzzy(const orc_index* idx, const orc_docstore* ds, const uint8_t* term_bytes, const uint32_t* term_off,
+                      size_t n_terms, uint32_t max_distance, const uint8_t* not_bytes, const uint32_t* not_off,
+                      size_t n_not, const orc_filter* filters, size_t n_filters, int ngram_size, int kanji_ngram_size,
+                      int cross_boundary, int verify_text, orc_pipeline_result* out, uint64_t* thetas);
 /* PostFilterByText, src/server/search_pipeline.cpp:1239-1246 (terms already normalized); caller frees the result. */
 uint32_t* orc_post_filter_by_text(const orc_docstore* ds, const uint32_t* cand, size_t n_cand,
                                   const uint8_t* term_bytes, const uint32_t* term_off, size_t n_terms, size_t* out_n);

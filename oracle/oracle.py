@@ -72,6 +72,11 @@ def lib():
     L.orc_execute.restype = C.c_int
     L.orc_execute.argtypes = [C.c_void_p, C.c_void_p, u8p, u32p, sz, u8p, u32p, sz, C.c_void_p, sz, C.c_int, C.c_int,
                               C.c_int, sz, C.c_int, C.c_int, C.c_void_p]
+    L.orc_contains_fuzzy_match.restype = C.c_int
+    L.orc_contains_fuzzy_match.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_uint32]
+    L.orc_execute_fuzzy.restype = C.c_int
+    L.orc_execute_fuzzy.argtypes = [C.c_void_p, C.c_void_p, u8p, u32p, sz, C.c_uint32, u8p, u32p, sz, C.c_void_p, sz,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.orc_post_filter_by_text.restype = C.POINTER(C.c_uint32)
     L.orc_post_filter_by_text.argtypes = [C.c_void_p, u32p, sz, u8p, u32p, sz, C.POINTER(sz)]
     L.orc_pipeline_result_free.argtypes = [C.c_void_p]
@@ -319,6 +324,45 @@ def execute(index, store, terms, not_terms=(), filters=(), filter_threshold=1000
         "term_estimated_size": [int(pr.term_estimated_size[i]) for i in range(pr.n_terms)],
         "exact_text_applied": bool(pr.exact_text_applied),
     }
+    lib().orc_pipeline_result_free(C.byref(pr))
+    return out
+
+
+def contains_fuzzy_match(text, term, max_distance):
+    """ContainsFuzzyMatch, src/utils/edit_distance.cpp:199-296."""
+    t = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    q = term.encode("utf-8") if isinstance(term, str) else bytes(term)
+    return bool(lib().orc_contains_fuzzy_match(t, len(t), q, len(q), max_distance))
+
+
+def execute_fuzzy(index, store, terms, max_distance, not_terms=(), filters=(), ngram_size=None, kanji_ngram_size=None,
+                  cross_boundary=None, verify_text=False):
+    """search_pipeline::ExecuteWithFuzzy (src/server/search_pipeline.cpp:1659-1744). -> dict like execute() plus
+    "thetas": the SearchByThreshold threshold of every term."""
+    tb, toff = pack_terms(terms)
+    nb, noff = pack_terms(not_terms)
+    keep = []
+    farr = (_Filter * max(len(filters), 1))()
+    for i, (docs, negate) in enumerate(filters):
+        a = np.ascontiguousarray(docs, dtype=np.uint32)
+        keep.append(a)
+        farr[i].docs, farr[i].n_docs, farr[i].negate = a.ctypes.data, len(a), int(negate)
+    pr = _PipelineResult()
+    thetas = np.zeros(max(len(terms), 1), dtype=np.uint64)
+    rc = lib().orc_execute_fuzzy(index._h, store._h if store is not None else None, tb.ctypes.data, toff.ctypes.data,
+                                 len(terms), int(max_distance), nb.ctypes.data, noff.ctypes.data, len(not_terms),
+                                 C.byref(farr), len(filters),
+                                 index.ngram_size if ngram_size is None else ngram_size,
+                                 index.kanji_ngram_size if kanji_ngram_size is None else kanji_ngram_size,
+                                 int(index.cross_boundary if cross_boundary is None else cross_boundary),
+                                 int(verify_text), C.byref(pr), thetas.ctypes.data)
+    if rc != 0:
+        raise ValueError("orc_execute_fuzzy rc=%d" % rc)
+    res = np.ctypeslib.as_array(pr.results, shape=(max(pr.n_results, 1),))[: pr.n_results].copy()
+    out = {"results": res.astype(np.uint32), "total_candidates": pr.total_candidates,
+           "after_intersection": pr.after_intersection, "after_not": pr.after_not, "after_filters": pr.after_filters,
+           "empty_term_detected": bool(pr.empty_term_detected), "exact_text_applied": bool(pr.exact_text_applied),
+           "thetas": [int(t) for t in thetas[: len(terms)]]}
     lib().orc_pipeline_result_free(C.byref(pr))
     return out
 

@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/mygram_tools.h"
 #include "../../mygram-db_amd/csrc/shim/mygram_shim.hpp"
 
 using mygramdb::index::BM25Params;
@@ -275,6 +276,90 @@ int main() {
     } else {
       std::printf("ExecuteBatch(exact) error: %s\n", r.error().message().c_str());
     }
+  }
+  {  // FUZZY (ExecuteWithFuzzy, search_pipeline.cpp:1659-1744) on the reference's pipeline fixture
+     // (tests/server/search_pipeline_test.cpp:916-951, :2034-2052): "learnig" has the bigrams le ea ar rn ni ig,
+     // theta = 6 - 1*2 = 4; docs 1 and 2 hold five of them
+    using namespace mygramdb::search_pipeline;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning techniques");
+    index.AddDocument(3, "old article about cats");
+    std::vector<BatchQuery> qs(4);
+    qs[0].terms = {"learnig"};
+    qs[0].fuzzy_max_distance = 1;
+    qs[1].terms = {"learnig", "machine"};   // AND across terms, in the order given
+    qs[1].fuzzy_max_distance = 1;
+    qs[2].terms = {"zzzzzz"};               // no known gram: empty, not an error
+    qs[2].fuzzy_max_distance = 2;
+    qs[3].terms = {"learnig"};
+    qs[3].fuzzy_max_distance = 1;
+    qs[3].not_terms = {"deep"};
+    for (auto& q : qs) q.order = SortOrder::ASC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      EXPECT((*r)[0].results == (V{1, 2}) && (*r)[0].total_candidates == 2);
+      EXPECT((*r)[1].results == (V{1}));
+      EXPECT((*r)[2].results.empty() && (*r)[2].total == 0);
+      EXPECT((*r)[3].results == (V{1}) && (*r)[3].after_not == 1);
+    } else {
+      std::printf("ExecuteBatch(fuzzy) error: %s\n", r.error().message().c_str());
+    }
+    // BatchExecutor: fresh batches through re-used batch objects, two in flight; deep OFFSET through the same entry
+    BatchExecutor::Options opt;
+    opt.depth = 2;
+    opt.planner_threads = 2;
+    BatchExecutor ex(index, opt);
+    std::vector<BatchQuery> a(2), b(1);
+    a[0].terms = {"learning"};
+    a[0].sort_by_score = true;
+    a[0].limit = 10;
+    a[1].terms = {"cats"};
+    b[0].terms = {"learning"};
+    b[0].sort_by_score = true;
+    b[0].limit = 5;
+    b[0].offset = 1;  // second-ranked doc only
+    for (int round = 0; round < 3; ++round) {
+      auto ta = ex.Submit(a);
+      auto tb = ex.Submit(b);
+      EXPECT(ta.has_value() && tb.has_value());
+      auto full = ex.Submit(a);
+      EXPECT(!full.has_value());  // both slots hold unfetched batches
+      if (!ta || !tb) break;
+      auto ra = ex.Wait(*ta);
+      auto rb = ex.Wait(*tb);
+      EXPECT(ra.has_value() && rb.has_value());
+      if (ra && rb) {
+        EXPECT((*ra)[0].total == 2 && (*ra)[0].results.size() == 2 && (*ra)[1].results == (V{3}));
+        EXPECT((*rb)[0].results.size() == 1 && (*rb)[0].results[0] == (*ra)[0].results[1]);
+        EXPECT((*rb)[0].scores.size() == 1 && (*rb)[0].scores[0] == (*ra)[0].scores[1]);
+      }
+    }
+  }
+  {  // No silent empty result (the reference tests its own allocation failure path,
+     // tests/index/posting_list_test.cpp:188-228): with device allocations failing, the reference-signature methods
+     // return {} AND report through LastDeviceError(); with the hook off the same call succeeds and the error is clear
+    Index index(1, 0, 0.0);
+    for (DocId d = 1; d <= 6000; ++d) index.AddDocument(d, d % 3 == 0 ? "ab" : "a");
+    EXPECT(index.SearchAnd({"b"}).size() == 2000 && mygramdb::index::LastDeviceError().empty());
+    V cand;
+    for (DocId d = 1; d <= 6000; d += 7) cand.push_back(d);
+    const V ok = index.FilterByNgrams(cand, {"a", "b"});
+    EXPECT(!ok.empty() && mygramdb::index::LastDeviceError().empty());
+    mgxt_fail_device_allocs(0, 1000);
+    const V failed = index.FilterByNgrams(cand, {"a", "b"});
+    EXPECT(failed.empty() && !mygramdb::index::LastDeviceError().empty());
+    const V sorted = ResultSorter::SortByScore(index, ok, std::vector<double>(ok.size(), 1.0), SortOrder::DESC, 10, 0);
+    EXPECT(sorted.empty() && !mygramdb::index::LastDeviceError().empty());
+    {
+      Index fresh(2, 0, 0.0);  // its device index cannot even be built
+      fresh.AddDocument(1, "hello");
+      EXPECT(fresh.SearchAnd({"he"}).empty() && !mygramdb::index::LastDeviceError().empty());
+    }
+    mgxt_fail_device_allocs(0, 0);
+    EXPECT(index.FilterByNgrams(cand, {"a", "b"}) == ok && mygramdb::index::LastDeviceError().empty());
+    EXPECT(ResultSorter::SortByScore(index, ok, std::vector<double>(ok.size(), 1.0), SortOrder::DESC, 10, 0).size() == 10);
   }
   std::printf("shim_test: %d checks, %d failed\n", g_checked, g_failed);
   return g_failed == 0 ? 0 : 1;

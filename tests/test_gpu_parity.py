@@ -181,15 +181,45 @@ def test_pipeline_fixture_boolean_vectors():
 
 
 def test_fuzzy_threshold_terms(pair60k):
-    # ExecuteWithFuzzy: per term "at least theta of its grams", AND across terms; checked against the oracle's
-    # SearchByThreshold composition
-    words = sorted({w for i in range(200) for w in pair60k.corpus.text(i).decode().split(" ") if len(w) >= 5})[:20]
-    for w in words:
-        q = Query([w], limit=0, descending=False, fuzzy=1)
-        got = pair60k.dev.search_batch([q])[0]
-        ti = pair60k.dev.term_info(w, 1)
-        want = pair60k.oidx.search_by_threshold(ti.grams, ti.threshold)
-        assert got.docs.tolist() == want.tolist(), w
+    """ExecuteWithFuzzy against the oracle's restatement of search_pipeline.cpp:1659-1744 (pinned by the reference's
+    FUZZY vectors in tests/golden/fuzzy.json): theta / n_eff come from the oracle, not from the code under test; typos,
+    several terms in the given order (no size sort), unknown grams skipped, NOT terms, funnel counters."""
+    words = sorted({w for i in range(400) for w in pair60k.corpus.text(i).decode().split(" ") if len(w) >= 5})
+    rng = np.random.default_rng(21)
+
+    def typo(w):
+        k = int(rng.integers(0, len(w)))
+        return w[:k] + "q" + w[k + 1:]
+
+    cases = []
+    for i, w in enumerate(words[:24]):
+        terms = [w if i % 3 else typo(w)]
+        if i % 4 == 0:
+            terms.append(words[(i * 7 + 3) % len(words)])
+        cases.append((terms, 1 + (i % 5 == 0), [words[(i + 11) % len(words)][:2]] if i % 6 == 1 else []))
+    cases.append((["zzqqzz"], 1, []))         # no known gram at all
+    cases.append((["thequick", "qq"], 2, []))
+    queries = [Query(t, nt, limit=0, descending=False, fuzzy=d) for t, d, nt in cases]
+    got = pair60k.dev.search_batch(queries)
+    for (terms, d, nts), g in zip(cases, got):
+        r = O.execute_fuzzy(pair60k.oidx, pair60k.ostore, terms, d, not_terms=nts, ngram_size=2, kanji_ngram_size=0,
+                            cross_boundary=True)
+        assert g.docs.tolist() == r["results"].tolist(), (terms, d, nts, r["thetas"])
+        assert g.total == len(r["results"])
+        if not r["empty_term_detected"]:
+            for k in ("total_candidates", "after_intersection", "after_not", "after_filters"):
+                assert getattr(g, k) == r[k], (terms, k)
+
+
+def test_fuzzy_cjk_effective_ngram_size():
+    """n_eff of a CJK-dominant term is the kanji size (search_pipeline.cpp:1685-1698): hybrid index (ascii 2, kanji 1),
+    the reference's FuzzyCjk corpus shape."""
+    texts = ["私は東京都に住む", "東京市役所", "大阪府大阪市", "東西南北", "tokyo tower 東京", "京都の市", "abc def"]
+    p = Pair(docs=list(enumerate(texts, start=1)), ngram=2, kanji=1, cross=False)
+    for terms, d in [(["東京市"], 1), (["東京都庁"], 1), (["大阪市"], 2), (["tokyo"], 1), (["東京", "市"], 1)]:
+        got = p.dev.search_batch([Query(terms, limit=0, descending=False, fuzzy=d)])[0]
+        r = O.execute_fuzzy(p.oidx, p.ostore, terms, d, ngram_size=2, kanji_ngram_size=1, cross_boundary=False)
+        assert got.docs.tolist() == r["results"].tolist(), (terms, d, r["thetas"])
 
 
 @pytest.mark.parametrize("ngram", [5, 2], ids=["tf-column", "text-level"])

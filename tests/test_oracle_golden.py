@@ -4,6 +4,7 @@ Every expectation here is data transcribed from /root/reference/tests (see the '
 fixture). Runs on CPU only.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -182,3 +183,33 @@ def test_search_scored_matches_manual_composition():
     assert total == len(r["results"]) and top.tolist() == want.tolist()
     lookup = dict(zip(r["results"].tolist(), sc.tolist()))
     assert [lookup[d] for d in top.tolist()] == scores.tolist()
+
+
+def test_fuzzy_contains_vectors():
+    """tests/utils/edit_distance_test.cpp:86-204 ContainsFuzzyMatch known answers pin the oracle's Levenshtein /
+    word-split / code-point-window restatement (src/utils/edit_distance.cpp)."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fuzzy.json")))
+    for text, term, d, want in g["contains_fuzzy_match"]["cases"]:
+        assert O.contains_fuzzy_match(text, term, d) == want, (text, term, d)
+
+
+def test_fuzzy_pipeline_vectors():
+    """tests/server/search_pipeline_test.cpp:2034-2078: ExecuteFullPipeline with FUZZY 1 and verify_text=all — the typo
+    'learnig' finds the 'learning' docs; a CJK term is verified by code-point windows inside unspaced text."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fuzzy.json")))["pipeline"]
+    for case in g["cases"]:
+        docs = g["docs"] + case.get("extra_docs", [])
+        kanji = case.get("query_kanji", g["index"]["kanji"])
+        idx = O.Index(g["index"]["ngram"], kanji, g["index"]["cross_boundary"])
+        store = O.DocumentStore()
+        for d, t in docs:
+            idx.add_document(d, t)
+            store.add(d, t)
+        r = O.execute_fuzzy(idx, store, case["terms"], case["distance"], verify_text=case["verify_text"])
+        got = r["results"].tolist()
+        if "expect" in case:
+            assert got == case["expect"], case["id"]
+        else:
+            assert len(got) >= case["min_results"] and set(case["expect_contains"]) <= set(got), (case["id"], got)
