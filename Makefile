@@ -26,8 +26,14 @@ $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
 
 # host C++17 layer (reference-signature classes, ExecuteBatch, BatchExecutor) + its C face for ctypes / cgo / JNI callers
-$(SHIM): $(CSRC)/mgx_text.hpp $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp $(CSRC)/shim/mygram_shim.hpp include/mygram_shim_c.h include/mygram_gpu.h $(LIB)
-	g++ $(CXXFLAGS) -shared -o $@ $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp -Lmygram-db_amd -lmygram_gpu -Wl,-rpath,'$$ORIGIN' -pthread
+# ICU (NormalizeText: NFKC / width / lower) when the system has it, like the reference's USE_ICU; MGX_NO_ICU=1 forces
+# the ASCII fallback. mgxs_normalize_uses_icu() / NormalizeTextUsesIcu() report which branch was built.
+ICU_OK := $(if $(MGX_NO_ICU),,$(shell printf '\043include <unicode/unorm2.h>\nint main(){return 0;}' | g++ -x c++ - -licuuc -licui18n -o /dev/null 2>/dev/null && echo 1))
+ICU_FLAGS := $(if $(ICU_OK),-DMGX_USE_ICU,)
+ICU_LIBS := $(if $(ICU_OK),-licui18n -licuuc,)
+SHIM_SRC := $(CSRC)/shim/mygram_shim.cpp $(CSRC)/shim/shim_capi.cpp $(CSRC)/shim/normalize.cpp
+$(SHIM): $(CSRC)/mgx_text.hpp $(SHIM_SRC) $(CSRC)/shim/mygram_shim.hpp include/mygram_shim_c.h include/mygram_gpu.h $(LIB)
+	g++ $(CXXFLAGS) $(ICU_FLAGS) -shared -o $@ $(SHIM_SRC) -Lmygram-db_amd -lmygram_gpu $(ICU_LIBS) -Wl,-rpath,'$$ORIGIN' -pthread
 
 oracle:
 	$(MAKE) -s -C oracle

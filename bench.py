@@ -186,6 +186,9 @@ def main():
     depth = int(os.environ.get("MGX_BENCH_DEPTH", "2"))
     planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, physical_cores()[0] - 1))
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
+    # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
+    # the intersection-only path (mgx::wave_count_kernel + page emit), docid-DESC pages of 10
+    by_score = os.environ.get("MGX_BENCH_SORT", "score") != "docid"
 
     t_setup = time.perf_counter()
     before, mine = mdist.shard_range(n_docs_total, rank, world)
@@ -205,7 +208,7 @@ def main():
     # (1) replay loop: 4 prepared batches re-executed — isolates the device side; the dominant kernel is timed by HIP
     #     events on its launch stream, algorithmic bytes come from the fetched match counts
     # ---------------------------------------------------------------------------------------------------------------
-    replay_q = [[mg.engine.Query(t, sort_score=True, limit=10) for t in tb] for tb in term_batches[:4]]
+    replay_q = [[mg.engine.Query(t, sort_score=by_score, limit=10) for t in tb] for tb in term_batches[:4]]
     batches = [table.prepare(qs) for qs in replay_q]
     replay_steps = max(8, min(args.steps, 40))
 
@@ -260,12 +263,12 @@ def main():
             nxt = 0
             for _ in range(min(depth - 1, k)):
                 sub_t[nxt] = time.perf_counter()
-                pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10)))
+                pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10, sort_by_score=by_score)))
                 nxt += 1
             for i in range(k):
                 if nxt < k:
                     sub_t[nxt] = time.perf_counter()
-                    pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10)))
+                    pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10, sort_by_score=by_score)))
                     nxt += 1
                 j, ticket = pending.pop(0)
                 out = ex.wait(ticket, outs[j % depth])
@@ -339,8 +342,10 @@ def main():
                 "execute_ms": 1e3 * replay_elapsed / replay_steps,
                 "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
                 "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth},
-            "config": {"workload": "10M-doc synthetic ASCII corpus (seed 42), bigram index, 3-term AND + BM25 top-10, "
-                                   "batch=1024 (BASELINE.json configs[1])",
+            "config": {"workload": ("10M-doc synthetic ASCII corpus (seed 42), bigram index, 3-term AND + BM25 top-10, "
+                                    "batch=1024 (BASELINE.json configs[1])") if by_score else
+                                   ("PROFILING VARIANT, not the headline: the same batches without scoring "
+                                    "(intersection only, docid-DESC top-10)"),
                        "n_docs": n_docs_total, "batch": batch_size, "limit": 10, "k1": 1.2, "b": 0.75,
                        "parallelism": "doc-range shards x%d, top-k all-gather + merge" % world,
                        "shard_docs": mine, "shard_grams": cols.n_grams, "shard_postings": cols.n_postings,
@@ -352,9 +357,10 @@ def main():
                          "traffic": None,
                          "peak_measured_read": measured_peak,
                          "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
-                         "kernel": "mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
-                                   "queries with a sorted-list operand run beside it as mgx::wave_score_lists_kernel on a "
-                                   "side stream inside the same timed region)",
+                         "kernel": ("mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
+                                    "queries with a sorted-list operand run beside it as mgx::wave_score_lists_kernel on a "
+                                    "side stream inside the same timed region)") if by_score else
+                                   "mgx::wave_count_kernel (+ tile_eval doc-count share): set algebra + per-tile counts",
                          "kernel_ms": k_ms, "launches_timed": k_n,
                          "algorithmic_bytes_per_launch": alg_total,
                          "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1],

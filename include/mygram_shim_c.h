@@ -29,7 +29,18 @@ int mgxs_table_adopt(mgx_columns* columns, mgx_index* device_index, int ngram_si
  * agree on, so that idf — and every score — is identical on all ranks. */
 int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double avg_doc_length,
                                 const uint64_t* global_posting_sizes, uint64_t n_grams);
+/* Index(normalize_nfkc, normalize_width, normalize_lower) of src/index/index.h:58-60 for an adopted table: how query
+ * terms are normalised before n-gram generation (defaults: nfkc, "keep", lower). */
+int mgxs_table_set_normalization(mgxs_table* table, int nfkc, const char* width, int lower);
 void mgxs_table_destroy(mgxs_table* table);
+
+/* mygram::utils::NormalizeText (src/utils/string_utils.cpp:295-380): NFKC -> width ("narrow" | "wide" | "keep") ->
+ * lower through ICU when this library was built with it (mgxs_normalize_uses_icu() == 1), otherwise the reference's
+ * non-ICU branch (ASCII lower-casing). Invalid UTF-8 normalises to "" (fails closed, :363-366). *out_len receives the
+ * byte length; MGX_ERR_OUT_OF_RANGE when it exceeds cap (nothing is written then). */
+int mgxs_normalize_uses_icu(void);
+int mgxs_normalize_text(const char* text, size_t len, int nfkc, const char* width, int lower, char* out, size_t cap,
+                        size_t* out_len);
 
 int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out);
 void mgxs_executor_destroy(mgxs_executor* ex);

@@ -9,6 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
+           "mgxs_table_set_normalization", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait"]
 _lib = None
 
@@ -29,6 +30,10 @@ def load():
     L.mgxs_last_error.restype = C.c_char_p
     L.mgxs_table_adopt.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
     L.mgxs_table_set_global_stats.argtypes = [vp, u64, f64, vp, u64]
+    L.mgxs_table_set_normalization.argtypes = [vp, i32, C.c_char_p, i32]
+    L.mgxs_normalize_uses_icu.restype = i32
+    L.mgxs_normalize_text.argtypes = [C.c_char_p, C.c_size_t, i32, C.c_char_p, i32, vp, C.c_size_t,
+                                      C.POINTER(C.c_size_t)]
     L.mgxs_table_destroy.argtypes = [vp]
     L.mgxs_table_destroy.restype = None
     L.mgxs_executor_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
@@ -47,6 +52,28 @@ class ShimError(RuntimeError):
 def _check(rc):
     if rc != 0:
         raise ShimError("mgxs error %d: %s" % (rc, load().mgxs_last_error().decode("utf-8", "replace")))
+
+
+def normalize_uses_icu():
+    """Which branch of mygram::utils::NormalizeText this build runs (ICU, or the reference's ASCII fallback)."""
+    return bool(load().mgxs_normalize_uses_icu())
+
+
+def normalize_text(text, nfkc=True, width="keep", lower=True):
+    """mygram::utils::NormalizeText (src/utils/string_utils.cpp:295-380) of the C++ host layer. `text` is str or bytes
+    (bytes may be invalid UTF-8: the answer is then b""); returns the same type."""
+    raw = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+    cap = len(raw) * 3 + 64
+    n = C.c_size_t(0)
+    buf = C.create_string_buffer(cap)
+    rc = load().mgxs_normalize_text(raw, len(raw), int(nfkc), width.encode(), int(lower), buf, cap, C.byref(n))
+    if rc == 3:  # the rare code point that expands further (U+FDFA: 1 -> 18)
+        cap = n.value
+        buf = C.create_string_buffer(cap)
+        rc = load().mgxs_normalize_text(raw, len(raw), int(nfkc), width.encode(), int(lower), buf, cap, C.byref(n))
+    _check(rc)
+    out = buf.raw[: n.value]
+    return out.decode("utf-8") if isinstance(text, str) else out
 
 
 class QueryBatch:
@@ -70,6 +97,8 @@ class Table:
         _check(load().mgxs_table_adopt(index.columns._h, index.device_index._h, index.ngram_size,
                                        index.kanji_ngram_size, int(index.cross_boundary), C.byref(h)))
         self._h = h
+        _check(load().mgxs_table_set_normalization(self._h, int(index.normalize_nfkc), index.normalize_width.encode(),
+                                                   int(index.normalize_lower)))
         if index._global_sizes is not None:
             sizes = np.ascontiguousarray(index._global_sizes, dtype=np.uint64)
             _check(load().mgxs_table_set_global_stats(self._h, int(index.total_docs), float(index.avg_doc_length),

@@ -166,10 +166,13 @@ struct Index::Impl {
 };
 
 Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, bool cross_boundary_ngrams,
-             bool /*normalize_nfkc*/, const std::string& /*normalize_width*/, bool /*normalize_lower*/, int device)
+             bool normalize_nfkc, const std::string& normalize_width, bool normalize_lower, int device)
     : ngram_size_(ngram_size),
       kanji_ngram_size_(kanji_ngram_size > 0 ? kanji_ngram_size : ngram_size),  // index.cpp:31
       cross_boundary_(cross_boundary_ngrams),
+      normalize_nfkc_(normalize_nfkc),
+      normalize_width_(normalize_width),
+      normalize_lower_(normalize_lower),
       impl_(std::make_unique<Impl>()) {
   impl_->device = device;
   impl_->dense_threshold = roaring_threshold;
@@ -257,11 +260,10 @@ std::string Index::Finalize() const {
 
 const std::string& Index::LastError() const { return impl_->last_error; }
 
-std::string Index::NormalizeText(std::string_view text) const {  // non-ICU branch, string_utils.cpp:371-377
-  std::string s(text);
-  for (char& c : s)
-    if (c >= 'A' && c <= 'Z') c = static_cast<char>(c + 32);
-  return s;
+void Index::SetNormalization(bool nfkc, const std::string& width, bool lower) {
+  normalize_nfkc_ = nfkc;
+  normalize_width_ = width;
+  normalize_lower_ = lower;
 }
 
 uint64_t Index::PostingSize(std::string_view term) const {  // index.cpp:580-584

@@ -18,7 +18,8 @@
 //     built and uploaded once (binlog updates are SURVEY.md §8f N4, not built);
 //   * BM25Scorer::ScoreDocuments takes the Index where the reference takes a DocumentStore: tf and doc length come
 //     from the index's own columns, which is exact for search terms that are one n-gram long;
-//   * NormalizeText lower-cases ASCII only (ICU NFKC / width folding is not rebuilt).
+//   * NormalizeText runs ICU (NFKC / width / lower) when the build found ICU, else the reference's ASCII fallback;
+//     mygram::utils::NormalizeTextUsesIcu() says which.
 #pragma once
 
 #include <cstdint>
@@ -87,6 +88,15 @@ class Expected {
   std::variant<T, E> v_;
 };
 
+// src/utils/string_utils.h NormalizeText (string_utils.cpp:295-380): invalid UTF-8 fails closed ("" + the failure
+// counter); with ICU (build flag MGX_USE_ICU, set by the Makefile when <unicode/unorm2.h> is present): NFKC ->
+// width transliteration ("narrow" = Fullwidth-Halfwidth, "wide" = Halfwidth-Fullwidth, anything else keeps) -> full
+// Unicode lower-casing; without ICU: ASCII lower-casing only (the reference's own non-ICU branch, :371-377).
+[[nodiscard]] std::string NormalizeText(std::string_view text, bool nfkc, std::string_view width, bool lower);
+[[nodiscard]] bool NormalizeTextUsesIcu();  // which of the two branches this build runs
+[[nodiscard]] uint64_t GetTextNormalizationFailureCount();
+void ResetTextNormalizationFailureCountForTesting();
+
 }  // namespace mygram::utils
 
 namespace mygramdb::storage {
@@ -140,7 +150,13 @@ class Index {
   [[nodiscard]] int GetNgramSize() const { return ngram_size_; }
   [[nodiscard]] int GetKanjiNgramSize() const { return kanji_ngram_size_; }
   [[nodiscard]] bool GetCrossBoundaryNgrams() const { return cross_boundary_; }
-  [[nodiscard]] std::string NormalizeText(std::string_view text) const;
+  [[nodiscard]] bool GetNormalizeNfkc() const { return normalize_nfkc_; }                 // index.h:312-318
+  [[nodiscard]] const std::string& GetNormalizeWidth() const { return normalize_width_; }
+  [[nodiscard]] bool GetNormalizeLower() const { return normalize_lower_; }
+  void SetNormalization(bool nfkc, const std::string& width, bool lower);  // for adopted handles (Adopt has no ctor args)
+  [[nodiscard]] std::string NormalizeText(std::string_view text) const {                  // index.h:321-323
+    return mygram::utils::NormalizeText(text, normalize_nfkc_, normalize_width_, normalize_lower_);
+  }
 
   // BM25Stats of the table (src/server/server_types.h:157-193), computed when the index is finalised.
   [[nodiscard]] uint64_t Bm25DocCount() const;
@@ -169,6 +185,9 @@ class Index {
  private:
   int ngram_size_, kanji_ngram_size_;
   bool cross_boundary_;
+  bool normalize_nfkc_ = true;
+  std::string normalize_width_ = "keep";
+  bool normalize_lower_ = true;
   std::unique_ptr<Impl> impl_;
 };
 

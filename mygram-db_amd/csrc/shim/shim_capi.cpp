@@ -1,5 +1,6 @@
 // shim_capi.cpp — extern "C" face of the C++17 shim (include/mygram_shim_c.h): what bench.py and the tests bind with
 // ctypes to drive search_pipeline::BatchExecutor, i.e. to plan, compile, run and fetch fresh batches entirely in C++.
+#include <cstring>
 #include <memory>
 #include <string>
 #include <vector>
@@ -55,6 +56,33 @@ int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double a
     const std::string err = table->index->SetGlobalStats(
         total_docs, avg_doc_length, std::vector<uint64_t>(global_posting_sizes, global_posting_sizes + n_grams));
     return err.empty() ? MGX_OK : Fail(MGX_ERR_INVALID_ARGUMENT, err);
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_table_set_normalization(mgxs_table* table, int nfkc, const char* width, int lower) {
+  if (!table || !width) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_set_normalization: null argument");
+  try {
+    table->index->SetNormalization(nfkc != 0, width, lower != 0);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_normalize_uses_icu(void) { return mygram::utils::NormalizeTextUsesIcu() ? 1 : 0; }
+
+int mgxs_normalize_text(const char* text, size_t len, int nfkc, const char* width, int lower, char* out, size_t cap,
+                        size_t* out_len) {
+  if ((len && !text) || !width || !out_len || (cap && !out))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_normalize_text: null argument");
+  try {
+    const std::string r = mygram::utils::NormalizeText(std::string_view(text ? text : "", len), nfkc != 0, width, lower != 0);
+    *out_len = r.size();
+    if (r.size() > cap) return Fail(MGX_ERR_OUT_OF_RANGE, "mgxs_normalize_text: output buffer too small (*out_len holds the size)");
+    if (!r.empty()) std::memcpy(out, r.data(), r.size());
+    return MGX_OK;
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
   }

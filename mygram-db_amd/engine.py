@@ -55,10 +55,17 @@ def generate_query_ngrams(normalized, ngram_size, kanji_ngram_size, cross_bounda
     return _generate_ngrams(normalized, ngram_size)
 
 
-def normalize_text(text):
-    """Index::NormalizeText restricted to what this build restates: ASCII lower-casing (non-ICU branch,
-    string_utils.cpp:371-377). NFKC / width folding (ICU) is not rebuilt: callers pass NFKC-normal text."""
-    return "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in text)
+def normalize_text(text, nfkc=True, width="keep", lower=True):
+    """mygram::utils::NormalizeText (string_utils.cpp:295-380) — the C++ host layer's implementation, so that the shim
+    and this module normalise identically: ICU NFKC -> width -> lower when libmygram_shim.so was built with ICU
+    (`normalize_uses_icu()`), otherwise the reference's non-ICU branch (ASCII lower-casing)."""
+    from . import _shim_capi
+    return _shim_capi.normalize_text(text, nfkc, width, lower)
+
+
+def normalize_uses_icu():
+    from . import _shim_capi
+    return _shim_capi.normalize_uses_icu()
 
 
 def _is_cjk_ideograph_pipeline(cp):
@@ -410,13 +417,15 @@ class Index:
 
     def __init__(self, corpus=None, texts=None, first_doc_id=1, ngram_size=2, kanji_ngram_size=0, cross_boundary=True,
                  device=0, dense_threshold=0.0, total_docs=None, avg_doc_length=None, global_posting_sizes=None,
-                 n_threads=0):
+                 n_threads=0, normalize_nfkc=True, normalize_width="keep", normalize_lower=True):
         if corpus is None:
             corpus = Corpus.from_texts(texts if texts is not None else [])
         self.ngram_size = ngram_size
         # the Index object keeps kanji = ngram when 0 (index.cpp:31); query n-grams use the table config value
         self.kanji_ngram_size = kanji_ngram_size
         self.cross_boundary = cross_boundary
+        # index.h:58-60: how QUERY terms are normalised; document texts arrive normalised (as Index::AddDocument's do)
+        self.normalize_nfkc, self.normalize_width, self.normalize_lower = normalize_nfkc, normalize_width, normalize_lower
         self.columns = Columns(corpus, first_doc_id, ngram_size, kanji_ngram_size, cross_boundary, n_threads)
         self.device_index = DeviceIndex(self.columns, device, dense_threshold)
         self.corpus = corpus        # the DocumentStore's normalized texts
@@ -574,7 +583,7 @@ class Index:
         """GenerateTermInfos for one term (search_pipeline.cpp:569-603); df from posting sizes (single-gram terms)."""
         ti = TermInfo()
         ti.term = term
-        ti.normalized = normalize_text(term)
+        ti.normalized = normalize_text(term, self.normalize_nfkc, self.normalize_width, self.normalize_lower)
         grams = generate_query_ngrams(ti.normalized, self.ngram_size, self.kanji_ngram_size, self.cross_boundary)
         ti.grams = sorted(set(g.encode("utf-8") for g in grams))  # DeduplicateSorted: bytewise
         ti.gram_ids = []

@@ -135,6 +135,33 @@ def count_term_occurrences(text, term):
     return int(lib().orc_count_term_occurrences(t, len(t), m, len(m)))
 
 
+def normalize_text(text, nfkc=True, width="keep", lower=True):
+    """mygram::utils::NormalizeText with ICU (src/utils/string_utils.cpp:307-380), restated with the interpreter's own
+    Unicode tables (unicodedata: an implementation independent of ICU; the tables here are Unicode 13, ICU 70's are
+    14 — identical on every code point assigned by 13): NFKC, then width folding, then full lower-casing. Width is
+    restated for the ASCII block only — "narrow": U+FF01..FF5E -> U+0021..007E and U+3000 -> space, "wide" the inverse
+    (ICU's Fullwidth-Halfwidth / Halfwidth-Fullwidth also fold kana and a few symbols: not restated, callers keep
+    those out of "narrow"/"wide" inputs). Invalid UTF-8 (bytes input) -> "" (:363-366). Pinned by the reference's
+    own NormalizeText vectors (tests/golden/normalize.json)."""
+    import unicodedata
+    if isinstance(text, (bytes, bytearray)):
+        try:
+            text = bytes(text).decode("utf-8")
+        except UnicodeDecodeError:
+            return ""
+    if nfkc:
+        text = unicodedata.normalize("NFKC", text)
+    if width == "narrow":
+        text = "".join(chr(ord(c) - 0xFEE0) if 0xFF01 <= ord(c) <= 0xFF5E else (" " if c == "\u3000" else c)
+                       for c in text)
+    elif width == "wide":
+        text = "".join(chr(ord(c) + 0xFEE0) if 0x21 <= ord(c) <= 0x7E else ("\u3000" if c == " " else c)
+                       for c in text)
+    if lower:
+        text = text.lower()
+    return text
+
+
 def compute_idf(total_docs, doc_freq):
     return float(lib().orc_compute_idf(int(total_docs), int(doc_freq)))
 

@@ -34,6 +34,27 @@ static V Range(DocId a, DocId b, int step) {
 }
 
 int main() {
+  {  // tests/utils/string_utils_test.cpp:136-283 through Index::NormalizeText (index.h:321-323)
+    using mygram::utils::NormalizeText;
+    EXPECT(NormalizeText("ABC", false, "keep", true) == "abc");
+    EXPECT(NormalizeText("ABC", false, "keep", false) == "ABC");
+    mygram::utils::ResetTextNormalizationFailureCountForTesting();
+    EXPECT(NormalizeText(std::string("abc") + static_cast<char>(0xC0) + static_cast<char>(0xAF), true, "keep", true).empty());
+    EXPECT(mygram::utils::GetTextNormalizationFailureCount() == 1);
+    if (mygram::utils::NormalizeTextUsesIcu()) {
+      Index idx(2, 1, 0.0, true, true, "narrow", true);
+      EXPECT(idx.NormalizeText("ＡＢＣ") == "abc");            // :217
+      Index keep(2, 1);                                         // defaults: nfkc, "keep", lower
+      EXPECT(keep.NormalizeText("ﾗｲﾌﾞ") == "ライブ");         // :246
+      EXPECT(keep.NormalizeText("ｱｲｳＡＢＣ") == "アイウabc");  // :229
+      EXPECT(idx.NormalizeText("　！？") == " !?");            // :282
+      Index wide(2, 1, 0.0, true, false, "wide", false);
+      EXPECT(wide.NormalizeText("ABC") == "ＡＢＣ");           // :200
+      std::printf("NormalizeText: ICU branch\n");
+    } else {
+      std::printf("NormalizeText: ASCII fallback (built without ICU)\n");
+    }
+  }
   {  // tests/index/index_search_test.cpp:22-59
     Index index(1);
     index.AddDocument(1, "abc");

@@ -52,7 +52,7 @@ class Pair:
     def oracle_expr(self, e, universe):
         """EvaluateBooleanAstExpanded (src/server/search_pipeline.cpp:327-378) with the oracle's set operations."""
         if isinstance(e, str):
-            norm = mg.engine.normalize_text(e)
+            norm = O.normalize_text(e)
             grams = sorted(set(O.generate_query_ngrams(norm, self.dev.ngram_size, self.dev.kanji_ngram_size,
                                                       self.dev.cross_boundary)))
             return set(self.oidx.search_and(grams).tolist()) if grams else set()
@@ -86,12 +86,15 @@ class Pair:
             if q.limit:
                 page = page[: q.limit]
             return len(res), page, None, {"empty_term_detected": True}
-        r = O.execute(self.oidx, self.ostore, q.terms, q.not_terms, filters, compute_df=q.sort_score,
+        # the C oracle restates the non-ICU NormalizeText branch; the ICU branch is applied here (idempotent under it)
+        q_terms = [O.normalize_text(t) for t in q.terms]
+        q_not = [O.normalize_text(t) for t in q.not_terms]
+        r = O.execute(self.oidx, self.ostore, q_terms, q_not, filters, compute_df=q.sort_score,
                       ngram_size=self.dev.ngram_size, kanji_ngram_size=self.dev.kanji_ngram_size,
                       cross_boundary=self.dev.cross_boundary, verify_text=q.verify_text)
         res = r["results"]
         if q.sort_score:
-            terms = [mg.engine.normalize_text(q.terms[i]) for i in r["term_order"]]
+            terms = [q_terms[i] for i in r["term_order"]]
             sc = O.score_documents(self.ostore, res, terms, r["term_df"], self.N, self.avgdl, q.k1, q.b)
             page = O.sort_by_score(res, sc, q.descending, q.limit, q.offset)
             lookup = dict(zip(res.tolist(), sc.tolist()))

@@ -127,3 +127,52 @@ def test_config3_shape_3term_and_top100_batch_1024(pair1m):
         assert g.total == total, (i, qs[i].terms)
         assert g.docs.tolist() == docs.tolist(), (i, qs[i].terms)
         assert np.array_equal(g.scores, scores), (i, qs[i].terms)
+
+
+def test_config2_raw_width_and_case_variants_are_normalised_like_the_reference():
+    """configs[2] as a client sends it: half-width katakana, full-width Latin, upper case and compatibility forms in
+    documents AND queries. Documents are normalised before Index::AddDocument (as the reference's loaders do with
+    NormalizeText); query terms inside the planner (Index::NormalizeText, ICU NFKC + lower). Engine and the C++ executor
+    against the oracle, whose normaliser is independent of ICU."""
+    from mygram_db_amd import _shim_capi as S
+    if not S.normalize_uses_icu():
+        pytest.skip("built without ICU: queries must arrive NFKC-normal")
+    rng = np.random.default_rng(91)
+    half_kana = [chr(c) for c in range(0xFF66, 0xFF9E)] + ["ｶﾞ", "ｷﾞ", "ﾊﾟ", "ﾋﾞ", "ﾌﾞ"]
+    full_latin = [chr(c) for c in range(0xFF21, 0xFF3B)] + [chr(c) for c in range(0xFF41, 0xFF5B)]
+    kanji = [chr(0x4E00 + i) for i in range(400)]
+    extra = ["ﬁ", "①", "㈱", "Å", "É", "Σ", "ß", "ǅ", "㌔", " "]
+    pools = [half_kana, full_latin, kanji, [chr(c) for c in range(0x41, 0x5B)], extra]
+    raw = []
+    for _ in range(40_000):
+        n = int(rng.integers(8, 33))
+        raw.append("".join(str(rng.choice(pools[int(rng.choice(5, p=[.3, .2, .3, .15, .05]))])) for _ in range(n)))
+    texts = [O.normalize_text(t) for t in raw]
+    for i in rng.choice(len(raw), size=2000, replace=False).tolist():  # the product's normaliser says the same
+        assert S.normalize_text(raw[i]) == texts[i], raw[i]
+    p = Pair(docs=list(enumerate(texts, start=1)), ngram=2, kanji=1)
+
+    def raw_term():
+        d = raw[int(rng.integers(0, len(raw)))]
+        n = int(rng.integers(2, 5))
+        s = int(rng.integers(0, max(1, len(d) - n)))
+        return d[s:s + n]
+
+    qs = [Query([raw_term() for _ in range(int(rng.integers(1, 4)))], sort_score=True, limit=20) for _ in range(600)]
+    # (a term that normalises to less than one n-gram takes the substring fallback: covered in test_gpu_parity.py)
+    qs = [q for q in qs if all(" " not in O.normalize_text(t) and O.generate_query_ngrams(O.normalize_text(t), 2, 1, True)
+                               for t in q.terms)]
+    got = p.dev.search_batch(qs)
+    hits = 0
+    for q, g in zip(qs, got):
+        total, page, scores, _ = p.oracle_query(q)
+        assert g.total == total and g.docs.tolist() == page.tolist(), q.terms
+        assert np.array_equal(g.scores, scores), q.terms
+        hits += total > 0
+    assert len(qs) > 200 and hits > 100
+    # the same raw batch through search_pipeline::BatchExecutor (planned and normalised in C++)
+    ex = S.Executor(S.Table(p.dev), depth=1, planner_threads=2)
+    totals, n_docs, docs, scores, _ = ex.wait(ex.submit(S.QueryBatch([q.terms for q in qs]), limit=20))
+    for qi, g in enumerate(got):
+        assert totals[qi] == g.total and docs[qi, :n_docs[qi]].tolist() == g.docs.tolist(), qs[qi].terms
+        assert np.array_equal(scores[qi, :n_docs[qi]], g.scores), qs[qi].terms

@@ -163,3 +163,68 @@ def test_columns_tf_overflow_table():
     # "ab" x255, "ba" inside "ab" x300, "ab" x300, "aa" in 700 a's
     assert sorted(cols.tf_overflow_val.tolist()) == [255, 299, 300, 350]
     assert np.all(np.diff(cols.tf_overflow_pos.astype(np.int64)) > 0)
+
+
+def _normalize_vectors():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "normalize.json"), encoding="utf-8"))
+
+
+def test_normalize_text_reference_vectors():
+    """mygram::utils::NormalizeText of the host layer (csrc/shim/normalize.cpp) against the reference's own vectors;
+    the vectors inside the reference's #ifdef USE_ICU apply when this build found ICU (the image has ICU 70)."""
+    from mygram_db_amd import _shim_capi as S
+    doc = _normalize_vectors()
+    icu = S.normalize_uses_icu()
+    ran = 0
+    for v in doc["vectors"]:
+        if v["needs_icu"] and not icu:
+            continue
+        assert S.normalize_text(v["text"], v["nfkc"], v["width"], v["lower"]) == v["expected"], v
+        ran += 1
+    assert ran >= (len(doc["vectors"]) if icu else 5)
+    bad = doc["invalid_utf8"]  # fails closed
+    assert S.normalize_text(bytes.fromhex(bad["hex"]), bad["nfkc"], bad["width"], bad["lower"]) == b""
+    assert mg.engine.normalize_uses_icu() == icu
+
+
+def test_normalize_text_against_oracle_restatement():
+    """ICU (the product's host layer) vs the oracle's independent restatement (the interpreter's Unicode tables) on
+    seeded strings over the blocks a CJK / Latin corpus meets: compatibility forms, width forms, case pairs."""
+    from mygram_db_amd import _shim_capi as S
+    if not S.normalize_uses_icu():
+        pytest.skip("built without ICU: only the ASCII branch exists")
+    import unicodedata
+    rng = np.random.default_rng(77)
+    blocks = [(0x20, 0x7E), (0xA0, 0x24F), (0x370, 0x3FF), (0x400, 0x4FF), (0x2100, 0x214F), (0x2460, 0x24FF),
+              (0x3040, 0x30FF), (0x3300, 0x33FF), (0x4E00, 0x4FFF), (0xFB00, 0xFB06), (0xFF01, 0xFFEE), (0x1F600, 0x1F64F)]
+    checked = 0
+    for _ in range(400):
+        cps = []
+        for _ in range(int(rng.integers(1, 24))):
+            lo, hi = blocks[int(rng.integers(len(blocks)))]
+            c = int(rng.integers(lo, hi + 1))
+            if unicodedata.category(chr(c)) == "Cn":  # unassigned in the interpreter's (older) tables: version-dependent
+                continue
+            cps.append(c)
+        s = "".join(map(chr, cps))
+        for nfkc in (True, False):
+            for lower in (True, False):
+                assert S.normalize_text(s, nfkc, "keep", lower) == O.normalize_text(s, nfkc, "keep", lower), \
+                    ([hex(c) for c in cps], nfkc, lower)
+                checked += 1
+        ascii_only = "".join(chr(c) for c in cps if c < 0x7F or 0xFF01 <= c <= 0xFF5E)
+        for w in ("narrow", "wide"):
+            assert S.normalize_text(ascii_only, False, w, False) == O.normalize_text(ascii_only, False, w, False), \
+                (ascii_only, w)
+    assert checked == 1600
+
+
+def test_index_normalizes_query_terms_like_the_reference():
+    """Index::NormalizeText forwards its three settings (index.h:321-323); engine.Index plans with them."""
+    from mygram_db_amd import _shim_capi as S
+    if not S.normalize_uses_icu():
+        pytest.skip("built without ICU")
+    assert S.normalize_text("ﾗｲﾌﾞ ＡＢＣ") == "ライブ abc"
+    assert S.normalize_text("ＡＢＣ", False, "keep", False) == "ＡＢＣ"
+    assert S.normalize_text("ÀÉ Σ", True, "keep", True) == "àé σ"

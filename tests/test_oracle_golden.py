@@ -3,6 +3,7 @@
 Every expectation here is data transcribed from /root/reference/tests (see the 'source' field of each
 fixture). Runs on CPU only.
 """
+import json
 import math
 import os
 
@@ -213,3 +214,12 @@ def test_fuzzy_pipeline_vectors():
             assert got == case["expect"], case["id"]
         else:
             assert len(got) >= case["min_results"] and set(case["expect_contains"]) <= set(got), (case["id"], got)
+
+
+def test_normalize_text_vectors():
+    """The ICU branch of NormalizeText as the oracle restates it (unicodedata) against the reference's own vectors."""
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "normalize.json"), encoding="utf-8"))
+    for v in doc["vectors"]:
+        assert O.normalize_text(v["text"], v["nfkc"], v["width"], v["lower"]) == v["expected"], v
+    bad = doc["invalid_utf8"]
+    assert O.normalize_text(bytes.fromhex(bad["hex"]), bad["nfkc"], bad["width"], bad["lower"]) == bad["expected"]
