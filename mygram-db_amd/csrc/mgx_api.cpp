@@ -258,6 +258,7 @@ struct mgx_index {
   DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
   DevBuf d_dl8, d_tfnib, d_tf_ovf_pos, d_tf_ovf_val;
+  DevBuf d_dev_index;  // `dev` in device memory: what out-of-line device functions take a pointer to (SyncDevIndex)
   std::vector<uint64_t> h_offsets;
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
@@ -286,6 +287,22 @@ struct mgx_index {
   DevBuf d_table_pool;
   uint32_t table_cap = 0, table_used = 0, table_dl = 0;
   size_t table_doubles() const { return static_cast<size_t>(mgx::kFastPoolTf + 1) * table_dl; }
+  // K[dl] = k1 * (1 - b + b * dl / avgdl), dl 0..255, per (k1, b, avgdl) of a batch (group_score_kernel)
+  struct NormTable {
+    uint64_t k1, b, avg;
+    DevBuf d;
+  };
+  std::vector<std::unique_ptr<NormTable>> norm_tables;
+  // block-max bytes of the dense grams' BM25 term factor per (k1, b, avgdl) (build_blockmax_kernel): top-k pruning
+  struct BlockMax {
+    uint64_t k1, b, avg;
+    double step;
+    DevBuf d, d_fine;
+  };
+  std::vector<std::unique_ptr<BlockMax>> block_max;
+  uint32_t n_bitmap_rows = 0, n_fine_rows = 0;
+  DevBuf d_fine_rows;                 // fine row -> bitmap row
+  std::vector<uint32_t> h_fine_map;   // bitmap row -> fine row (kNoRow: none)
 };
 
 namespace mgx {
@@ -293,6 +310,16 @@ static inline uint64_t Bits(double d) {
   uint64_t u;
   std::memcpy(&u, &d, 8);
   return u;
+}
+
+// Keeps the device-memory copy of idx->dev current (after creation and whenever a pointer inside it changes).
+static hipError_t SyncDevIndex(mgx_index* idx) {
+  if (!idx->d_dev_index.p) {
+    ResourceScope none(nullptr);
+    hipError_t e = idx->d_dev_index.Alloc(sizeof(DevIndex));
+    if (e != hipSuccess) return e;
+  }
+  return hipMemcpy(idx->d_dev_index.p, &idx->dev, sizeof(DevIndex), hipMemcpyHostToDevice);
 }
 
 // Device address of the contribution table of (dense gram row, idf, k1, b, avgdl); built and uploaded on first use.
@@ -329,6 +356,93 @@ static uint64_t GetContributionTable(mgx_index* idx, uint32_t bm_row, double idf
   idx->table_used++;
   idx->table_slot.emplace(key, slot);
   return reinterpret_cast<uint64_t>(dst);
+}
+
+// Device address of K[0..255], K[dl] = k1 * ((1 - b) + b * dl / max(avgdl, 1)): the doc-length half of the BM25
+// denominator (bm25_scorer.cpp:80-84), evaluated on the host operation by operation so that tf + K[dl] is the
+// reference's denominator bit for bit. nullptr when it cannot be built (the queries then take the table-based path).
+static const double* GetLengthNormTable(mgx_index* idx, double k1, double b, double avgdl) {
+  std::lock_guard<std::mutex> lock(idx->table_mu);
+  for (const auto& t : idx->norm_tables)
+    if (t->k1 == Bits(k1) && t->b == Bits(b) && t->avg == Bits(avgdl)) return t->d.as<double>();
+  if (idx->norm_tables.size() >= 64) return nullptr;
+  double h[256];
+  const double one_minus_b = 1.0 - b, avg = std::max(avgdl, 1.0);
+  for (uint32_t dli = 0; dli < 256; ++dli) {
+    const double length_norm = one_minus_b + b * static_cast<double>(dli) / avg;
+    h[dli] = k1 * length_norm;
+  }
+  auto t = std::make_unique<mgx_index::NormTable>();
+  t->k1 = Bits(k1);
+  t->b = Bits(b);
+  t->avg = Bits(avgdl);
+  ResourceScope none(nullptr);  // index-owned memory, not a batch arena
+  if (hipSetDevice(idx->device) != hipSuccess || t->d.Alloc(sizeof(h)) != hipSuccess ||
+      hipMemcpy(t->d.p, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  idx->norm_tables.push_back(std::move(t));
+  return idx->norm_tables.back()->d.as<double>();
+}
+
+// Block-max bytes of the index for (k1, b, avgdl), built on first use (one pass over the tf-nibble rows and doc
+// lengths: a few ms, ~9 bytes per 64 docs per dense gram... 1 byte per word per row). nullptr when pruning is off for
+// these parameters (it needs k1 > 0 and 0 <= b <= 1: the term factor must grow with tf and shrink with dl), when the
+// index has no tf columns, or when the few parameter sets an index keeps are taken.
+static const uint8_t* GetBlockMax(mgx_index* idx, double k1, double b, double avgdl, double* step, const uint8_t** fine) {
+  *fine = nullptr;
+  static const bool off = std::getenv("MGX_NO_PRUNE") != nullptr && atoi(std::getenv("MGX_NO_PRUNE")) != 0;
+  if (off || !idx->can_score || idx->n_bitmap_rows == 0 || !(k1 > 0.0) || !(b >= 0.0 && b <= 1.0) || !(avgdl >= 0.0))
+    return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(idx->table_mu);
+    for (const auto& t : idx->block_max)
+      if (t->k1 == Bits(k1) && t->b == Bits(b) && t->avg == Bits(avgdl)) {
+        *step = t->step;
+        *fine = t->d_fine.as<uint8_t>();
+        return t->d.as<uint8_t>();
+      }
+    if (idx->block_max.size() >= 4) return nullptr;
+  }
+  const double* ktab = GetLengthNormTable(idx, k1, b, avgdl);
+  if (!ktab) return nullptr;
+  std::lock_guard<std::mutex> lock(idx->table_mu);
+  for (const auto& t : idx->block_max)  // (another planner thread may have built it meanwhile)
+    if (t->k1 == Bits(k1) && t->b == Bits(b) && t->avg == Bits(avgdl)) {
+      *step = t->step;
+      *fine = t->d_fine.as<uint8_t>();
+      return t->d.as<uint8_t>();
+    }
+  auto t = std::make_unique<mgx_index::BlockMax>();
+  t->k1 = Bits(k1);
+  t->b = Bits(b);
+  t->avg = Bits(avgdl);
+  t->step = (k1 + 1.0) / 250.0;
+  ResourceScope none(nullptr);
+  const size_t bytes = static_cast<size_t>(idx->dev.n_tiles) * idx->n_bitmap_rows * 256u;
+  if (hipSetDevice(idx->device) != hipSuccess || t->d.Alloc(bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const size_t fine_bytes = static_cast<size_t>(idx->dev.n_tiles) * idx->n_fine_rows * 1024u;
+  if (fine_bytes && t->d_fine.Alloc(fine_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (LaunchBuildBlockMax(idx->dev.tfnib, idx->dev.nib_row_stride, idx->dev.dl8, ktab, k1 + 1.0, 1.0 / t->step, nullptr,
+                          idx->n_bitmap_rows, idx->dev.n_tiles, false, t->d.p, idx->stream) != 0 ||
+      LaunchBuildBlockMax(idx->dev.tfnib, idx->dev.nib_row_stride, idx->dev.dl8, ktab, k1 + 1.0, 1.0 / t->step,
+                          idx->d_fine_rows.as<uint32_t>(), idx->n_fine_rows, idx->dev.n_tiles, true, t->d_fine.p,
+                          idx->stream) != 0 ||
+      hipStreamSynchronize(idx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *step = t->step;
+  *fine = t->d_fine.as<uint8_t>();
+  idx->block_max.push_back(std::move(t));
+  return idx->block_max.back()->d.as<uint8_t>();
 }
 }  // namespace mgx
 
@@ -538,9 +652,10 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
     MGX_HIP(idx->d_table_pool.Alloc(static_cast<size_t>(idx->table_cap) * idx->table_doubles() * sizeof(double)));
   }
   if (idx->can_score) {
-    std::vector<uint8_t> dl8(n_docs);
+    // padded to whole tiles (zeros): group_score_kernel copies a tile's 16 KiB into LDS whole
+    std::vector<uint8_t> dl8((n_docs + mgx::kTileDocs - 1) / mgx::kTileDocs * mgx::kTileDocs, 0);
     for (uint64_t i = 0; i < n_docs; ++i) dl8[i] = static_cast<uint8_t>(std::min<uint32_t>(d->doc_len[i], 255u));
-    MGX_HIP(mgx::Upload(idx->d_dl8, dl8.data(), n_docs, 16));
+    MGX_HIP(mgx::Upload(idx->d_dl8, dl8.data(), dl8.size(), 16));
   }
 
   mgx::DevIndex& v = idx->dev;
@@ -557,6 +672,22 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.tile_off = idx->d_tile_off.as<uint32_t>();
   v.gram_bitmaps = idx->d_gram_bitmaps.as<uint64_t>();
   v.gb_tile_stride = bm_grams.size() * mgx::kWordsPerTile;
+  idx->n_bitmap_rows = static_cast<uint32_t>(bm_grams.size());
+  if (idx->can_score && !bm_grams.empty()) {
+    // the grams held by more than a fifth of the docs get block-max bytes per 16-doc quarter (GetBlockMax)
+    static const double kFineDensity = std::getenv("MGX_FINE_DENSITY") ? atof(std::getenv("MGX_FINE_DENSITY")) : 0.2;
+    std::vector<uint32_t> fine_map(bm_grams.size(), mgx::kNoRow), fine_rows;
+    for (size_t r = 0; r < bm_grams.size(); ++r) {
+      const uint64_t sz = d->offsets[bm_grams[r] + 1] - d->offsets[bm_grams[r]];
+      if (static_cast<double>(sz) > kFineDensity * static_cast<double>(n_docs)) {
+        fine_map[r] = static_cast<uint32_t>(fine_rows.size());
+        fine_rows.push_back(static_cast<uint32_t>(r));
+      }
+    }
+    idx->n_fine_rows = static_cast<uint32_t>(fine_rows.size());
+    idx->h_fine_map = fine_map;
+    MGX_HIP(mgx::Upload(idx->d_fine_rows, fine_rows.data(), fine_rows.size(), 1));
+  }
   v.gb_row_stride = mgx::kWordsPerTile;
   idx->filter_row_stride = idx->words_per_row + 32 * ((n_tiles % 2) ? 1 : 3);  // 256 B / 768 B of padding
   v.fb_tile_stride = mgx::kWordsPerTile;
@@ -566,6 +697,7 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.n_docs = static_cast<uint32_t>(n_docs);
   v.n_tiles = n_tiles;
   v.max_doc_len = max_doc_len;
+  MGX_HIP(mgx::SyncDevIndex(idx.get()));
   *out = idx.release();
   return MGX_OK;
 }
@@ -628,6 +760,7 @@ int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint6
   MGX_HIP(mgx::Upload(idx->d_text_off, rel.data(), rel.size()));
   idx->dev.text = idx->d_text.as<uint8_t>();
   idx->dev.text_off = idx->d_text_off.as<uint64_t>();
+  MGX_HIP(mgx::SyncDevIndex(idx));
   return MGX_OK;
 }
 
@@ -652,6 +785,7 @@ int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t
     idx->d_filter_bitmaps = std::move(nb);
     idx->filter_cap_rows = ncap;
     idx->dev.filter_bitmaps = idx->d_filter_bitmaps.as<uint64_t>();
+    MGX_HIP(mgx::SyncDevIndex(idx));
   }
   const uint32_t row = idx->n_filter_rows;
   uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->filter_row_stride;
@@ -1072,7 +1206,7 @@ struct mgx_batch {
     mgx::WavePlan wplan_lists{};
     mgx::DevBatch dev_wave_lists{};
     DevBuf d_items_wave_lists;
-    // score mode, fast path (and_score_kernel<T>): resolved query descriptors and one item list per number of scored terms
+    // score mode, fast path (bitmap_score_kernel<T>): resolved query descriptors and one item list per number of scored terms
     mgx::FastPlan fplan{};
     mgx::DevBatch dev_fast[mgx::kFastMaxScore]{};
     DevBuf d_fast_queries, d_items_fast[mgx::kFastMaxScore];
@@ -1210,16 +1344,19 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   std::vector<DevFastQuery> fastq;
   std::vector<uint64_t> wave_tables;
   if (score_mode) {
-    // ---- fast path: flat programs over bitmap-form operands, 1..4 scored terms that are dense grams --------------
-    // and_score_kernel is opt-in (MGX_FAST_PATH=1): measured slower than wave_score_kernel on the benchmark batch
-    // (both are bound by the gather line traffic, and this one holds fewer waves per CU)
-    const bool allow_fast = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr && std::getenv("MGX_FAST_PATH") != nullptr &&
-                            atoi(std::getenv("MGX_FAST_PATH")) != 0;
+    // ---- fast path (bitmap_score_kernel): flat programs over bitmap-form operands, 1..5 scored terms that are dense
+    // grams, a page of at most 128 entries, one (k1, b, avgdl) for the whole set (they are table constants)
+    const bool allow_fast = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr &&
+                            !(std::getenv("MGX_FAST_PATH") && atoi(std::getenv("MGX_FAST_PATH")) == 0);
     mgx_index* idx = b->idx;
-    uint32_t fsc = 0, fcap = 64;
+    uint32_t fcap = 64;
+    bool have_params = false;
+    double pk1 = 0, pb = 0, pavg = 0;
     for (uint32_t i = 0; allow_fast && i < n; ++i) {
       const QuerySpec& s = specs[g.qids[i]];
       if (!s.flat || !s.fast_score_ok || s.score.empty() || s.score.size() > static_cast<size_t>(kFastMaxScore)) continue;
+      if (dq[i].cap > 128) continue;
+      if (have_params && (Bits(s.k1) != Bits(pk1) || Bits(s.b) != Bits(pb) || Bits(s.avgdl) != Bits(pavg))) continue;
       DevFastQuery f{};
       bool ok = true;
       for (uint32_t ins : s.prog) {
@@ -1255,13 +1392,34 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         if (lf.kind != kLeafGramBitmap) { ok = false; break; }
         FastScore& fs = f.score[t];
         fs.nib = reinterpret_cast<uint64_t>(idx->dev.tfnib + static_cast<uint64_t>(lf.b) * idx->dev.nib_row_stride);
-        fs.table = GetContributionTable(idx, lf.b, s.score[t].idf, s.k1, s.b, s.avgdl);
         fs.idf = s.score[t].idf;
         fs.gram = lf.a;
         fs.skip_row = lf.row;
-        ok = fs.table != 0;
       }
       if (!ok) continue;
+      if (s.reverse != 0) {  // SORT _score DESC: top-k pruning by block-max bounds
+        double step = 0.0;
+        f.blockmax = GetBlockMax(idx, s.k1, s.b, s.avgdl, &step, &f.blockmax_fine);
+        if (f.blockmax) {
+          f.bm_tile_stride = idx->n_bitmap_rows * 256u;
+          f.bmf_tile_stride = idx->n_fine_rows * 1024u;
+          for (size_t t = 0; t < s.score.size(); ++t) {
+            const DevLeaf& lf = s.leaves[s.score[t].leaf];
+            FastScore& fs = f.score[t];
+            // (weights rounded up: the fp32 bound must stay above the exact one)
+            fs.bm_weight = std::nextafter(static_cast<float>(s.score[t].idf * step) * (1.0f + 0x1p-20f), INFINITY);
+            const uint32_t frow = f.blockmax_fine ? idx->h_fine_map[lf.b] : kNoRow;
+            fs.bm_mode = frow != kNoRow ? 2u : 1u;
+            fs.bm_off = frow != kNoRow ? frow * 1024u : lf.b * 256u;
+          }
+        }
+      }
+      if (!have_params) {
+        pk1 = s.k1;
+        pb = s.b;
+        pavg = s.avgdl;
+        have_params = true;
+      }
       f.n_score = static_cast<uint32_t>(s.score.size());
       f.needed = dq[i].needed;
       f.cap = dq[i].cap;
@@ -1274,12 +1432,14 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       if (fastq.empty()) fastq.resize(n);
       fastq[i] = f;
       on_wave[i] = 3;
-      fsc = std::max(fsc, f.n_score);
       fcap = std::max(fcap, f.cap);
     }
-    g.fplan = PlanFast(fsc, fcap, idx->dev.max_doc_len);
-    if (g.fplan.bytes > 160 * 1024)  // (a page of ~1000 entries per wave does not fit beside the tables)
-      for (auto& w : on_wave) w = 0;
+    if (have_params) {
+      const double* ktab = GetLengthNormTable(idx, pk1, pb, pavg);
+      g.fplan = PlanFast(fcap, ktab);
+      if (ktab == nullptr || g.fplan.bytes > 64 * 1024)
+        for (auto& w : on_wave) w = 0;
+    }
     const bool allow = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr;
     uint32_t wl = 0, wsc = 0, wi = 0, wc = 64;
     bool has_list = false;
@@ -1378,10 +1538,13 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   // cost of one tile ~ 1 (operand fetch, program) + matches/128 (enumeration + scoring); a workgroup gets ~48 units.
   std::vector<DevItem> items;
   std::vector<uint32_t> list_begin(n + 1, 0);
+  uint32_t n_lists = 0;
+  std::vector<uint32_t> item_begin(n + 1, 0);  // a query's own items (none for the members of a group)
   {
     const uint32_t n_tiles = b->idx->dev.n_tiles;
     for (uint32_t i = 0; i < n; ++i) {
       const QuerySpec& s = specs[g.qids[i]];
+      item_begin[i] = static_cast<uint32_t>(items.size());
       static const double kMatchesPerUnit = std::getenv("MGX_ITEM_MATCHES") ? atof(std::getenv("MGX_ITEM_MATCHES")) : 256.0;
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 192.0;
       // (a text scan per candidate costs about what scoring a match does)
@@ -1392,14 +1555,14 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // the workgroup kernel walks its tiles one after the other (~4 us each): short items keep the few queries it
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;
-      list_begin[i] = static_cast<uint32_t>(items.size());
+      list_begin[i] = n_lists;
       for (uint32_t t = 0; t < n_tiles; t += tiles) {
-        DevItem it{i, t, std::min(tiles, n_tiles - t), 0};
+        DevItem it{i, t, std::min(tiles, n_tiles - t), n_lists++};  // candidate lists stay grouped by query
         items.push_back(it);
       }
     }
-    list_begin[n] = static_cast<uint32_t>(items.size());
-    for (uint32_t k = 0; k < items.size(); ++k) items[k].list = k;  // candidate lists stay grouped by query
+    list_begin[n] = n_lists;
+    item_begin[n] = static_cast<uint32_t>(items.size());
     // Launch order: by doc band (kSortTiles tiles), so concurrent workgroups share operand tiles in L2/MALL; inside a
     // band by the query's largest gram (its bitmap and tf column are the lines the band re-reads most), dealt so that
     // workgroup j — which runs on XCD j % 8 under round-robin dispatch, every XCD with its own L2 — gets a contiguous
@@ -1433,7 +1596,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       std::vector<uint32_t> cur(band_at.begin(), band_at.end() - 1);
       for (uint32_t oi = 0; oi < n; ++oi) {
         const uint32_t i = order[oi];
-        for (uint32_t k = list_begin[i]; k < list_begin[i + 1]; ++k) sorted[cur[items[k].tile_begin / kSortTiles]++] = items[k];
+        for (uint32_t k = item_begin[i]; k < item_begin[i + 1]; ++k) sorted[cur[items[k].tile_begin / kSortTiles]++] = items[k];
       }
     }
     if (kXcdAffinity && score_mode) {
@@ -1448,7 +1611,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       items.swap(sorted);
     }
   }
-  const uint32_t n_lists_all = static_cast<uint32_t>(items.size());
+  const uint32_t n_lists_all = n_lists;
   std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore];
   for (const DevItem& it : items) {
     const uint8_t w = on_wave[it.query];
@@ -1468,8 +1631,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
             "[mgx] %s group: %u queries; fast path %zu items (lds %u B, ring %u), wave kernel %u items (lds %u B), "
             "block kernel %u items (lds %u B)\n",
             score_mode ? "score" : "bitmap", n,
-            items_fast[0].size() + items_fast[1].size() + items_fast[2].size() + items_fast[3].size(), g.fplan.bytes,
-            g.fplan.ring, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()), g.wplan.bytes, g.n_items,
+            items_fast[0].size() + items_fast[1].size() + items_fast[2].size() + items_fast[3].size() + items_fast[4].size(),
+            g.fplan.bytes, g.fplan.ring, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()), g.wplan.bytes, g.n_items,
             g.plan.bytes);
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
@@ -1539,6 +1702,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     d.wave_tables = g.d_tables.as<uint64_t>();
   }
   d.fast_queries = g.d_fast_queries.as<DevFastQuery>();
+  d.dev_index = b->idx->d_dev_index.as<DevIndex>();
   for (int t = 0; t < kFastMaxScore; ++t) {
     g.dev_fast[t] = d;
     g.dev_fast[t].items = g.d_items_fast[t].as<DevItem>();
@@ -1786,7 +1950,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
     MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side));
     for (int t = 0; t < kFastMaxScore; ++t)
-      MGX_LAUNCH(LaunchAndScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
+      MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
     if (side != s) {
       MGX_HIP(hipEventRecord(b->res->join_ev, side));

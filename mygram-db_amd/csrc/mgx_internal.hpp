@@ -138,16 +138,13 @@ struct DevIndex {
 };
 
 // ---- fast path of SORT _score batches: flat programs over bitmap-form operands, <= kFastMaxScore dense scored terms --
-// The query arrives at the kernel fully resolved: every operand is a device address + tile stride (no operand-kind
-// dispatch, no leaf table), every scored term is the address of its tf-nibble row and of its BM25 contribution table.
-// The tables are per (gram, idf, k1, b, avgdl) — table constants, not query data — and live in a pool owned by the
-// index (built on first use, bm25_scorer.cpp:80-84 operation by operation on the host), so a query carries addresses
-// instead of the values.
+// The query arrives at the kernel fully resolved (bitmap_score_kernel): every operand is a device address + tile stride
+// (no operand-kind dispatch, no leaf table), every scored term is the address of its tf-nibble row, its idf and where
+// its block-max bytes are (top-k pruning).
 constexpr int kFastMaxOps = 8;
-constexpr int kFastMaxScore = 4;
-constexpr uint32_t kFastLdsTf = 6;    // table rows tf 0..6 are staged in LDS (row 0 = zeros: a term the doc lacks)
-constexpr uint32_t kFastPoolTf = 14;  // rows tf 0..14 exist in the pool (a nibble of 15 = "15 or more": exact lookup)
-constexpr int kFastBlock = 512;       // 8 autonomous waves per workgroup share the query's tables
+constexpr int kFastMaxScore = 5;
+constexpr uint32_t kFastPoolTf = 14;  // contribution-table pool of the wave kernel: rows tf 0..14
+constexpr int kFastBlock = 512;       // 8 autonomous waves per workgroup on one query
 constexpr int kFastWaves = kFastBlock / 64;
 
 enum FastOpKind : uint32_t { kFastOr = 0, kFastAnd = 1, kFastAndNot = 2 };  // (LOAD = OR into the empty accumulator)
@@ -158,29 +155,36 @@ struct FastOp {
 };
 struct FastScore {
   uint64_t nib;          // address of the term's tf-nibble row (DevIndex::tfnib + row * nib_row_stride)
-  uint64_t table;        // address of its contribution table: (kFastPoolTf + 1) rows x tdl doubles
-  double idf;            // direct evaluation (tf >= 15 or a doc longer than the table)
-  uint32_t gram, skip_row;
+  double idf;
+  uint32_t gram, skip_row;  // exact tf lookup of a saturated nibble
+  // block-max bytes of the term (pruning): mode 0 none (its bound is inside DevFastQuery::ub_const), 1 one byte per
+  // 64-doc word at blockmax + tile * bm_tile_stride + bm_off, 2 one byte per 16-doc quarter at blockmax_fine + ...
+  uint32_t bm_mode, bm_off;
+  float bm_weight;       // idf * (value of one block-max unit), rounded up
+  uint32_t pad;
 };
 struct DevFastQuery {
   uint32_t n_ops, n_score, needed, cap;
-  uint32_t descending, pad0, pad1, pad2;
+  uint32_t descending, pad0;
+  float ub_const;        // pruning: the part of the score bound that does not depend on the block (terms without bytes)
+  uint32_t pad1;
   double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;
-  double pad3;
+  const uint8_t* blockmax;       // null: score every match (SORT _score ASC, or pruning unavailable)
+  const uint8_t* blockmax_fine;
+  uint32_t bm_tile_stride, bmf_tile_stride;  // bytes per tile of the two arrays
   FastOp ops[kFastMaxOps];
   FastScore score[kFastMaxScore];
 };
-static_assert(sizeof(DevFastQuery) % 16 == 0, "DevFastQuery is read with 16-byte scalar loads");
+static_assert(sizeof(DevFastQuery) % 8 == 0, "DevFastQuery is read with scalar loads");
 
 struct FastPlan {
-  uint32_t tdl;        // doc-length extent of the tables (even)
   uint32_t ring;       // match-buffer entries per wave
-  uint32_t max_score, max_cap;
-  uint32_t dl_escape;  // dl8 can hold the escape value 255 (max_doc_len >= 255)
-  uint32_t bytes;
+  uint32_t max_cap;
+  uint32_t bytes, pad;
+  const double* ktab;  // [256] K[dl] = k1 * (1 - b + b * dl / avgdl) of the batch's (k1, b, avgdl)
 };
-FastPlan PlanFast(uint32_t max_score, uint32_t max_cap, uint32_t max_doc_len);
-uint32_t FastTableDl(uint32_t max_doc_len);  // tdl of an index
+FastPlan PlanFast(uint32_t max_cap, const double* ktab);
+uint32_t FastTableDl(uint32_t max_doc_len);  // tdl of an index's contribution-table pool
 
 // One workgroup's share of a query: tiles [tile_begin, tile_begin + n_tiles). The host cuts every query into items
 // of about equal estimated cost (expensive queries — many matches per tile — get more, shorter items), so no
@@ -212,6 +216,7 @@ struct DevBatch {
   uint32_t cand_stride;
   const uint64_t* wave_tables;  // [n_queries][kWaveScoreSlots] addresses of the scored terms' pool tables (wave kernel)
   const DevFastQuery* fast_queries;  // [n_queries] resolved descriptors of the fast-path queries (others: unused rows)
+  const struct DevIndex* dev_index;  // the index's descriptor in device memory (out-of-line cold paths take a pointer)
   uint32_t debug_skip;   // -DMGX_ABLATION builds only (MGX_DEBUG_SKIP: 1 = no scoring, 2 = no enumeration + scoring); 0 otherwise
   // bitmap mode
   uint64_t* rbits;       // [n_bitmap_queries][n_tiles][256]

@@ -40,6 +40,9 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // A value every lane of the wave holds identically, moved to scalar registers: loads through LDS or vector memory
 // leave wave-uniform values in VGPRs, and the scoring kernel has none to spare.
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float wave_uniform(float v) {
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+}
 __device__ __forceinline__ uint64_t wave_uniform(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
   const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
@@ -200,6 +203,61 @@ __global__ void build_tfnib_kernel(const uint32_t* __restrict__ docids, const ui
     const uint32_t v = tf[p] < 15 ? tf[p] : 15u;
     atomicOr(&out[slot >> 3], v << ((slot & 7u) * 4u));
   }
+}
+
+// Block-max of the BM25 term factor, for top-k pruning (the block-max idea of WAND-style retrieval on this layout):
+// for every dense gram row and every 64-doc word of its bitmap, an upper bound of g(tf, dl) = tf * (k1 + 1) / (tf + K[dl])
+// over the docs of the word that hold the gram, in units of `step` (one byte; 0 = no doc of the word holds the gram).
+// A doc's score is sum_i idf_i * g_i, so sum_i idf_i * step * q_i bounds every score of the word from above; the scoring
+// kernels skip the words whose bound is below the query's current k-th best (they still count their matches).
+// q = floor(g / step) + 2: at least one whole step above g, so no rounding in g / step or in the kernels' sums can
+// bring the bound below a score. A saturated nibble (tf >= 15) takes the supremum k1 + 1, a saturated doc length
+// K[255] (the true length is longer, its factor smaller). Layout: [tile][row][256 words], like the gram bitmaps.
+// kFine: the rows listed in `rows` (the densest grams: every 64-doc word of theirs holds some doc with a near-maximal
+// factor, so the per-word bound prunes nothing) get one byte per 16-doc QUARTER of a word, four per word, as a u32.
+template <bool kFine>
+__global__ __launch_bounds__(256) void build_blockmax_kernel(const uint8_t* __restrict__ nib, uint64_t nib_row_stride,
+                                                             const uint8_t* __restrict__ dl8,
+                                                             const double* __restrict__ ktab, double k1_plus_1,
+                                                             double inv_step, const uint32_t* __restrict__ rows,
+                                                             uint32_t n_rows, uint64_t n_out, void* __restrict__ out) {
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n_out) return;
+  const uint32_t word = static_cast<uint32_t>(idx & 255u);
+  const uint64_t tr = idx >> 8;
+  const uint32_t r = static_cast<uint32_t>(tr % n_rows);
+  const uint32_t row = rows ? rows[r] : r;          // the bitmap / nibble row this output row describes
+  const uint64_t gw = (tr / n_rows) * 256u + word;  // the word's index in the doc-slot space
+  const uint4* np = reinterpret_cast<const uint4*>(nib + static_cast<uint64_t>(row) * nib_row_stride + gw * 32u);
+  const uint4* dp = reinterpret_cast<const uint4*>(dl8 + gw * 64u);
+  const uint4 n4[2] = {np[0], np[1]};
+  const uint4 d4[4] = {dp[0], dp[1], dp[2], dp[3]};
+  const uint32_t nw[8] = {n4[0].x, n4[0].y, n4[0].z, n4[0].w, n4[1].x, n4[1].y, n4[1].z, n4[1].w};
+  const uint32_t dw[16] = {d4[0].x, d4[0].y, d4[0].z, d4[0].w, d4[1].x, d4[1].y, d4[1].z, d4[1].w,
+                           d4[2].x, d4[2].y, d4[2].z, d4[2].w, d4[3].x, d4[3].y, d4[3].z, d4[3].w};
+  double best[4] = {0.0, 0.0, 0.0, 0.0};  // per 16-doc quarter of the word
+#pragma unroll
+  for (int s = 0; s < 64; ++s) {
+    const uint32_t tf = (nw[s >> 3] >> ((s & 7) * 4)) & 15u;
+    if (tf == 0u) continue;
+    const uint32_t d = (dw[s >> 2] >> ((s & 3) * 8)) & 255u;
+    const double tfd = static_cast<double>(tf);
+    const double gv = tf == 15u ? k1_plus_1 : tfd * k1_plus_1 / (tfd + ktab[d]);
+    best[s >> 4] = gv > best[s >> 4] ? gv : best[s >> 4];
+  }
+  uint32_t packed = 0, whole = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t qv = 0;
+    if (best[j] > 0.0) {
+      const double steps = floor(best[j] * inv_step);
+      qv = steps >= 253.0 ? 255u : static_cast<uint32_t>(steps) + 2u;
+    }
+    packed |= qv << (8 * j);
+    whole = qv > whole ? qv : whole;
+  }
+  if (kFine) static_cast<uint32_t*>(out)[idx] = packed;
+  else static_cast<uint8_t*>(out)[idx] = static_cast<uint8_t>(whole);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1395,34 +1453,44 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_lists_kernel(DevInde
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// and_score_kernel: the fast path of SORT _score batches (flat AND/OR/ANDNOT programs over bitmap-form operands)
+// bitmap_score_kernel: the fast path of SORT _score batches (flat AND/OR/ANDNOT programs over bitmap-form operands)
 // ---------------------------------------------------------------------------------------------------------------
 //
-// Same results as wave_score_kernel, a third of its instructions. What changed, and why (profiles/r01_final_pmc_sq.json:
-// the old kernel issued 1,567 VALU instructions per tile visit at 73 % VALU busy — issue-bound, not bandwidth-bound):
-//   * no interpreter and no operand-kind dispatch: the query arrives resolved (DevFastQuery): an operand is an
-//     address + tile stride in scalar registers, the loads of up to four operands are issued back to back;
-//   * byte gathers go through buffer descriptors (one SRD per nibble row and one for dl8 in SGPRs; the per-lane part
-//     is a 32-bit offset), so a gather costs one shift instead of a 64-bit address computation;
-//   * matches are appended to a per-wave buffer that carries over from tile to tile and are scored only in FULL groups
-//     of 128 (two per lane): a sparse query (16 matches per tile) scores 64-lane-wide instead of at 25 % utilisation;
-//   * BM25 contribution tables are per gram and come from the index's pool (built once per (gram, idf, k1, b, avgdl)):
-//     rows tf 0..6 are staged in LDS (row 0 = zeros, so a term the doc lacks needs no branch), tf 7..14 are read
-//     from the pool (L2-resident) by the few lanes that need them, tf >= 15 / over-long docs are evaluated directly.
+// Same results as wave_score_kernel. What the round-2 profile of that kernel says (profiles/r02_headline_*): it moves
+// 12.8 GB of L2 misses per 1024-query launch at 5.8 TB/s — 84 % of the streaming bandwidth this box reaches — and four
+// fifths of that is the per-match byte gathers (three tf nibbles + one doc length), not the operand bitmaps (the
+// intersection alone, wave_count_kernel, runs AT the streaming bandwidth). It is bound by bytes, so this kernel
+// removes bytes — by not scoring matches that cannot reach the page:
+//   * block-max pruning. The index keeps, per dense gram and per 64-doc word (the densest grams: per 16-doc quarter),
+//     one byte bounding the gram's BM25 term factor over the docs of the block (build_blockmax_kernel). A lane reads
+//     the bytes of its 256 doc slots with its operands, sums idf-weighted bounds per quarter and drops the quarters
+//     whose bound is below the query's current k-th best score (its own list's, or any wave's of the query through the
+//     shared bound). The matches are still counted (total_results is exact); only survivors are enumerated, gathered
+//     and scored. On the benchmark batch about a fifth of the matches survive.
+//   * no per-query BM25 tables: a contribution is idf * (tf * (k1 + 1)) / (tf + K[dl]) with K[dl] = k1 * (1 - b + b *
+//     dl / avgdl) — a 2 KiB table of the BATCH (k1, b, avgdl are table constants), built on the host operation by
+//     operation like bm25_scorer.cpp:80-84 — and one correctly rounded fp64 division per (match, term) on the device:
+//     no staging of up to 36 KB per workgroup, every nibble value 1..14 covered (the tables stopped at tf 6).
+//   * the resolved-query form: an operand is an address + tile stride in scalar registers (no interpreter, no operand-
+//     kind dispatch), byte gathers go through buffer descriptors, survivors wait in a per-wave buffer from tile to tile
+//     and are scored in full rounds (a round's gathers cost one memory round trip however few lanes carry a match).
 // One workgroup = 8 autonomous waves on one query; a wave owns whole 16384-doc tiles (a lane owns 256 doc slots =
-// eight 32-bit words). No workgroup barrier inside the tile loop.
+// eight 32-bit words = sixteen 16-doc quarters). No workgroup barrier inside the tile loop.
 
-constexpr uint32_t kFastRare = 128;  // per wave: < 64 left over + at most 64 set aside by one scoring step
+#ifndef MGX_FPL
+#define MGX_FPL 4
+#endif
+constexpr int kFastPerLane = MGX_FPL;               // matches per lane scored in one round: their gathers fly together
+constexpr uint32_t kFastRound = 64 * kFastPerLane;  // matches per round
 
 struct FastOffsets {
-  uint32_t table, ring, rare, tk_keys, tk_docs, misc, total;
+  uint32_t ktab, ring, tk_keys, tk_docs, misc, total;
 };
 __host__ __device__ inline FastOffsets carve_fast(const FastPlan& p) {
   FastOffsets o;
   uint32_t at = 0;
-  o.table = at;    at += p.max_score * (kFastLdsTf + 1) * p.tdl * 8;
+  o.ktab = at;     at += 256 * 8;
   o.ring = at;     at += kFastWaves * p.ring * 4;
-  o.rare = at;     at += kFastWaves * kFastRare * 4;
   o.tk_keys = at;  at += kFastWaves * 2 * p.max_cap * 8;
   o.tk_docs = at;  at += kFastWaves * 2 * p.max_cap * 4;
   o.misc = at;     at += 64;
@@ -1433,127 +1501,58 @@ uint32_t FastTableDl(uint32_t max_doc_len) {
   const uint32_t t = max_doc_len + 1 < kTableDlMax ? max_doc_len + 1 : kTableDlMax;
   return (t + 1u) & ~1u;  // even: table rows are copied 16 bytes at a time
 }
-FastPlan PlanFast(uint32_t max_score, uint32_t max_cap, uint32_t max_doc_len) {
-  FastPlan p{FastTableDl(max_doc_len), 512, max_score ? max_score : 1, max_cap, max_doc_len >= 255 ? 1u : 0u, 0};
+FastPlan PlanFast(uint32_t max_cap, const double* ktab) {
+  FastPlan p{};
+  p.ring = kFastRound + 128;
+  p.max_cap = max_cap;
+  p.ktab = ktab;
   p.bytes = carve_fast(p).total;
   return p;
-}
-
-// merge of the waves' kept lists into the item's candidate list (best first) — shared epilogue of the scoring kernels
-template <int kWaves>
-__device__ __forceinline__ void waves_to_item_list(const DevBatch& bt, const WaveTopK& tk, uint32_t needed, uint32_t cap,
-                                                   const uint64_t* all_keys, const uint32_t* all_docs, uint32_t* misc,
-                                                   uint32_t list, unsigned long long* gbound_ptr) {
-  const uint32_t tid = threadIdx.x;
-  if (lane_id() == 0) misc[wave_id()] = tk.have;
-  __syncthreads();
-  uint32_t have[kWaves];
-  uint32_t total = 0;
-  for (int w = 0; w < kWaves; ++w) {
-    have[w] = min(misc[w], needed);
-    total += have[w];
-  }
-  const uint64_t obase = static_cast<uint64_t>(list) * bt.cand_stride;
-  for (uint32_t e = tid; e < kWaves * cap; e += kWaves * 64) {
-    const uint32_t w = e / cap, i = e % cap;
-    if (i >= have[w]) continue;
-    const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
-    const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
-    uint32_t rank = i;  // entries of the other waves' (sorted) lists that beat this one, plus its own position
-    for (uint32_t w2 = 0; w2 < kWaves; ++w2) {
-      if (w2 == w) continue;
-      const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
-      const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
-      uint32_t lo = 0, hi = have[w2];
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
-      }
-      rank += lo;
-    }
-    if (rank < needed) {
-      bt.cand_keys[obase + rank] = k;
-      bt.cand_docs[obase + rank] = d;
-      // the needed-th best of the whole item (8 waves' matches merged) is a far tighter query-wide bound than any one
-      // wave's: later items of the query start from it
-      if (rank == needed - 1 && gbound_ptr && !MGX_ABLATE(bt, 8u))
-        atomicMax(gbound_ptr, static_cast<unsigned long long>(k));
-    }
-  }
-  if (tid == 0) bt.cand_n[list] = min(total, needed);
 }
 
 // Global-address-space views of resolved addresses: the compiler cannot see that an integer turned pointer is global
 // memory and would emit flat loads (which also tick the LDS counter).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef const u32x4 __attribute__((address_space(1)))* gptr_u4;
-typedef const f64x2 __attribute__((address_space(1)))* gptr_d2;
+typedef const uint32_t __attribute__((address_space(1)))* gptr_u1;
 
-constexpr int kFastPerLane = 4;                     // matches per lane scored in one round: their gathers fly together
-constexpr uint32_t kFastGroup = 64 * kFastPerLane;  // matches per round
-constexpr int kFastPrefetch = 3;                    // operands of the NEXT tile requested before this tile is scored
+// The cold corner of scoring, out of line so that its needs (posting arrays, skip rows, the overflow table) stay out of
+// the hot loop's registers: the exact tf of a saturated nibble (tf >= 15). `ix` is the index's descriptor in device
+// memory (DevBatch::dev_index).
+__device__ __noinline__ uint32_t fast_exact_tf(const DevIndex* ix, uint32_t gram, uint32_t row, uint32_t slot) {
+  return exact_tf(*ix, gram, row, slot);
+}
 
 template <int T>
-__device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan,
-                                               const DevFastQuery* __restrict__ fq, const DevItem it) {
+__device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan,
+                                                  const DevFastQuery* __restrict__ fq, const DevItem it) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FastOffsets fo = carve_fast(plan);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = wave_uniform(tid >> 6);
-  double* const table = reinterpret_cast<double*>(smem + fo.table);
+  double* const ktab = reinterpret_cast<double*>(smem + fo.ktab);
   uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + fo.ring) + wave * plan.ring;
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + fo.misc);
-  const uint32_t tdl = plan.tdl;
-  const uint32_t lds_rows = (kFastLdsTf + 1) * tdl;  // doubles per term in LDS
   const uint32_t n_ops = fq->n_ops;
-  const uint32_t needed = fq->needed, cap = fq->cap;
   const bool desc = fq->descending != 0;
   const uint32_t tile_begin = it.tile_begin;
   const uint32_t tile_end = min(tile_begin + it.n_tiles, ix.n_tiles);
-  const uint64_t filter_base = reinterpret_cast<uint64_t>(ix.filter_bitmaps);
 
-  // This lane's 32 bytes of operand `o` for `tile` (two 16-byte loads, issued and not waited for).
-  auto load_operand = [&](uint32_t o, uint32_t tile, uint4 (&w)[2]) {
-    const FastOp op = fq->ops[o];
-    const uint64_t base = op.base + ((op.code & 16u) ? filter_base : 0ull) + static_cast<uint64_t>(tile) * op.tile_stride;
-    const gptr_u4 p = reinterpret_cast<gptr_u4>(base) + lane * 2;
-    const u32x4 v0 = p[0], v1 = p[1];
-    w[0] = make_uint4(v0.x, v0.y, v0.z, v0.w);
-    w[1] = make_uint4(v1.x, v1.y, v1.z, v1.w);
-  };
-  // The memory system answers in microseconds under this kernel's load and a wave has nothing else to do meanwhile, so
-  // what counts is how few DEPENDENT round trips a tile costs: the first tile's operands are requested before anything
-  // else (they fly while the tables are staged), every later tile's while its predecessor is enumerated and scored.
-  uint4 wn[kFastPrefetch][2];
-  {
-    const uint32_t t0 = tile_begin + wave;
-#pragma unroll
-    for (int u = 0; u < kFastPrefetch; ++u) {
-      wn[u][0] = wn[u][1] = make_uint4(0, 0, 0, 0);
-      if (static_cast<uint32_t>(u) < n_ops && t0 < tile_end) load_operand(u, t0, wn[u]);
-    }
-  }
+  // the batch's K[dl] = k1 * (1 - b + b * dl / avgdl), dl 0..254 (entry 255 unused: the escape value)
+  if (tid < 256) ktab[tid] = plan.ktab[tid];
 
-  // ---- stage the terms' tables (rows tf 0..6) ------------------------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const gptr_d2 src = reinterpret_cast<gptr_d2>(fq->score[i].table);
-    f64x2* dst = reinterpret_cast<f64x2*>(table + i * lds_rows);
-    for (uint32_t e = tid; e < lds_rows / 2; e += kFastBlock) dst[e] = src[e];
-  }
   WaveTopK tk;
-  tk.cap = cap;
-  tk.needed = needed;
-  tk.lds_sort = MGX_ABLATE(bt, 16u);
-  tk.keys = reinterpret_cast<uint64_t*>(smem + fo.tk_keys) + static_cast<size_t>(wave) * 2 * cap;
-  tk.docs = reinterpret_cast<uint32_t*>(smem + fo.tk_docs) + static_cast<size_t>(wave) * 2 * cap;
+  tk.cap = fq->cap;
+  tk.needed = fq->needed;
+  tk.lds_sort = true;
+  tk.keys = reinterpret_cast<uint64_t*>(smem + fo.tk_keys) + static_cast<size_t>(wave) * 2 * fq->cap;
+  tk.docs = reinterpret_cast<uint32_t*>(smem + fo.tk_docs) + static_cast<size_t>(wave) * 2 * fq->cap;
   tk.have = 0;
   tk.pend = 0;
   tk.bound_key = 0;
   tk.bound_doc = 0;
   tk.gbound_ptr = bt.bounds ? bt.bounds + it.query : nullptr;
   tk.gbound = 0;
-  for (uint32_t i = lane; i < 2 * cap; i += 64) {
+  for (uint32_t i = lane; i < 2 * tk.cap; i += 64) {
     tk.keys[i] = 0;
     tk.docs[i] = 0;
   }
@@ -1561,55 +1560,24 @@ __device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatc
 
   // buffer descriptors of the byte columns (wave-uniform: built from kernel arguments and scalar loads only)
   __amdgpu_buffer_rsrc_t nib_rsrc[T];
+  double idf[T];
 #pragma unroll
-  for (int i = 0; i < T; ++i)
+  for (int i = 0; i < T; ++i) {
     nib_rsrc[i] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fq->score[i].nib), 0,
                                                     static_cast<int>((ix.n_docs + 1u) >> 1), 0x00020000);
+    idf[i] = fq->score[i].idf;
+  }
   const __amdgpu_buffer_rsrc_t dl_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint8_t*>(ix.dl8), 0, static_cast<int>(ix.n_docs), 0x00020000);
+  const double k1_plus_1 = fq->k1_plus_1;
+  const bool prune = fq->blockmax != 0;  // wave-uniform
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
   uint32_t pend = 0;  // matches waiting in the ring (wave-uniform)
 
-  // Matches the LDS tables do not cover (a term with tf > 6, a doc-length escape) are set aside in a small per-wave
-  // buffer and scored 64 at a time by score_rare: the hot loop below then holds no division, no binary search and no
-  // pool access, and the rare work itself runs at full lane utilisation.
-  uint32_t* const rbuf = reinterpret_cast<uint32_t*>(smem + fo.rare) + wave * kFastRare;
-  uint32_t n_rare = 0;  // wave-uniform
-
-  // scores rbuf[0 .. n), n <= 64: every term evaluated on its own (pool table, exact tf lookup, direct formula)
-  auto score_rare = [&](uint32_t n) {
-    const bool valid = lane < n;
-    const uint32_t slot = valid ? rbuf[lane] : 0u;
-    uint32_t d = __builtin_amdgcn_raw_buffer_load_b8(dl_rsrc, slot, 0, 0);
-    if (plan.dl_escape && d == 255u) d = ix.doc_len[slot];
-    double score = 0.0;
-#pragma nounroll
-    for (int i = 0; i < T; ++i) {
-      const FastScore st = fq->score[i];
-      uint32_t t = (reinterpret_cast<const uint8_t*>(st.nib)[slot >> 1] >> ((slot & 1u) << 2)) & 15u;
-      if (t == 15u) t = exact_tf(ix, st.gram, st.skip_row, slot);
-      double c = 0.0;
-      if (t != 0u) {
-        if (t <= kFastPoolTf && d < tdl) {
-          c = reinterpret_cast<const double*>(st.table)[t * tdl + d];
-        } else {  // bm25_scorer.cpp:80-84, same operation order as the tables
-          const double dl = static_cast<double>(d), tfd = static_cast<double>(t);
-          const double length_norm = fq->one_minus_b + fq->b * dl / fq->avgdl_clamped;
-          const double numerator = tfd * fq->k1_plus_1;
-          const double denominator = tfd + fq->k1 * length_norm;
-          c = st.idf * numerator / denominator;
-        }
-      }
-      score += c;  // (0.0 + c0 is c0; a term the doc lacks adds +0.0 where bm25_scorer.cpp:86 skips it)
-    }
-    const uint32_t doc = ix.first_doc_id + slot;
-    wave_topk_offer<true>(tk, valid, score_key(score, desc), desc ? doc : ~doc);
-  };
-
-  // scores the pending matches ring[g0 .. g0+n), n <= kFastGroup: one per lane and step, kFastPerLane steps whose
-  // T + 1 byte gathers are all requested before the first is looked at (one memory round trip per round)
-  auto score_group = [&](uint32_t g0, uint32_t n) {
+  // scores ring[g0 .. g0+n), n <= kFastRound: one match per lane and step, kFastPerLane steps whose T + 1 byte gathers
+  // are all requested before the first is looked at
+  auto score_round = [&](uint32_t g0, uint32_t n) {
     uint32_t slot[kFastPerLane], dli[kFastPerLane], nb[kFastPerLane][T];
 #pragma unroll
     for (int m = 0; m < kFastPerLane; ++m) {
@@ -1637,46 +1605,48 @@ __device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatc
           for (int i = 0; i < T; ++i) nbm[i] = nb[mm][i];
         }
       }
-      bool valid = static_cast<uint32_t>(m) * 64u + lane < n;
+      const bool valid = static_cast<uint32_t>(m) * 64u + lane < n;
+      double kd = ktab[dl];
       const uint32_t sh = (sl & 1u) << 2;
-      uint32_t mx = 0;
+      uint32_t tf[T], mx = 0;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        tf[i] = (nbm[i] >> sh) & 15u;
+        mx = max(mx, tf[i]);
+      }
+      if (__ballot(valid && (mx == 15u || dl == 255u)) != 0) {  // wave-uniform, rare: saturated nibble / doc length
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+          if (valid && tf[i] == 15u) tf[i] = fast_exact_tf(bt.dev_index, fq->score[i].gram, fq->score[i].skip_row, sl);
+        if (valid && dl == 255u) {
+          const double dld = static_cast<double>(ix.doc_len[sl]);
+          kd = fq->k1 * (fq->one_minus_b + fq->b * dld / fq->avgdl_clamped);  // bm25_scorer.cpp:80-84
+        }
+      }
       double score = 0.0;
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        const uint32_t tf = (nbm[i] >> sh) & 15u;
-        mx = max(mx, tf);
-        // a term the doc lacks reads row 0 (+0.0); tf > 6 reads just past the staged rows (allocated LDS, any value):
-        // such a match goes to rbuf and its score here is never offered
-        const double c = table[i * lds_rows + min(tf, kFastLdsTf + 1u) * tdl + dl];
+        const double tfd = static_cast<double>(tf[i]);
+        // bm25_scorer.cpp:80-84: idf * numerator / denominator, numerator = tf * (k1 + 1), denominator = tf + k1 * norm;
+        // a term the doc lacks adds +0.0 where bm25_scorer.cpp:86 skips it
+        const double c = tf[i] != 0u ? idf[i] * (tfd * k1_plus_1) / (tfd + kd) : 0.0;
         score = i == 0 ? c : score + c;
       }
-      const bool rare = valid && (mx > kFastLdsTf || (plan.dl_escape && dl == 255u));
-      const uint64_t rm = __ballot(rare);
-      if (rm != 0) {  // wave-uniform
-        if (rare) rbuf[n_rare + __popcll(rm & ((1ull << lane) - 1ull))] = sl;
-        n_rare += __popcll(rm);
-        valid = valid && !rare;
-        wave_lds_sync();
-        if (n_rare >= 64u) {  // a full group of set-aside matches: score it, move the (< 64) rest to the front
-          score_rare(64u);
-          const uint32_t left = n_rare - 64u;
-          const uint32_t v0 = lane < left ? rbuf[64u + lane] : 0u;
-          wave_lds_sync();
-          if (lane < left) rbuf[lane] = v0;
-          n_rare = left;
-          wave_lds_sync();
-        }
-      }
-      if (MGX_ABLATE(bt, 1u)) {  // (ablation: score, do not offer)
-        asm volatile("" ::"v"(score));
-        continue;
-      }
       const uint32_t doc = ix.first_doc_id + sl;
-      wave_topk_offer<true>(tk, valid, score_key(score, desc), desc ? doc : ~doc);
+      wave_topk_offer(tk, valid, score_key(score, desc), desc ? doc : ~doc);
     }
   };
 
-  // The tile loop runs one extra, tile-less pass at the end that only flushes the wave's last partial group, so the
+  // This lane's 16 bytes of half `h` of operand `o` for `tile` (issued and not waited for)
+  auto load_half = [&](uint32_t o, uint32_t tile, uint32_t h) {
+    const FastOp op = fq->ops[o];
+    const uint64_t base = op.base + ((op.code & 16u) ? reinterpret_cast<uint64_t>(ix.filter_bitmaps) : 0ull) +
+                          static_cast<uint64_t>(tile) * op.tile_stride;
+    const gptr_u4 p = reinterpret_cast<gptr_u4>(base) + lane * 2 + h;
+    return p[0];
+  };
+
+  // The tile loop runs one extra, tile-less pass at the end that only scores the wave's last partial round, so the
   // scoring code exists once.
   for (uint32_t tile = tile_begin + wave;; tile += kFastWaves) {
     const bool flush = tile >= tile_end;  // wave-uniform
@@ -1684,56 +1654,110 @@ __device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatc
     uint32_t mine = 0;
     if (!flush) {
       wave_topk_refresh_gbound(tk);
-      // ---- A. the operands of this lane's 256 doc slots, combined in registers ---------------------------------------
-      auto combine = [&](uint32_t o, const uint4 (&w)[2]) {
-        const uint32_t code = fq->ops[o].code;
-        const uint32_t x[8] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w};
-        const uint32_t kind = code & 15u;
-        if (kind == kFastOr) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] |= x[j];
-        } else if (kind == kFastAnd) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] &= x[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) a[j] &= ~x[j];
-        }
-        const uint32_t cmask = code >> 8;
-        if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
-          uint32_t pc = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pc += __popc(a[j]);
-          if (cmask & 1u) cnt0 += pc;
-          if (cmask & 2u) cnt1 += pc;
-          if (cmask & 4u) cnt2 += pc;
-          if (cmask & 8u) cnt3 += pc;
-        }
-      };
-      // operands beyond the prefetched ones are requested now (their round trip is exposed: rare query shapes)
-#pragma unroll
-      for (int u = 0; u < kFastPrefetch; ++u)
-        if (static_cast<uint32_t>(u) < n_ops) combine(u, wn[u]);
-      for (uint32_t o = kFastPrefetch; o < n_ops; o += 2) {
-        uint4 w0[2], w1[2];
-        load_operand(o, tile, w0);
-        if (o + 1 < n_ops) load_operand(o + 1, tile, w1);
-        combine(o, w0);
-        if (o + 1 < n_ops) combine(o + 1, w1);
+      // ---- pruning: one bit per 16-doc quarter of this lane's 256 slots — "can still enter the page". The block-max
+      // bytes are requested first, the operands right behind them, and the bits are made while the operands fly.
+      uint32_t qmask = 0xFFFFu;
+      uint64_t bound = 0;
+      if (prune) {
+        // the k-th best so far — this wave's own list or any wave's of the query: a quarter whose bound is below it
+        // holds no doc that can enter the page (equal scores are kept: the docid decides)
+        bound = tk.gbound;
+        if (tk.have >= tk.needed && tk.bound_key > bound) bound = tk.bound_key;
       }
-      // the next tile's operands: in flight while this tile is enumerated and scored
-      if (tile + kFastWaves < tile_end) {
+      uint32_t bmw[T][4];  // per quarter: one u32 per 64-doc word; per word: [0] only (expanded when looked at)
 #pragma unroll
-        for (int u = 0; u < kFastPrefetch; ++u)
-          if (static_cast<uint32_t>(u) < n_ops) load_operand(u, tile + kFastWaves, wn[u]);
+      for (int i = 0; i < T; ++i) {
+        bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
+        if (bound == 0) continue;  // wave-uniform: nothing to prune against yet
+        const uint32_t mode = fq->score[i].bm_mode;
+        if (mode == 2u) {
+          const u32x4 v = reinterpret_cast<gptr_u4>(reinterpret_cast<uint64_t>(fq->blockmax_fine) +
+                                                    static_cast<uint64_t>(tile) * fq->bmf_tile_stride +
+                                                    fq->score[i].bm_off)[lane];
+          bmw[i][0] = v.x;
+          bmw[i][1] = v.y;
+          bmw[i][2] = v.z;
+          bmw[i][3] = v.w;
+        } else if (mode == 1u) {
+          bmw[i][0] = reinterpret_cast<gptr_u1>(reinterpret_cast<uint64_t>(fq->blockmax) +
+                                                static_cast<uint64_t>(tile) * fq->bm_tile_stride + fq->score[i].bm_off)[lane];
+        }
+      }
+      // ---- A. the operands of this lane's 256 doc slots, combined in registers; in two halves of 128 slots, so that
+      //         the loads in flight hold 4 registers per operand, not 8
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        for (uint32_t o = 0; o < n_ops; o += 3) {  // three operands' loads in flight together
+          const u32x4 w0 = load_half(o, tile, h);
+          u32x4 w1 = w0, w2 = w0;
+          if (o + 1 < n_ops) w1 = load_half(o + 1, tile, h);
+          if (o + 2 < n_ops) w2 = load_half(o + 2, tile, h);
+          if (h == 0 && o == 0 && bound != 0) {  // (the block-max loads are older than the operands': no extra wait)
+            const float theta = static_cast<float>(key_score(bound, true)) * (1.0f - 0x1p-20f);
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+              if (fq->score[i].bm_mode == 1u) {  // wave-uniform: a word's byte stands for its four quarters
+                const uint32_t c = bmw[i][0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bmw[i][k] = ((c >> (8 * k)) & 255u) * 0x01010101u;
+              }
+            }
+            uint32_t mk = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                // fp32 with every rounding pushed outwards (weights up by 2^-20 on the host, the sum up by 2^-18, the
+                // threshold down by 2^-20); the exact bound itself sits a whole quantisation step above any score
+                float ub = fq->ub_const;
+#pragma unroll
+                for (int i = 0; i < T; ++i)
+                  ub += fq->score[i].bm_weight * static_cast<float>((bmw[i][k] >> (8 * j)) & 255u);
+                if (!(ub * (1.0f + 0x1p-18f) < theta)) mk |= 1u << (4 * k + j);
+              }
+            }
+            qmask = mk;
+          }
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            if (o + u >= n_ops) break;  // wave-uniform
+            const u32x4 w = u == 0 ? w0 : u == 1 ? w1 : w2;
+            const uint32_t code = fq->ops[o + u].code;
+            const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+            const uint32_t kind = code & 15u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              uint32_t& acc = a[h * 4 + j];
+              acc = kind == kFastOr ? (acc | x[j]) : kind == kFastAnd ? (acc & x[j]) : (acc & ~x[j]);
+            }
+            const uint32_t cmask = code >> 8;
+            if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
+              uint32_t pc = 0;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) pc += __popc(a[h * 4 + j]);
+              if (cmask & 1u) cnt0 += pc;
+              if (cmask & 2u) cnt1 += pc;
+              if (cmask & 4u) cnt2 += pc;
+              if (cmask & 8u) cnt3 += pc;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cnt_res += __popc(a[j]);  // every match counts ...
+      if (qmask != 0xFFFFu) {                                // ... only the quarters that can reach the page are scored
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t m2 = qmask >> (2 * j);
+          a[j] &= ((m2 & 1u) ? 0x0000FFFFu : 0u) | ((m2 & 2u) ? 0xFFFF0000u : 0u);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) mine += __popc(a[j]);
-      cnt_res += mine;
-      if (MGX_ABLATE(bt, 2u)) mine = 0;  // operands + counts only
+      if (MGX_ABLATE(bt, 2u)) mine = 0;  // (ablation: operands + counts + pruning only)
     }
 
-    // ---- B. append the matches (doc slots) to the wave's buffer; C. score every full round ---------------------------
+    // ---- B. append the surviving matches (doc slots) to the wave's buffer; C. score every full round -----------------
     const uint32_t slot0 = tile * kTileDocs + lane * 256u;
     for (;;) {
       uint32_t n_new;
@@ -1741,50 +1765,35 @@ __device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatc
       bool more = false;  // wave-uniform: bits left in a[] after this round
       if (n_new != 0) {
         const uint32_t space = plan.ring - pend;
-        if (n_new <= space) {  // the usual case: everything fits, no per-match capacity test
-          uint32_t* out = ring + pend + my_first;
+        uint32_t r = my_first;
+        mine = 0;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            uint32_t x = a[j];
-            while (x != 0) {
-              *out++ = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
-              x &= x - 1;
-            }
+        for (int j = 0; j < 8; ++j) {
+          uint32_t x = a[j];
+          while (x != 0 && r < space) {
+            ring[pend + r] = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
+            x &= x - 1;
+            ++r;
           }
-          mine = 0;
-          pend += n_new;
-        } else {  // a dense tile: take what fits, keep the rest of the bits for the next round
-          uint32_t r = my_first;
-          mine = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            uint32_t x = a[j];
-            while (x != 0 && r < space) {
-              ring[pend + r] = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
-              x &= x - 1;
-              ++r;
-            }
-            a[j] = x;
-            mine += __popc(x);
-          }
-          pend = plan.ring;
-          more = true;
+          a[j] = x;
+          mine += __popc(x);
         }
+        more = n_new > space;
+        pend = more ? plan.ring : pend + n_new;
         wave_lds_sync();
       }
-      const bool fin = flush && !more;  // the wave's last pass: partial groups are scored too
+      const bool fin = flush && !more;  // the wave's last pass: the partial round is scored too
       uint32_t g0 = 0;
       for (;;) {
-        const uint32_t n = min(pend - g0, kFastGroup);
-        if (n == 0 || (n < kFastGroup && !fin)) break;
-        if (!MGX_ABLATE(bt, 4u)) score_group(g0, n);  // (ablation: enumerate, do not score)
+        const uint32_t n = min(pend - g0, kFastRound);
+        if (n == 0 || (n < kFastRound && !fin)) break;
+        if (!MGX_ABLATE(bt, 1u)) score_round(g0, n);  // (ablation: enumerate, do not score)
+#ifdef MGX_ABLATION
+        if (MGX_ABLATE(bt, 64u) && lane == 0) cnt3 += n;  // (debug: after_filters reports the matches that were scored)
+#endif
         g0 += n;
       }
-      if (fin && n_rare != 0u) {  // the last set-aside matches
-        score_rare(n_rare);
-        n_rare = 0;
-      }
-      if (g0 != 0) {  // move the (< kFastGroup) leftover to the front: sources sit at >= kFastGroup, destinations below
+      if (g0 != 0) {  // move the (< kFastRound) leftover to the front: sources sit at >= kFastRound, destinations below
         const uint32_t left = pend - g0;
         uint32_t v[kFastPerLane];
 #pragma unroll
@@ -1811,17 +1820,56 @@ __device__ __forceinline__ void and_score_body(const DevIndex& ix, const DevBatc
       if (lane == 0 && x) atomicAdd(&bt.counters[static_cast<uint64_t>(it.query) * 8 + s], (unsigned long long)x);
     }
   }
-  wave_topk_flush(tk);
-  waves_to_item_list<kFastWaves>(bt, tk, needed, cap, reinterpret_cast<const uint64_t*>(smem + fo.tk_keys),
-                                 reinterpret_cast<const uint32_t*>(smem + fo.tk_docs), misc, it.list, tk.gbound_ptr);
+
+  // ---- merge the waves' lists into this workgroup's best `needed`, best first, to HBM ---------------------------------
+  wave_topk_truncate(tk);
+  if (lane == 0) misc[wave] = tk.have;
+  __syncthreads();
+  {
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + fo.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + fo.tk_docs);
+    const uint32_t cap = tk.cap, needed = tk.needed;
+    uint32_t have[kFastWaves];
+    uint32_t total = 0;
+    for (int w = 0; w < kFastWaves; ++w) {
+      have[w] = min(misc[w], needed);
+      total += have[w];
+    }
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
+    for (uint32_t e = tid; e < kFastWaves * cap; e += kFastBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= have[w]) continue;
+      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+      const uint32_t d = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+      uint32_t rank = i;  // entries of the other waves' (sorted) lists that beat this one, plus its own position
+      for (uint32_t w2 = 0; w2 < kFastWaves; ++w2) {
+        if (w2 == w) continue;
+        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+        uint32_t lo = 0, hi = have[w2];
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, d)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = d;
+        // the needed-th best of the whole item (8 waves' matches merged) is a far tighter query-wide bound than any one
+        // wave's: later items of the query start from it
+        if (rank == needed - 1 && tk.gbound_ptr) atomicMax(tk.gbound_ptr, static_cast<unsigned long long>(k));
+      }
+    }
+    if (tid == 0) bt.cand_n[it.list] = min(total, needed);
+  }
 }
 
 // One kernel per number of scored terms (own register allocation each); a batch launches the ones it has items for.
-// OCC = waves per SIMD the register allocation is held to (6: 80 VGPRs, three workgroups per CU; 4: 128 VGPRs, two).
-template <int T, int OCC>
-__global__ __launch_bounds__(kFastBlock, OCC) void and_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
+template <int T>
+__global__ __launch_bounds__(kFastBlock, 6) void bitmap_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
   const DevItem it = bt.items[blockIdx.x];
-  and_score_body<T>(ix, bt, plan, bt.fast_queries + it.query, it);
+  bitmap_score_body<T>(ix, bt, plan, bt.fast_queries + it.query, it);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2618,6 +2666,22 @@ int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const ui
   return 0;
 }
 
+int LaunchBuildBlockMax(const uint8_t* nib, uint64_t nib_row_stride, const uint8_t* dl8, const double* ktab,
+                        double k1_plus_1, double inv_step, const uint32_t* rows, uint32_t n_rows, uint32_t n_tiles,
+                        bool fine, void* out, hipStream_t s) {
+  const uint64_t n_out = static_cast<uint64_t>(n_tiles) * n_rows * 256u;
+  if (n_out == 0) return 0;
+  const dim3 grid(static_cast<uint32_t>((n_out + 255) / 256));
+  if (fine)
+    hipLaunchKernelGGL(build_blockmax_kernel<true>, grid, dim3(256), 0, s, nib, nib_row_stride, dl8, ktab, k1_plus_1,
+                       inv_step, rows, n_rows, n_out, out);
+  else
+    hipLaunchKernelGGL(build_blockmax_kernel<false>, grid, dim3(256), 0, s, nib, nib_row_stride, dl8, ktab, k1_plus_1,
+                       inv_step, rows, n_rows, n_out, out);
+  MGX_KCHECK();
+  return 0;
+}
+
 int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* row_lo, const uint64_t* row_hi,
                      uint32_t n_rows, uint32_t first_doc_id, uint64_t row_stride_bytes, uint8_t* nib, hipStream_t s) {
   for (uint32_t r0 = 0; r0 < n_rows; r0 += 32768) {
@@ -2707,36 +2771,27 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
   return 0;
 }
 
-template <int T, int OCC>
-static int LaunchAndScoreT(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
+template <int T>
+static int LaunchBitmapScoreT(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
   if (plan.bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&and_score_kernel<T, OCC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bitmap_score_kernel<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL((and_score_kernel<T, OCC>), dim3(bt.n_items), dim3(kFastBlock), plan.bytes, s, ix, bt, plan);
+  hipLaunchKernelGGL((bitmap_score_kernel<T>), dim3(bt.n_items), dim3(kFastBlock), plan.bytes, s, ix, bt, plan);
   MGX_KCHECK();
   return 0;
 }
 
 // bt.items: the fast-path items of the queries with `n_score` scored terms
-int LaunchAndScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
+int LaunchBitmapScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
   if (bt.n_items == 0) return 0;
-  static const int occ = std::getenv("MGX_FAST_OCC") ? atoi(std::getenv("MGX_FAST_OCC")) : 6;
-  if (occ == 4) {
-    switch (n_score) {
-      case 1: return LaunchAndScoreT<1, 4>(ix, bt, plan, s);
-      case 2: return LaunchAndScoreT<2, 4>(ix, bt, plan, s);
-      case 3: return LaunchAndScoreT<3, 4>(ix, bt, plan, s);
-      case 4: return LaunchAndScoreT<4, 4>(ix, bt, plan, s);
-      default: return static_cast<int>(hipErrorInvalidValue);
-    }
-  }
   switch (n_score) {
-    case 1: return LaunchAndScoreT<1, 6>(ix, bt, plan, s);
-    case 2: return LaunchAndScoreT<2, 6>(ix, bt, plan, s);
-    case 3: return LaunchAndScoreT<3, 6>(ix, bt, plan, s);
-    case 4: return LaunchAndScoreT<4, 6>(ix, bt, plan, s);
+    case 1: return LaunchBitmapScoreT<1>(ix, bt, plan, s);
+    case 2: return LaunchBitmapScoreT<2>(ix, bt, plan, s);
+    case 3: return LaunchBitmapScoreT<3>(ix, bt, plan, s);
+    case 4: return LaunchBitmapScoreT<4>(ix, bt, plan, s);
+    case 5: return LaunchBitmapScoreT<5>(ix, bt, plan, s);
     default: return static_cast<int>(hipErrorInvalidValue);
   }
 }

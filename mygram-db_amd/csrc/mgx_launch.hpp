@@ -8,6 +8,9 @@ namespace mgx {
 
 int LaunchBuildTileOff(const uint64_t* offsets, const uint32_t* docids, const uint32_t* rows_gram, uint32_t n_rows,
                        uint32_t n_tiles, uint32_t first_doc_id, uint32_t* tile_off, hipStream_t s);
+int LaunchBuildBlockMax(const uint8_t* nib, uint64_t nib_row_stride, const uint8_t* dl8, const double* ktab,
+                        double k1_plus_1, double inv_step, const uint32_t* rows, uint32_t n_rows, uint32_t n_tiles,
+                        bool fine, void* out, hipStream_t s);
 int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* row_lo, const uint64_t* row_hi,
                      uint32_t n_rows, uint32_t first_doc_id, uint64_t row_stride_bytes, uint8_t* nib, hipStream_t s);
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
@@ -15,7 +18,7 @@ int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uin
                        uint64_t* bitmaps, hipStream_t s);
 int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
-int LaunchAndScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s);
+int LaunchBitmapScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s);
 int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, bool text_df, hipStream_t s);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
