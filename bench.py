@@ -357,9 +357,10 @@ def main():
                          "traffic": None,
                          "peak_measured_read": measured_peak,
                          "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
-                         "kernel": ("mgx::wave_score_kernel (set algebra + fused BM25 from doc-slot tf nibbles + per-wave top-k; "
-                                    "queries with a sorted-list operand run beside it as mgx::wave_score_lists_kernel on a "
-                                    "side stream inside the same timed region)") if by_score else
+                         "kernel": ("mgx::bitmap_score_kernel<3> (set algebra on tile bitmaps, block-max top-k pruning, fused BM25 "
+                                    "of the surviving matches from doc-slot tf nibbles, per-wave top-k; queries with a "
+                                    "sorted-list operand run beside it as mgx::wave_score_lists_kernel on a side stream "
+                                    "inside the same timed region)") if by_score else
                                    "mgx::wave_count_kernel (+ tile_eval doc-count share): set algebra + per-tile counts",
                          "kernel_ms": k_ms, "launches_timed": k_n,
                          "algorithmic_bytes_per_launch": alg_total,

@@ -674,8 +674,9 @@ static int IndexCreateImpl(const mgx_index_desc* d, mgx_index** out) {
   v.gb_tile_stride = bm_grams.size() * mgx::kWordsPerTile;
   idx->n_bitmap_rows = static_cast<uint32_t>(bm_grams.size());
   if (idx->can_score && !bm_grams.empty()) {
-    // the grams held by more than a fifth of the docs get block-max bytes per 16-doc quarter (GetBlockMax)
-    static const double kFineDensity = std::getenv("MGX_FINE_DENSITY") ? atof(std::getenv("MGX_FINE_DENSITY")) : 0.2;
+    // the grams held by more than a twentieth of the docs get block-max bytes per 16-doc quarter (GetBlockMax):
+    // measured on the benchmark batch, 0.05 beats 0.2 (1.55 vs 1.62 ms) and no fine rows at all (1.97 ms)
+    static const double kFineDensity = std::getenv("MGX_FINE_DENSITY") ? atof(std::getenv("MGX_FINE_DENSITY")) : 0.05;
     std::vector<uint32_t> fine_map(bm_grams.size(), mgx::kNoRow), fine_rows;
     for (size_t r = 0; r < bm_grams.size(); ++r) {
       const uint64_t sz = d->offsets[bm_grams[r] + 1] - d->offsets[bm_grams[r]];
@@ -1548,10 +1549,13 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       static const double kMatchesPerUnit = std::getenv("MGX_ITEM_MATCHES") ? atof(std::getenv("MGX_ITEM_MATCHES")) : 256.0;
       static const double kItemCost = std::getenv("MGX_ITEM_COST") ? atof(std::getenv("MGX_ITEM_COST")) : 192.0;
       // (a text scan per candidate costs about what scoring a match does)
-      const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / kMatchesPerUnit : 0.0);
-      uint32_t tiles = static_cast<uint32_t>(kItemCost / per_tile);
       static const uint32_t kMaxTiles = std::getenv("MGX_MAX_ITEM_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_MAX_ITEM_TILES"))) : static_cast<uint32_t>(kMaxTilesPerItem);
-      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, kMaxTiles)) & ~7u;  // whole rounds of the waves of a workgroup
+      // The fast path prunes most matches once a query has a k-th best score, and a longer item keeps that bound in the
+      // workgroup: 4x the tiles per item (measured on the benchmark batch: 1.55 -> 1.49 ms; 8x loses to the tail).
+      const bool fast = on_wave[i] == 3;
+      const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / (fast ? kMatchesPerUnit / 2 : kMatchesPerUnit) : 0.0);
+      uint32_t tiles = static_cast<uint32_t>((fast ? 4.0 * kItemCost : kItemCost) / per_tile);
+      tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, fast ? 2 * kMaxTiles : kMaxTiles)) & ~7u;  // whole rounds of the waves of a workgroup
       // the workgroup kernel walks its tiles one after the other (~4 us each): short items keep the few queries it
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;

@@ -1745,7 +1745,7 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) cnt_res += __popc(a[j]);  // every match counts ...
-      if (qmask != 0xFFFFu) {                                // ... only the quarters that can reach the page are scored
+      if (qmask != 0xFFFFu && !MGX_ABLATE(bt, 128u)) {       // ... only the quarters that can reach the page are scored
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const uint32_t m2 = qmask >> (2 * j);

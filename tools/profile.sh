@@ -6,7 +6,7 @@
 # --kernel-trace only (no --sys-trace / --hip-trace beside --pmc: refused on this pool), FETCH_SIZE and WRITE_SIZE in
 # separate passes (TCC slots). The program after `--` is python3 itself (no env/bash hop under the profiler).
 set -u
-TAG=${1:?tag}; KERNEL=${2:-and_score_kernel}; shift; shift || true
+TAG=${1:?tag}; KERNEL=${2:-bitmap_score_kernel}; shift; shift || true
 for kv in "$@"; do export "$kv"; done
 export MGX_BENCH_CPU_SECONDS=${MGX_BENCH_CPU_SECONDS:-0}
 OUT=$PWD/gpurun_out/prof_$TAG
