@@ -246,12 +246,14 @@ def main():
     results0 = batches[0].fetch() if rank == 0 else None
 
     # ---------------------------------------------------------------------------------------------------------------
-    # (2) the timed region: fresh batches end to end in C++ (N = 1); N > 1 keeps the exchange path of dist.py per step
+    # (2) the timed region: fresh batches end to end in C++; N > 1 adds the RCCL exchange inside the same C++ executor
     # ---------------------------------------------------------------------------------------------------------------
     lat, timings = [], []
-    if not exchange:
+    cxx_exchange = exchange and dist.get_backend() == "nccl"  # (gloo: the CPU rehearsal of dist.py, tests only)
+    if not exchange or cxx_exchange:
         shim_table = S.Table(table.index)
-        ex = S.Executor(shim_table, depth=depth, planner_threads=planners)
+        comm = mdist.Comm() if cxx_exchange else None  # RCCL communicator behind the C ABI (mgx_comm_create)
+        ex = S.Executor(shim_table, depth=depth, planner_threads=planners, comm=comm)
         qbs = [S.QueryBatch(tb) for tb in term_batches]
         outs = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
                  np.zeros((batch_size, 10), np.float64), np.zeros(4, np.float64)) for _ in range(depth)]
@@ -334,7 +336,9 @@ def main():
                 "what": ("fresh batch per step, in C++: plan (GenerateTermInfos, size sort, idf) -> compile + schedule "
                          "(mgx_batch_reset) -> async upload -> kernels -> pinned results -> BatchResult; %d batches in "
                          "flight, %d distinct batches cycled, %d host planner threads" % (depth, N_DISTINCT_BATCHES, planners))
-                        if not exchange else "prepared batches + per-step RCCL exchange (dist.ShardedTable.run)",
+                        + ("; every batch's per-shard top-k all-gathered over RCCL (mgx_batch_exchange) and merged on "
+                           "the batch's stream, in C++" if cxx_exchange else "")
+                        if (not exchange or cxx_exchange) else "prepared batches + per-step gloo exchange (dist.ShardedTable.run)",
                 "end_to_end_qps": qps,
                 "prepare_ms": float(tm[:, 0].mean() + tm[:, 1].mean()), "plan_ms": float(tm[:, 0].mean()),
                 "compile_ms": float(tm[:, 1].mean()), "enqueue_ms": float(tm[:, 2].mean()),

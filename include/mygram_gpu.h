@@ -287,6 +287,22 @@ int mgx_batch_export_buffer(mgx_batch* batch, void** device_blob, uint64_t* byte
  * all-gather moves everything: pitch64 = bytes_per_rank/8, pitch32 = bytes_per_rank/4. */
 int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
                            const uint32_t* blob32, uint64_t pitch32, void* hip_stream);
+/* The collective of the sharded path behind this ABI (RCCL, loaded on first use): one communicator per rank of a table
+ * whose shards are doc ranges, one rank per GPU. Rank 0 draws the id (mgx_comm_unique_id), the host layer hands its
+ * MGX_COMM_ID_BYTES bytes to every rank by whatever channel it has (the reference has none to replace: it is a single
+ * process), every rank calls mgx_comm_create — collectively.
+ * mgx_batch_exchange, after mgx_batch_execute on the same stream: all-gathers every shard's per-query top-(offset+limit)
+ * (ONE ncclAllGather of the batch's exchange blob) and merges them (mgx_batch_merge_shards); mgx_batch_fetch then
+ * returns the table-wide page and total on every rank. mgx_batch_exchange_df, BEFORE mgx_batch_execute: the df pass of
+ * the batch's text-level terms + ONE ncclAllReduce of their counts (no-op without such terms). Every rank must call
+ * the same sequence of exchanges on its communicator, in the same order. */
+#define MGX_COMM_ID_BYTES 128
+typedef struct mgx_comm mgx_comm;
+int mgx_comm_unique_id(uint8_t* id /* [MGX_COMM_ID_BYTES] */);
+int mgx_comm_create(const uint8_t* id, int rank, int world, int device, mgx_comm** out);
+void mgx_comm_destroy(mgx_comm* comm);
+int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
+int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
 /* Text-level terms across shards: df must be table-wide before idf is taken. mgx_batch_count_df enqueues only the df
  * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per DISTINCT
  * term of the batch, in order of first appearance — the same on every shard), which the caller sums over ranks in place (one RCCL all-reduce); the next

@@ -43,6 +43,10 @@ int mgxs_normalize_text(const char* text, size_t len, int nfkc, const char* widt
                         size_t* out_len);
 
 int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out);
+/* One rank of a table sharded by doc range: every batch's per-shard top-k is all-gathered over `comm` (mgx_comm_create,
+ * RCCL) and merged inside mgxs_submit, on the batch's stream; mgxs_wait returns table-wide pages and totals on every
+ * rank. Collective: every rank submits the same batches in the same order (BatchExecutor::Options::comm). */
+int mgxs_executor_create_sharded(mgxs_table* table, int depth, int planner_threads, mgx_comm* comm, mgxs_executor** out);
 void mgxs_executor_destroy(mgxs_executor* ex);
 
 /* One batch of plain conjunctive queries (query::Query with search_text + and_terms): query i has n_terms[i] raw term

@@ -21,7 +21,8 @@ EXPORTS = [
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
-    "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
+    "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy",
+    "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
     "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth", "mgxt_fail_device_allocs",
 ]
@@ -128,6 +129,12 @@ def load():
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]
     L.mgx_batch_export_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_merge_shards.argtypes = [vp, u32, vp, u64, vp, u64, vp]
+    L.mgx_comm_unique_id.argtypes = [vp]
+    L.mgx_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.mgx_comm_destroy.argtypes = [vp]
+    L.mgx_comm_destroy.restype = None
+    L.mgx_batch_exchange.argtypes = [vp, vp, vp]
+    L.mgx_batch_exchange_df.argtypes = [vp, vp, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]
     L.mgx_batch_destroy.argtypes = [vp]

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
            "mgxs_table_set_normalization", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
-           "mgxs_executor_create", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait"]
+           "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait"]
 _lib = None
 
 
@@ -37,6 +37,7 @@ def load():
     L.mgxs_table_destroy.argtypes = [vp]
     L.mgxs_table_destroy.restype = None
     L.mgxs_executor_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.mgxs_executor_create_sharded.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
     L.mgxs_executor_destroy.argtypes = [vp]
     L.mgxs_executor_destroy.restype = None
     L.mgxs_submit.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, C.POINTER(u64)]
@@ -113,10 +114,16 @@ class Table:
 class Executor:
     """search_pipeline::BatchExecutor: submit() plans + compiles + enqueues a fresh batch in C++, wait() fetches it."""
 
-    def __init__(self, table, depth=2, planner_threads=4):
+    def __init__(self, table, depth=2, planner_threads=4, comm=None):
+        """comm: a dist.Comm (one rank of a doc-range-sharded table) — every batch's top-k is then all-gathered over RCCL
+        and merged inside submit(); every rank submits the same batches in the same order."""
         self._table = table
+        self._comm = comm  # kept alive
         h = C.c_void_p()
-        _check(load().mgxs_executor_create(table._h, depth, planner_threads, C.byref(h)))
+        if comm is None:
+            _check(load().mgxs_executor_create(table._h, depth, planner_threads, C.byref(h)))
+        else:
+            _check(load().mgxs_executor_create_sharded(table._h, depth, planner_threads, comm._h, C.byref(h)))
         self._h = h
         self._shape = {}
 

@@ -7,6 +7,8 @@
 // operator either runs on the device or fails.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -306,6 +308,11 @@ struct mgx_index {
 };
 
 namespace mgx {
+// RCCL's by-value types, restated (rccl.h:40-41, :259-270) so that the library needs no RCCL header to build
+struct RcclId {
+  char internal[128];
+};
+constexpr int kRcclUint8 = 1, kRcclUint64 = 5, kRcclSum = 0;
 static inline uint64_t Bits(double d) {
   uint64_t u;
   std::memcpy(&u, &d, 8);
@@ -1232,6 +1239,7 @@ struct mgx_batch {
   // by the merge kernel: [keys n*S u64 | totals n u64 | docs n*S u32 | counts n u32]  (S = top_stride)
   DevBuf d_export;
   size_t ex_off32 = 0, ex_bytes = 0;
+  DevBuf d_xchg_send, d_xchg_recv;  // mgx_batch_exchange: this rank's blob (docid pages only) and every rank's (owned: kept across resets)
   uint64_t* ex_keys() const { return d_export.as<uint64_t>(); }
   uint64_t* ex_totals(size_t n) const { return d_export.as<uint64_t>() + n * top_stride; }
   uint32_t* ex_docs() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(d_export.p) + ex_off32); }
@@ -2385,6 +2393,149 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
   batch->merged_shards = true;
   batch->last_stream = s;
   return mgx::IssueResultCopy(batch, s);
+}
+
+// =================================================================================================================
+// RCCL exchange (one rank per doc-range shard): the collective of the sharded path lives behind the C ABI
+// =================================================================================================================
+// librccl is loaded on first use (dlopen), so the library itself loads on hosts without it; the five entry points
+// below are RCCL's own (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclAllReduce :611, ncclAllGather :678).
+namespace mgx {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string error;
+};
+static Rccl& LoadRccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      r.error = std::string("librccl.so not found: ") + dlerror();
+      return;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(r.lib, n);
+      if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n;
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return r;
+}
+static int RcclFail(const char* what, int rc) {
+  Rccl& r = LoadRccl();
+  return Fail(MGX_ERR_INTERNAL, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error") +
+                                    " (" + std::to_string(rc) + ")");
+}
+}  // namespace mgx
+
+struct mgx_comm {
+  void* comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+int mgx_comm_unique_id(uint8_t* id) {
+  if (!id) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_comm_unique_id: null argument");
+  mgx::Rccl& r = mgx::LoadRccl();
+  if (!r.error.empty()) return mgx::Fail(MGX_ERR_INTERNAL, r.error);
+  mgx::RcclId uid{};
+  const int rc = r.GetUniqueId(&uid);
+  if (rc != 0) return mgx::RcclFail("ncclGetUniqueId", rc);
+  std::memcpy(id, uid.internal, MGX_COMM_ID_BYTES);
+  return MGX_OK;
+}
+
+int mgx_comm_create(const uint8_t* id, int rank, int world, int device, mgx_comm** out) {
+  if (out) *out = nullptr;
+  if (!id || !out || world < 1 || rank < 0 || rank >= world)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_comm_create: bad argument");
+  mgx::Rccl& r = mgx::LoadRccl();
+  if (!r.error.empty()) return mgx::Fail(MGX_ERR_INTERNAL, r.error);
+  MGX_HIP(hipSetDevice(device));
+  mgx::RcclId uid{};
+  std::memcpy(uid.internal, id, MGX_COMM_ID_BYTES);
+  auto c = std::make_unique<mgx_comm>();
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  const int rc = r.CommInitRank(&c->comm, world, uid, rank);
+  if (rc != 0) return mgx::RcclFail("ncclCommInitRank", rc);
+  *out = c.release();
+  return MGX_OK;
+}
+
+void mgx_comm_destroy(mgx_comm* comm) {
+  if (!comm) return;
+  if (comm->comm) (void)mgx::LoadRccl().CommDestroy(comm->comm);
+  delete comm;
+}
+
+int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
+  if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange_df: null argument");
+  uint64_t* counts = nullptr;
+  uint32_t n = 0;
+  int rc = mgx_batch_df_buffer(batch, &counts, &n);
+  if (rc || n == 0) return rc;
+  rc = mgx_batch_count_df(batch, hip_stream);
+  if (rc) return rc;
+  hipStream_t s = nullptr;
+  rc = mgx::BatchStream(batch, hip_stream, &s);
+  if (rc) return rc;
+  // PopulateTermDocumentFrequency over every shard's candidates: the per-shard counts are summed before any rank takes idf
+  const int nrc = mgx::LoadRccl().AllReduce(counts, counts, n, mgx::kRcclUint64, mgx::kRcclSum, comm->comm, s);
+  if (nrc != 0) return mgx::RcclFail("ncclAllReduce", nrc);
+  return MGX_OK;
+}
+
+int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
+  if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange: null argument");
+  if (batch->n_queries == 0) return MGX_OK;
+  if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange: not executed");
+  hipStream_t s = nullptr;
+  int rc = mgx::BatchStream(batch, hip_stream, &s);
+  if (rc) return rc;
+  MGX_HIP(hipSetDevice(batch->idx->device));
+  mgx::ResourceScope own(nullptr);  // exchange buffers are the batch object's own (kept across mgx_batch_reset)
+  void* blob = nullptr;
+  uint64_t bytes = 0, off32 = 0;
+  rc = mgx_batch_export_buffer(batch, &blob, &bytes, &off32);
+  if (rc) return rc;
+  if (!blob) {  // docid-ordered pages: exported by copy into the exchange layout
+    uint32_t stride = 0;
+    rc = mgx_batch_export_topk(batch, nullptr, nullptr, &stride, s);
+    if (rc) return rc;
+    const uint64_t elems = static_cast<uint64_t>(batch->n_queries) * stride + batch->n_queries;
+    off32 = elems * 8;
+    bytes = (elems * 12 + 7) / 8 * 8;
+    if (batch->d_xchg_send.bytes < bytes) MGX_HIP(batch->d_xchg_send.Alloc(bytes));
+    blob = batch->d_xchg_send.p;
+    rc = mgx_batch_export_topk(batch, static_cast<uint64_t*>(blob),
+                               reinterpret_cast<uint32_t*>(static_cast<char*>(blob) + off32), &stride, s);
+    if (rc) return rc;
+  }
+  const uint64_t need = bytes * static_cast<uint64_t>(comm->world);
+  if (batch->d_xchg_recv.bytes < need) MGX_HIP(batch->d_xchg_recv.Alloc(need));
+  // one all-gather moves every rank's keys, totals, doc ids and counts (both blobs sit in one buffer per rank)
+  const int nrc = mgx::LoadRccl().AllGather(blob, batch->d_xchg_recv.p, bytes, mgx::kRcclUint8, comm->comm, s);
+  if (nrc != 0) return mgx::RcclFail("ncclAllGather", nrc);
+  char* g = static_cast<char*>(batch->d_xchg_recv.p);
+  return mgx_batch_merge_shards(batch, static_cast<uint32_t>(comm->world), reinterpret_cast<const uint64_t*>(g),
+                                bytes / 8, reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, s);
 }
 
 int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes,

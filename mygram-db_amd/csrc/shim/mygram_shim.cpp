@@ -929,7 +929,10 @@ Expected<uint64_t, Error> BatchExecutor::Submit(const std::vector<BatchQuery>& q
   if (!slot->mq.empty()) {
     void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
     rc = mgx_batch_stream(slot->batch, &stream);
+    mgx_comm* comm = impl_->opt.comm;
+    if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
     if (rc == MGX_OK) rc = mgx_batch_execute(slot->batch, stream);  // asynchronous
+    if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);  // all-gather + merge, same stream
     if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   }
   const auto t3 = clock::now();

@@ -288,6 +288,12 @@ class BatchExecutor {
   struct Options {
     int depth = 2;
     int planner_threads = 4;
+    // One rank of a table sharded by doc range: after every execute the shards' top-k are all-gathered
+    // over this communicator (mgx_comm_create; RCCL) and merged, so Wait returns the table-wide page and total on
+    // every rank. Every rank submits the same batches in the same order; the index carries the table-wide statistics
+    // (Index::SetGlobalStats), and every query gram is in every shard's dictionary (the planner resolves grams in the
+    // shard's own; mygram-db_amd/dist.py covers the general case with MGX_GRAM_ABSENT).
+    mgx_comm* comm = nullptr;
   };
   struct Timing {  // host milliseconds of one batch
     double plan_ms = 0, compile_ms = 0, enqueue_ms = 0, wait_ms = 0;

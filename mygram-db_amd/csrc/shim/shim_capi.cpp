@@ -90,20 +90,25 @@ int mgxs_normalize_text(const char* text, size_t len, int nfkc, const char* widt
 
 void mgxs_table_destroy(mgxs_table* table) { delete table; }
 
-int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out) {
+int mgxs_executor_create_sharded(mgxs_table* table, int depth, int planner_threads, mgx_comm* comm, mgxs_executor** out) {
   if (out) *out = nullptr;
-  if (!table || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_executor_create: null argument");
+  if (!table || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_executor_create_sharded: null argument");
   try {
     auto e = std::make_unique<mgxs_executor>();
     BatchExecutor::Options o;
     o.depth = depth > 0 ? depth : 2;
     o.planner_threads = planner_threads > 0 ? planner_threads : 1;
+    o.comm = comm;
     e->ex = std::make_unique<BatchExecutor>(*table->index, o);
     *out = e.release();
     return MGX_OK;
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
   }
+}
+
+int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs_executor** out) {
+  return mgxs_executor_create_sharded(table, depth, planner_threads, nullptr, out);
 }
 
 void mgxs_executor_destroy(mgxs_executor* ex) { delete ex; }

@@ -57,6 +57,38 @@ def global_table_stats(local_keys, local_sizes, local_doc_count, local_total_len
     return sizes, int(tot[-2]), int(tot[-1]), {k: int(tot[i]) for k, i in pos.items()}
 
 
+class Comm:
+    """mgx_comm (include/mygram_gpu.h): this rank's RCCL communicator over the ranks of a sharded table. The 128-byte id
+    is drawn on rank 0 and handed round with torch.distributed (whatever backend the job runs: plumbing only — the
+    per-batch collective itself is RCCL inside the library, search_pipeline::BatchExecutor::Options::comm)."""
+
+    def __init__(self, rank=None, world=None, device=None):
+        import ctypes as C
+        from . import _capi
+        L = _capi.load()
+        init = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank() if init else 0) if rank is None else rank
+        self.world = (dist.get_world_size() if init else 1) if world is None else world
+        self.device = torch.cuda.current_device() if device is None else device
+        ident = [None]
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _capi.check(L.mgx_comm_unique_id(buf))
+            ident[0] = bytes(buf)
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        h = C.c_void_p()
+        raw = (C.c_uint8 * 128).from_buffer_copy(ident[0])
+        _capi.check(L.mgx_comm_create(raw, self.rank, self.world, self.device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            from . import _capi
+            _capi.load().mgx_comm_destroy(self._h)
+            self._h = None
+
+
 class ShardedTable:
     """One rank's shard of a table plus the global statistics every rank agrees on."""
 
@@ -125,6 +157,16 @@ class ShardedTable:
         the table-wide page and total on every rank."""
         stream = torch.cuda.current_stream().cuda_stream
         exchange = self.world > 1 or self.force_exchange
+        if exchange and dist.get_backend() == "nccl":
+            # the production path: both collectives are RCCL calls inside the library (mgx_batch_exchange[_df])
+            if getattr(self, "comm", None) is None:
+                self.comm = Comm()
+            if batch.n:
+                batch.exchange_df(self.comm, stream)
+            batch.execute(stream)
+            if batch.n:
+                batch.exchange(self.comm, stream)
+            return
         if exchange and batch.n:
             ptr, n_tt = batch.df_buffer()
             if n_tt:

@@ -379,6 +379,14 @@ class PreparedBatch:
         check(load().mgx_batch_fetch(self._h, C.byref(v)))
         return v
 
+    def exchange_df(self, comm, stream=None):
+        """mgx_batch_exchange_df: table-wide df of the text-level terms (df pass + RCCL all-reduce); before execute."""
+        check(load().mgx_batch_exchange_df(self._h, comm._h, stream))
+
+    def exchange(self, comm, stream=None):
+        """mgx_batch_exchange: RCCL all-gather of every shard's top-k + merge; after execute, same stream."""
+        check(load().mgx_batch_exchange(self._h, comm._h, stream))
+
     def count_df(self, stream=None):
         """df pass of the text-level terms only (sharded tables reduce the counts before execute)."""
         check(load().mgx_batch_count_df(self._h, stream))
