@@ -183,8 +183,8 @@ def main():
     batch_size = int(os.environ.get("MGX_BENCH_BATCH", "1024"))
     cpu_seconds = float(os.environ.get("MGX_BENCH_CPU_SECONDS", "24"))
     dense = float(os.environ.get("MGX_BENCH_DENSE", "0"))
-    depth = int(os.environ.get("MGX_BENCH_DEPTH", "2"))
-    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, physical_cores()[0] - 1))
+    depth = int(os.environ.get("MGX_BENCH_DEPTH", "3"))
+    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (physical_cores()[0] - 1) // max(1, world)))
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
     # the intersection-only path (mgx::wave_count_kernel + page emit), docid-DESC pages of 10

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <map>
 #include <cstdio>
@@ -1564,6 +1565,12 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / (fast ? kMatchesPerUnit / 2 : kMatchesPerUnit) : 0.0);
       uint32_t tiles = static_cast<uint32_t>((fast ? 4.0 * kItemCost : kItemCost) / per_tile);
       tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, fast ? 2 * kMaxTiles : kMaxTiles)) & ~7u;  // whole rounds of the waves of a workgroup
+      // a small shard (few tiles per query) still wants a few workgroups per CU slot, or the launch is one ragged round
+      if (score_mode) {
+        const uint64_t want_items = 4ull * 768ull;  // ~4 rounds of the 768 workgroups a launch keeps resident
+        const uint64_t cap = std::max<uint64_t>(8, (static_cast<uint64_t>(n_tiles) * n / want_items + 7) & ~7ull);
+        tiles = static_cast<uint32_t>(std::min<uint64_t>(tiles, cap));
+      }
       // the workgroup kernel walks its tiles one after the other (~4 us each): short items keep the few queries it
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;
@@ -2227,15 +2234,29 @@ int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queri
     std::vector<mgx::QuerySpec> specs = std::move(batch->specs);  // (their vectors' storage is compiled into again)
     specs.resize(n_queries);
     int rc = MGX_OK;
+    static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < n_queries && rc == MGX_OK; ++i) {
       specs[i].Clear();
       rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
       if (rc) mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
     }
+    const auto t1 = std::chrono::steady_clock::now();
     MGX_HIP(hipSetDevice(idx->device));
     mgx::ResetBatch(batch);
     if (rc) return rc;  // (the batch is empty but usable)
-    return mgx::PrepareInto(batch, idx, std::move(specs));
+    rc = mgx::PrepareInto(batch, idx, std::move(specs));
+    if (kTrace) {
+      static std::atomic<uint64_t> n{0};
+      static std::atomic<uint64_t> us_compile{0}, us_into{0};
+      const auto t2 = std::chrono::steady_clock::now();
+      us_compile += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+      us_into += std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+      if (++n % 64 == 0)
+        fprintf(stderr, "[mgx] reset x64: CompileQuery loop %.3f ms, reset + PrepareInto %.3f ms per batch\n",
+                us_compile.exchange(0) / 64e3, us_into.exchange(0) / 64e3);
+    }
+    return rc;
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_reset: ") + e.what());
   }

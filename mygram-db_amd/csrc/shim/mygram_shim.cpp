@@ -806,74 +806,134 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
 }
 
 // ---- BatchExecutor ------------------------------------------------------------------------------------------------
+//
+// Submit only queues: a pool of workers plans the batch in chunks of queries (several batches at once when several are
+// queued); one dispatcher thread compiles planned batches (mgx_batch_reset: host work, one object per slot) and puts
+// them on the device strictly in ticket order — on a sharded table each execute is followed by a collective that every
+// rank must issue in the same order. Wait blocks until its ticket is on the device, then fetches.
 
 struct BatchExecutor::Impl {
+  using clock = std::chrono::steady_clock;
   const index::Index& index;
   Options opt;
   uint64_t total_docs = 0;
   double avgdl = 0.0;
+  enum State { kFree, kPlanning, kPlanned, kCompiled, kEnqueued, kFailed };
   struct Slot {
     mgx_batch* batch = nullptr;
+    std::vector<BatchQuery> queries;
     std::vector<PlannedQuery> plans;
     std::vector<mgx_query> mq;
-    uint64_t ticket = 0;  // 0 = free
+    uint64_t ticket = 0;
+    State state = kFree;
+    size_t chunks_left = 0;  // under mu
+    Error error{ErrorCode::kSuccess, ""};
     Timing timing;
+    clock::time_point t_submit, t_planned, t_compiled;
   };
+  struct Chunk {
+    Slot* slot;
+    size_t begin, end;
+  };
+  static constexpr size_t kChunk = 64;
   std::vector<Slot> slots;
-  uint64_t next_ticket = 1;
-  // planner pool: Submit hands out query ranges, the workers run PlanQuery on them
+  uint64_t next_ticket = 1, next_enqueue = 1;
   std::vector<std::thread> workers;
-  std::mutex mu;
-  std::condition_variable cv_work, cv_done;
-  const std::vector<BatchQuery>* job_queries = nullptr;
-  std::vector<PlannedQuery>* job_plans = nullptr;
-  size_t job_next = 0, job_end = 0, job_pending = 0;
-  uint64_t job_generation = 0;
+  std::thread dispatcher;
+  std::mutex mu;  // slots' state, the chunk queue, the enqueue turn
+  std::condition_variable cv_work, cv_state;
+  std::deque<Chunk> chunks;
   bool stop = false;
 
   Impl(const index::Index& ix, Options o) : index(ix), opt(o) {}
 
+  Slot* ByTicket(uint64_t ticket) {
+    for (auto& s : slots)
+      if (s.state != kFree && s.ticket == ticket) return &s;
+    return nullptr;
+  }
+
+  // host side of one batch after planning: the device queries, compiled into the slot's batch object
+  void Compile(Slot* slot) {
+    index::Index::Impl* im = index.impl();
+    slot->mq.clear();
+    for (const auto& p : slot->plans) {
+      if (p.error != ErrorCode::kSuccess) {
+        slot->error = MakeError(p.error, p.error_message);
+        return;
+      }
+      if (p.on_device) slot->mq.push_back(p.q);
+    }
+    if (slot->mq.empty()) return;
+    int rc;
+    if (!slot->batch)
+      rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
+    else
+      rc = mgx_batch_reset(slot->batch, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()));
+    if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
+  }
+
+  // device side, in ticket order (called with mu held; the calls below only enqueue)
+  void EnqueueReady() {
+    for (;;) {
+      Slot* slot = ByTicket(next_enqueue);
+      if (!slot || (slot->state != kCompiled && slot->state != kFailed)) return;
+      if (slot->state == kCompiled && !slot->mq.empty()) {
+        const auto t0 = clock::now();
+        void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
+        int rc = mgx_batch_stream(slot->batch, &stream);
+        mgx_comm* comm = opt.comm;
+        if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
+        if (rc == MGX_OK) rc = mgx_batch_execute(slot->batch, stream);                    // asynchronous
+        if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
+        if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
+        slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
+      }
+      slot->state = slot->error.code() == ErrorCode::kSuccess && slot->state == kCompiled ? kEnqueued : kFailed;
+      ++next_enqueue;
+      cv_state.notify_all();
+    }
+  }
+
   void Work() {
     std::unique_lock<std::mutex> lock(mu);
     for (;;) {
-      cv_work.wait(lock, [&] { return stop || job_next < job_end; });
+      cv_work.wait(lock, [&] { return stop || !chunks.empty(); });
       if (stop) return;
-      const size_t chunk = 32;
-      const size_t a = job_next, b = std::min(job_end, a + chunk);
-      job_next = b;
-      const auto* queries = job_queries;
-      auto* plans = job_plans;
+      const Chunk c = chunks.front();
+      chunks.pop_front();
       lock.unlock();
-      for (size_t i = a; i < b; ++i) PlanQuery(index, (*queries)[i], total_docs, avgdl, &(*plans)[i]);
+      for (size_t i = c.begin; i < c.end; ++i)
+        PlanQuery(index, c.slot->queries[i], total_docs, avgdl, &c.slot->plans[i]);
       lock.lock();
-      job_pending -= b - a;
-      if (job_pending == 0) cv_done.notify_all();
+      if (--c.slot->chunks_left != 0) continue;
+      c.slot->t_planned = clock::now();
+      c.slot->state = kPlanned;
+      cv_state.notify_all();
     }
   }
-  void PlanAll(const std::vector<BatchQuery>& queries, std::vector<PlannedQuery>* plans) {
-    plans->clear();
-    plans->resize(queries.size());
-    if (workers.empty() || queries.size() < 64) {
-      for (size_t i = 0; i < queries.size(); ++i) PlanQuery(index, queries[i], total_docs, avgdl, &(*plans)[i]);
-      return;
-    }
+
+  // One thread compiles and enqueues, ticket after ticket: the compile step walks the same arenas and pinned blocks
+  // every time (they stay in its caches; compiling on whichever planner finished last cost 2-3x), and the device
+  // order — which a sharded table's collectives need identical on every rank — is the loop's own order.
+  void Dispatch() {
     std::unique_lock<std::mutex> lock(mu);
-    job_queries = &queries;
-    job_plans = plans;
-    job_next = 0;
-    job_end = job_pending = queries.size();
-    cv_work.notify_all();
-    // the submitting thread plans too
-    while (job_next < job_end) {
-      const size_t a = job_next, b = std::min(job_end, a + 32);
-      job_next = b;
+    for (;;) {
+      Slot* slot = nullptr;
+      cv_state.wait(lock, [&] {
+        slot = ByTicket(next_enqueue);
+        return stop || (slot && slot->state == kPlanned);
+      });
+      if (stop) return;
       lock.unlock();
-      for (size_t i = a; i < b; ++i) PlanQuery(index, queries[i], total_docs, avgdl, &(*plans)[i]);
+      Compile(slot);
+      slot->t_compiled = clock::now();
+      slot->timing.plan_ms = std::chrono::duration<double, std::milli>(slot->t_planned - slot->t_submit).count();
+      slot->timing.compile_ms = std::chrono::duration<double, std::milli>(slot->t_compiled - slot->t_planned).count();
       lock.lock();
-      job_pending -= b - a;
+      slot->state = slot->error.code() == ErrorCode::kSuccess ? kCompiled : kFailed;
+      EnqueueReady();
     }
-    cv_done.wait(lock, [&] { return job_pending == 0; });
-    job_end = 0;
   }
 };
 
@@ -882,87 +942,96 @@ BatchExecutor::BatchExecutor(const index::Index& index, Options options) : impl_
   impl_->total_docs = index.Bm25DocCount();
   impl_->avgdl = index.Bm25AvgDocLength();
   impl_->slots.resize(static_cast<size_t>(std::max(1, options.depth)));
-  for (int t = 1; t < options.planner_threads; ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
+  for (int t = 0; t < std::max(1, options.planner_threads); ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
+  impl_->dispatcher = std::thread([this] { impl_->Dispatch(); });
 }
 
 BatchExecutor::~BatchExecutor() {
   {
-    std::lock_guard<std::mutex> lock(impl_->mu);
+    std::unique_lock<std::mutex> lock(impl_->mu);
+    // batches still in the pipeline reach the device first: a collective half-issued would hang the other ranks
+    impl_->cv_state.wait(lock, [&] {
+      for (auto& s : impl_->slots)
+        if (s.state == Impl::kPlanning || s.state == Impl::kPlanned || s.state == Impl::kCompiled) return false;
+      return true;
+    });
     impl_->stop = true;
   }
   impl_->cv_work.notify_all();
+  impl_->cv_state.notify_all();
   for (auto& w : impl_->workers) w.join();
-  for (auto& s : impl_->slots)
+  impl_->dispatcher.join();
+  for (auto& s : impl_->slots) {
+    if (s.state == Impl::kEnqueued && s.batch && !s.mq.empty()) {
+      mgx_result_view v{};
+      (void)mgx_batch_fetch(s.batch, &v);  // (drain the device before the object goes)
+    }
     if (s.batch) mgx_batch_destroy(s.batch);
+  }
 }
 
-Expected<uint64_t, Error> BatchExecutor::Submit(const std::vector<BatchQuery>& queries) {
+Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& queries) {
   index::Index::Impl* im = impl_->index.impl();
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  std::unique_lock<std::mutex> lock(impl_->mu);
   Impl::Slot* slot = nullptr;
   for (auto& s : impl_->slots)
-    if (s.ticket == 0) {
+    if (s.state == Impl::kFree) {
       slot = &s;
       break;
     }
   if (!slot)
     return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument,
                                     "BatchExecutor: every slot holds an unfetched batch (Wait for one first)"));
-  using clock = std::chrono::steady_clock;
-  const auto t0 = clock::now();
-  impl_->PlanAll(queries, &slot->plans);
-  slot->mq.clear();
-  for (const auto& p : slot->plans) {
-    if (p.error != ErrorCode::kSuccess) return MakeUnexpected(MakeError(p.error, p.error_message));
-    if (p.on_device) slot->mq.push_back(p.q);
-  }
-  const auto t1 = clock::now();
-  int rc = MGX_OK;
-  if (!slot->mq.empty()) {
-    if (!slot->batch)
-      rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
-    else
-      rc = mgx_batch_reset(slot->batch, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()));
-    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
-  }
-  const auto t2 = clock::now();
-  if (!slot->mq.empty()) {
-    void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
-    rc = mgx_batch_stream(slot->batch, &stream);
-    mgx_comm* comm = impl_->opt.comm;
-    if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
-    if (rc == MGX_OK) rc = mgx_batch_execute(slot->batch, stream);  // asynchronous
-    if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);  // all-gather + merge, same stream
-    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
-  }
-  const auto t3 = clock::now();
-  slot->timing.plan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-  slot->timing.compile_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
-  slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
+  slot->queries = std::move(queries);
+  slot->plans.clear();
+  slot->plans.resize(slot->queries.size());
+  slot->error = Error{ErrorCode::kSuccess, ""};
+  slot->timing = Timing{};
+  slot->t_submit = Impl::clock::now();
   slot->ticket = impl_->next_ticket++;
+  slot->state = Impl::kPlanning;
+  const size_t n = slot->queries.size();
+  slot->chunks_left = std::max<size_t>(1, (n + Impl::kChunk - 1) / Impl::kChunk);
+  if (n == 0) impl_->chunks.push_back(Impl::Chunk{slot, 0, 0});
+  for (size_t a = 0; a < n; a += Impl::kChunk) impl_->chunks.push_back(Impl::Chunk{slot, a, std::min(n, a + Impl::kChunk)});
+  impl_->cv_work.notify_all();
   return slot->ticket;
 }
 
+Expected<uint64_t, Error> BatchExecutor::Submit(const std::vector<BatchQuery>& queries) {
+  return Submit(std::vector<BatchQuery>(queries));
+}
+
 Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, Timing* timing) {
-  for (auto& s : impl_->slots) {
-    if (s.ticket != ticket || ticket == 0) continue;
-    std::vector<BatchResult> out;
-    mgx_result_view v{};
-    const auto t0 = std::chrono::steady_clock::now();
-    if (!s.mq.empty()) {
-      const int rc = mgx_batch_fetch(s.batch, &v);
-      if (rc != MGX_OK) {
-        s.ticket = 0;
-        return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
-      }
-    }
-    Collect(s.plans, v, &out);
-    s.timing.wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (timing) *timing = s.timing;
-    s.ticket = 0;
-    return out;
+  std::unique_lock<std::mutex> lock(impl_->mu);
+  Impl::Slot* s = ticket ? impl_->ByTicket(ticket) : nullptr;
+  if (!s) return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "BatchExecutor::Wait: unknown ticket"));
+  impl_->cv_state.wait(lock, [&] { return s->state == Impl::kEnqueued || s->state == Impl::kFailed; });
+  if (s->state == Impl::kFailed) {
+    const Error e = s->error;
+    s->state = Impl::kFree;
+    return MakeUnexpected(e);
   }
-  return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "BatchExecutor::Wait: unknown ticket"));
+  lock.unlock();  // (the slot is this caller's until it is freed below)
+  std::vector<BatchResult> out;
+  mgx_result_view v{};
+  const auto t0 = Impl::clock::now();
+  if (!s->mq.empty()) {
+    const int rc = mgx_batch_fetch(s->batch, &v);
+    if (rc != MGX_OK) {
+      const Error e = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
+      lock.lock();
+      s->state = Impl::kFree;
+      return MakeUnexpected(e);
+    }
+  }
+  Collect(s->plans, v, &out);
+  s->timing.wait_ms = std::chrono::duration<double, std::milli>(Impl::clock::now() - t0).count();
+  if (timing) *timing = s->timing;
+  lock.lock();
+  s->state = Impl::kFree;
+  return out;
 }
 
 }  // namespace search_pipeline

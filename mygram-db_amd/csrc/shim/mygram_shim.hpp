@@ -278,11 +278,14 @@ struct BatchResult {
 mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> ExecuteBatch(
     const index::Index& index, const std::vector<BatchQuery>& queries);
 
-// A serving loop over ExecuteBatch's work: every Submit plans a FRESH batch on the host (GenerateTermInfos, the size sort
-// and idf per term — on `planner_threads` threads, the way the reference plans each request on its own worker), compiles
-// it into one of `depth` re-used batch objects (mgx_batch_reset: no allocation in steady state) and enqueues it on that
-// object's own stream; Wait returns its results. With depth >= 2 the host plans batch i+1 while the device runs batch i.
-// Not thread-safe: one submitting thread (a micro-batching front end owns it).
+// A serving loop over ExecuteBatch's work. Submit queues a FRESH batch and returns at once; a pool of `planner_threads`
+// workers plans it in chunks of queries (GenerateTermInfos, the size sort and idf per term — the way the reference
+// plans each request on its own worker; several queued batches are planned side by side), the worker that ends a batch's
+// planning compiles it into one of `depth` re-used batch objects (mgx_batch_reset: no allocation in steady state), and
+// batches go to the device in ticket order, each on its object's own stream. Wait returns a ticket's results. The host
+// therefore prepares up to `depth` batches while the device runs others: throughput is bounded by the slower of the
+// two, not by their sum, and the host side scales with its threads.
+// One submitting / waiting thread at a time (a micro-batching front end owns it).
 class BatchExecutor {
  public:
   struct Options {
@@ -305,6 +308,7 @@ class BatchExecutor {
   BatchExecutor& operator=(const BatchExecutor&) = delete;
   // -> ticket. Fails (kInvalidArgument) when all `depth` slots hold unfetched batches.
   mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(const std::vector<BatchQuery>& queries);
+  mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(std::vector<BatchQuery>&& queries);  // (no copy)
   mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> Wait(uint64_t ticket, Timing* timing = nullptr);
 
  private:

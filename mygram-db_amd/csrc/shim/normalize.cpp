@@ -9,9 +9,11 @@
 #include "../mgx_text.hpp"
 
 #include <atomic>
+#include <cstring>
 #include <vector>
 
 #ifdef MGX_USE_ICU
+#include <unicode/uloc.h>
 #include <unicode/unorm2.h>
 #include <unicode/ustring.h>
 #include <unicode/utrans.h>
@@ -130,6 +132,24 @@ std::string NormalizeText(std::string_view text, bool nfkc, std::string_view wid
     return {};
   }
 #ifdef MGX_USE_ICU
+  // ASCII needs no tables: NFKC and the narrowing transliterator leave it alone and lower-casing it is a byte
+  // operation — in every locale but the three whose 'I' does not lower to 'i' (the default locale decides, as it does
+  // for UnicodeString::toLower()). Query terms are mostly ASCII; this keeps ICU off the planner's hot path.
+  static const bool ascii_lower_is_plain = [] {
+    const char* lang = uloc_getDefault();
+    return !(lang && (std::strncmp(lang, "tr", 2) == 0 || std::strncmp(lang, "az", 2) == 0 || std::strncmp(lang, "lt", 2) == 0));
+  }();
+  if (width != "wide" && ascii_lower_is_plain) {
+    bool ascii = true;
+    for (const char c : text) ascii = ascii && static_cast<unsigned char>(c) < 0x80;
+    if (ascii) {
+      std::string out(text);
+      if (lower)
+        for (char& c : out)
+          if (c >= 'A' && c <= 'Z') c = static_cast<char>(c + 32);
+      return out;
+    }
+  }
   std::string out;
   if (!IcuNormalize(text, nfkc, width, lower, &out)) {
     g_failures.fetch_add(1, std::memory_order_relaxed);

@@ -131,7 +131,8 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
       q.offset = offset;
     }
     ex->limit = limit;
-    auto r = ex->ex->Submit(ex->queries);
+    auto r = ex->ex->Submit(std::move(ex->queries));
+    ex->queries.clear();
     if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
     *ticket = *r;
     return MGX_OK;
