@@ -97,6 +97,19 @@ typedef struct mgx_columns_view {
 /* Docs are first_doc_id, first_doc_id+1, ...; doc i's normalized text is text_bytes[text_off[i] .. text_off[i+1]). */
 int mgx_columns_build(const mgx_build_params* params, const uint8_t* text_bytes, const uint64_t* text_off,
                       uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out);
+/* The reference's index dump ("MGIX" v1..v4: Index::SaveToStream / LoadFromData, src/index/index_serialization.cpp:113-194,
+ * :260-420; posting lists as fixed-width deltas or Roaring portable bytes, src/index/posting_list.cpp:973-1073) ->
+ * columns. The CRC32 trailer (v2+) is verified. A dump holds doc ids only: the view's tf / doc_len are NULL (an index
+ * created from it answers everything but SORT _score). n_docs == 0: the doc range is the span of the ids found. */
+typedef struct mgx_mgix_info {
+  uint32_t version;
+  int32_t ngram_size, kanji_ngram_size, cross_boundary_ngrams;
+  int32_t normalize_nfkc, normalize_lower;
+  char normalize_width[16];
+  uint64_t n_terms;
+} mgx_mgix_info;
+int mgx_columns_from_mgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out,
+                          mgx_mgix_info* info /* may be NULL */);
 int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out);
 /* Gram dictionary lookup (host-side replacement of Index::TakePostingSnapshot's map lookup, index.cpp:728-747).
  * *found = 0 and *gram_id = 0 for an unknown gram. */

@@ -17,7 +17,7 @@ SORT_DOCID, SORT_SCORE = 0, 1
 # every symbol include/mygram_gpu.h and include/mygram_tools.h declare
 EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
-    "mgx_columns_build", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
+    "mgx_columns_build", "mgx_columns_from_mgix", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
@@ -31,6 +31,12 @@ EXPORTS = [
 class BuildParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32), ("ngram_size", C.c_int32),
                 ("kanji_ngram_size", C.c_int32), ("cross_boundary_ngrams", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class MgixInfo(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("ngram_size", C.c_int32), ("kanji_ngram_size", C.c_int32),
+                ("cross_boundary_ngrams", C.c_int32), ("normalize_nfkc", C.c_int32), ("normalize_lower", C.c_int32),
+                ("normalize_width", C.c_char * 16), ("n_terms", C.c_uint64)]
 
 
 class ColumnsView(C.Structure):
@@ -117,6 +123,7 @@ def load():
     L.mgx_index_destroy.restype = None
     L.mgx_posting_size.argtypes = [vp, u32, C.POINTER(u64)]
     L.mgx_index_memory_bytes.argtypes = [vp, C.POINTER(u64)]
+    L.mgx_columns_from_mgix.argtypes = [vp, u64, u32, u64, C.POINTER(vp), C.POINTER(MgixInfo)]
     L.mgx_index_add_filter_bitmap.argtypes = [vp, vp, u64, C.POINTER(u32)]
     L.mgx_batch_prepare.argtypes = [vp, C.POINTER(Query), u32, C.POINTER(vp)]
     L.mgx_batch_reset.argtypes = [vp, C.POINTER(Query), u32]

@@ -493,6 +493,24 @@ int mgx_columns_build(const mgx_build_params* params, const uint8_t* text_bytes,
   }
 }
 
+int mgx_columns_from_mgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out,
+                          mgx_mgix_info* info) {
+  if (out) *out = nullptr;
+  if (!data || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_from_mgix: null argument");
+  if (static_cast<uint64_t>(first_doc_id) + n_docs > 0xFFFFFFFFull)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_columns_from_mgix: doc ids exceed uint32");
+  try {
+    mgx::Columns* c = nullptr;
+    std::string err;
+    const int rc = mgx::ColumnsFromMgix(data, len, first_doc_id, n_docs, &c, info, &err);
+    if (rc != MGX_OK) return mgx::Fail(rc, err);
+    *out = reinterpret_cast<mgx_columns*>(c);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_columns_from_mgix: ") + e.what());
+  }
+}
+
 int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out) {
   if (!cols || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_view_get: null argument");
   mgx::ColumnsView(reinterpret_cast<const mgx::Columns*>(cols), out);

@@ -326,11 +326,11 @@ void ColumnsView(const Columns* c, mgx_columns_view* v) {
   v->key_off = c->key_off.data();
   v->offsets = c->offsets.data();
   v->docids = c->docids.data();
-  v->tf = c->tf.data();
+  v->tf = c->tf.empty() ? nullptr : c->tf.data();
   v->n_postings = c->offsets.empty() ? 0 : c->offsets.back();
   v->first_doc_id = c->first_doc_id;
   v->n_docs = c->n_docs;
-  v->doc_len = c->doc_len.data();
+  v->doc_len = c->doc_len.empty() ? nullptr : c->doc_len.data();
   v->bm25_doc_count = c->bm25_doc_count;
   v->bm25_total_len = c->bm25_total_len;
   v->tf_overflow_pos = c->tf_ovf_pos.data();
@@ -348,5 +348,242 @@ bool ColumnsLookup(const Columns* c, const uint8_t* gram, size_t len, uint32_t* 
 }
 
 void DestroyColumns(Columns* c) { delete c; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// MGIX: the reference's index dump (Index::SaveToStream / LoadFromData, src/index/index_serialization.cpp:113-194 and
+// :260-420) -> CSR columns. Little-endian throughout:
+//   "MGIX" | u32 version (1..4) | u32 ngram_size | [v3+: u32 kanji_ngram_size, u8 cross_boundary] |
+//   [v4: u8 normalize_nfkc, u32 width_len, width bytes, u8 normalize_lower] | u64 term_count |
+//   term_count x { u32 term_len, term bytes, u64 posting_size, posting bytes } | [v2+: u32 CRC32 (zlib) of all before]
+// posting bytes (PostingList::Serialize, src/index/posting_list.cpp:973-1023): u8 strategy, u32 size, then
+//   strategy 0 (kFixedWidthDelta): `size` u32 values — the first doc id, then deltas;
+//   strategy 1 (kRoaringBitmap)  : `size` bytes of Roaring's PORTABLE format (CRoaring's published RoaringFormatSpec:
+//     cookie 12347 | (n-1) << 16 + run-flag bitset, or cookie 12346 + u32 n; n x {u16 key, u16 cardinality-1};
+//     n x u32 offsets unless (run cookie and n < 4); containers: sorted u16 array (cardinality <= 4096), 1024 x u64
+//     bitset, or u16 n_runs + n_runs x {u16 start, u16 length-1}).
+// A dump holds doc ids only: tf and doc lengths live in the reference's DocumentStore, so the columns come back without
+// them (BM25 then needs the texts: mgx_columns_build).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Reader {
+  const uint8_t* p;
+  uint64_t n, at = 0;
+  bool ok = true;
+  bool Need(uint64_t k) {
+    if (!ok || k > n - at) ok = false;
+    return ok;
+  }
+  uint8_t U8() { return Need(1) ? p[at++] : 0; }
+  uint16_t U16() {
+    if (!Need(2)) return 0;
+    const uint16_t v = static_cast<uint16_t>(p[at] | (p[at + 1] << 8));
+    at += 2;
+    return v;
+  }
+  uint32_t U32() {
+    if (!Need(4)) return 0;
+    const uint32_t v = static_cast<uint32_t>(p[at]) | (static_cast<uint32_t>(p[at + 1]) << 8) |
+                       (static_cast<uint32_t>(p[at + 2]) << 16) | (static_cast<uint32_t>(p[at + 3]) << 24);
+    at += 4;
+    return v;
+  }
+  uint64_t U64() {
+    const uint64_t lo = U32(), hi = U32();
+    return lo | (hi << 32);
+  }
+};
+
+uint32_t Crc32(const uint8_t* d, uint64_t n) {  // zlib's crc32 (IEEE 802.3, reflected), as src/utils/crc32.h uses it
+  static uint32_t table[256];
+  static const bool init = [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[i] = c;
+    }
+    return true;
+  }();
+  (void)init;
+  uint32_t c = 0xFFFFFFFFu;
+  for (uint64_t i = 0; i < n; ++i) c = table[(c ^ d[i]) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+// Roaring portable bytes -> ascending doc ids (appended). false: malformed.
+bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out) {
+  Reader r{data, len};
+  const uint32_t cookie = r.U32();
+  uint32_t n = 0;
+  bool has_runs = false;
+  const uint8_t* run_flags = nullptr;
+  if ((cookie & 0xFFFFu) == 12347u) {
+    has_runs = true;
+    n = (cookie >> 16) + 1;
+    const uint32_t fb = (n + 7) / 8;
+    if (!r.Need(fb)) return false;
+    run_flags = data + r.at;
+    r.at += fb;
+  } else if (cookie == 12346u) {
+    n = r.U32();
+  } else {
+    return false;
+  }
+  if (!r.ok || n > 65536) return false;
+  std::vector<uint16_t> keys(n);
+  std::vector<uint32_t> cards(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    keys[i] = r.U16();
+    cards[i] = static_cast<uint32_t>(r.U16()) + 1;
+  }
+  if (!has_runs || n >= 4) {  // offset header (not needed for a sequential read)
+    if (!r.Need(4ull * n)) return false;
+    r.at += 4ull * n;
+  }
+  for (uint32_t i = 0; i < n && r.ok; ++i) {
+    const uint32_t hi = static_cast<uint32_t>(keys[i]) << 16;
+    if (i && keys[i] <= keys[i - 1]) return false;
+    const bool is_run = has_runs && ((run_flags[i / 8] >> (i % 8)) & 1u);
+    if (is_run) {
+      const uint32_t n_runs = r.U16();
+      for (uint32_t k = 0; k < n_runs && r.ok; ++k) {
+        const uint32_t start = r.U16(), last = start + r.U16();
+        if (last > 0xFFFFu) return false;
+        for (uint32_t v = start; v <= last; ++v) out->push_back(hi | v);
+      }
+    } else if (cards[i] <= 4096) {
+      for (uint32_t k = 0; k < cards[i] && r.ok; ++k) out->push_back(hi | r.U16());
+    } else {
+      if (!r.Need(8192)) return false;
+      for (uint32_t w = 0; w < 1024; ++w) {
+        uint64_t bits = 0;
+        for (int b = 0; b < 8; ++b) bits |= static_cast<uint64_t>(data[r.at + w * 8 + b]) << (8 * b);
+        while (bits) {
+          out->push_back(hi | (w * 64 + static_cast<uint32_t>(__builtin_ctzll(bits))));
+          bits &= bits - 1;
+        }
+      }
+      r.at += 8192;
+    }
+  }
+  return r.ok;
+}
+
+}  // namespace
+
+int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, uint64_t n_docs, Columns** out,
+                    mgx_mgix_info* info, std::string* err) {
+  auto fail = [&](int code, const char* what) {
+    *err = std::string("mgx_columns_from_mgix: ") + what;
+    return code;
+  };
+  Reader r{data, len};
+  if (len < 20 || std::memcmp(data, "MGIX", 4) != 0) return fail(MGX_ERR_INVALID_ARGUMENT, "not an MGIX dump (bad magic)");
+  r.at = 4;
+  const uint32_t version = r.U32();
+  if (version < 1 || version > 4) return fail(MGX_ERR_NOT_IMPLEMENTED, "unsupported format version");
+  if (version >= 2) {  // CRC32 trailer over everything before it (index_serialization.cpp:71-112)
+    if (len < 24) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated");
+    const uint64_t body = len - 4;
+    const uint32_t want = static_cast<uint32_t>(data[body]) | (static_cast<uint32_t>(data[body + 1]) << 8) |
+                          (static_cast<uint32_t>(data[body + 2]) << 16) | (static_cast<uint32_t>(data[body + 3]) << 24);
+    if (Crc32(data, body) != want) return fail(MGX_ERR_INVALID_ARGUMENT, "CRC32 mismatch");
+    r.n = body;
+  }
+  mgx_mgix_info mi{};
+  mi.version = version;
+  mi.ngram_size = static_cast<int32_t>(r.U32());
+  mi.kanji_ngram_size = 0;
+  mi.cross_boundary_ngrams = 1;
+  mi.normalize_nfkc = 1;
+  mi.normalize_lower = 1;
+  std::strcpy(mi.normalize_width, "keep");
+  if (version >= 3) {
+    mi.kanji_ngram_size = static_cast<int32_t>(r.U32());
+    mi.cross_boundary_ngrams = r.U8() ? 1 : 0;
+  }
+  if (version >= 4) {
+    mi.normalize_nfkc = r.U8() ? 1 : 0;
+    const uint32_t wl = r.U32();
+    if (wl >= sizeof(mi.normalize_width) || !r.Need(wl)) return fail(MGX_ERR_INVALID_ARGUMENT, "bad normalize_width");
+    std::memset(mi.normalize_width, 0, sizeof(mi.normalize_width));
+    std::memcpy(mi.normalize_width, data + r.at, wl);
+    r.at += wl;
+    mi.normalize_lower = r.U8() ? 1 : 0;
+  }
+  const uint64_t n_terms = r.U64();
+  if (!r.ok || n_terms > (r.n - r.at) / 17) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated header");
+  mi.n_terms = n_terms;
+  struct Term {
+    Key key;
+    std::vector<uint32_t> docs;
+  };
+  std::vector<Term> terms;
+  terms.reserve(n_terms);
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (uint64_t t = 0; t < n_terms; ++t) {
+    const uint32_t tl = r.U32();
+    if (!r.Need(tl)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated term");
+    if (tl == 0 || tl > 15) return fail(MGX_ERR_NOT_IMPLEMENTED, "a term longer than 15 bytes (n-gram keys are at most 15)");
+    Term term;
+    term.key = MakeKey(data + r.at, tl);
+    r.at += tl;
+    const uint64_t ps = r.U64();
+    if (!r.Need(ps) || ps < 5) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated posting list");
+    Reader pr{data + r.at, ps};
+    r.at += ps;
+    const uint8_t strategy = pr.U8();
+    const uint32_t size = pr.U32();
+    if (strategy == 0) {
+      if (size > (pr.n - pr.at) / 4) return fail(MGX_ERR_INVALID_ARGUMENT, "delta list longer than its bytes");
+      term.docs.reserve(size);
+      uint32_t prev = 0;
+      for (uint32_t i = 0; i < size; ++i) {  // PostingList::DecodeDelta, posting_list.cpp:954-971
+        const uint32_t v = pr.U32();
+        prev = i ? prev + v : v;
+        if (i && v == 0) return fail(MGX_ERR_INVALID_ARGUMENT, "delta list is not strictly ascending");
+        term.docs.push_back(prev);
+      }
+    } else if (strategy == 1) {
+      if (size > pr.n - pr.at) return fail(MGX_ERR_INVALID_ARGUMENT, "roaring bitmap longer than its bytes");
+      if (!DecodeRoaring(pr.p + pr.at, size, &term.docs)) return fail(MGX_ERR_INVALID_ARGUMENT, "malformed roaring bitmap");
+    } else {
+      return fail(MGX_ERR_INVALID_ARGUMENT, "unknown posting strategy");
+    }
+    if (!term.docs.empty()) {
+      lo = std::min(lo, term.docs.front());
+      hi = std::max(hi, term.docs.back());
+    }
+    terms.push_back(std::move(term));
+  }
+  if (!r.ok) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated");
+  std::sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) { return a.key < b.key; });
+  for (size_t i = 1; i < terms.size(); ++i)
+    if (terms[i].key == terms[i - 1].key) return fail(MGX_ERR_INVALID_ARGUMENT, "a term appears twice");
+  auto cols = std::make_unique<Columns>();
+  cols->params = mgx_build_params{sizeof(mgx_build_params), MGX_ABI_VERSION, mi.ngram_size, mi.kanji_ngram_size,
+                                  mi.cross_boundary_ngrams, 0};
+  if (n_docs == 0) {  // the range the dump's doc ids span
+    first_doc_id = lo == 0xFFFFFFFFu ? 1u : lo;
+    n_docs = lo == 0xFFFFFFFFu ? 0 : static_cast<uint64_t>(hi) - lo + 1;
+  } else if (lo != 0xFFFFFFFFu && (lo < first_doc_id || static_cast<uint64_t>(hi) - first_doc_id >= n_docs)) {
+    return fail(MGX_ERR_OUT_OF_RANGE, "a doc id lies outside the given range");
+  }
+  cols->first_doc_id = first_doc_id;
+  cols->n_docs = n_docs;
+  cols->key_off.push_back(0);
+  cols->offsets.push_back(0);
+  for (const Term& t : terms) {
+    cols->sorted_keys.push_back(t.key);
+    const size_t nb = static_cast<size_t>(t.key & 0xFF);
+    for (size_t i = 0; i < nb; ++i) cols->key_bytes.push_back(static_cast<uint8_t>(t.key >> (8 * (15 - i))));
+    cols->key_off.push_back(static_cast<uint32_t>(cols->key_bytes.size()));
+    cols->docids.insert(cols->docids.end(), t.docs.begin(), t.docs.end());
+    cols->offsets.push_back(cols->docids.size());
+  }
+  if (info) *info = mi;
+  *out = cols.release();
+  return MGX_OK;
+}
 
 }  // namespace mgx

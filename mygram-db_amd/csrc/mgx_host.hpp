@@ -11,6 +11,8 @@ namespace mgx {
 struct Columns;
 int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const uint64_t* text_off,
                  uint32_t first_doc_id, uint64_t n_docs, Columns** out, std::string* err);
+int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, uint64_t n_docs, Columns** out,
+                    mgx_mgix_info* info, std::string* err);
 void ColumnsView(const Columns* c, mgx_columns_view* v);
 bool ColumnsLookup(const Columns* c, const uint8_t* gram, size_t len, uint32_t* id);
 void DestroyColumns(Columns* c);

@@ -171,6 +171,27 @@ class Columns:
         h = C.c_void_p()
         check(L.mgx_columns_build(C.byref(bp), corpus.text_bytes.ctypes.data, corpus.text_off.ctypes.data,
                                   first_doc_id, corpus.n_docs, C.byref(h)))
+        self._adopt(h)
+
+    @classmethod
+    def from_mgix(cls, data, first_doc_id=0, n_docs=0):
+        """The reference's index dump (MGIX v1..v4, Index::SaveToStream) -> columns: doc ids only (tf / doc_len stay
+        empty — BM25 needs the texts). n_docs=0: the doc range is the span of the ids in the dump."""
+        L = load()
+        raw = bytes(data)
+        h, info = C.c_void_p(), _capi.MgixInfo()
+        check(L.mgx_columns_from_mgix(raw, len(raw), first_doc_id, n_docs, C.byref(h), C.byref(info)))
+        self = cls.__new__(cls)
+        self.ngram_size, self.kanji_ngram_size = int(info.ngram_size), int(info.kanji_ngram_size)
+        self.cross_boundary = bool(info.cross_boundary_ngrams)
+        self.mgix = {"version": int(info.version), "normalize_nfkc": bool(info.normalize_nfkc),
+                     "normalize_width": info.normalize_width.decode(), "normalize_lower": bool(info.normalize_lower),
+                     "n_terms": int(info.n_terms)}
+        self._adopt(h)
+        return self
+
+    def _adopt(self, h):
+        L = load()
         self._h = h
         v = _capi.ColumnsView()
         check(L.mgx_columns_view_get(h, C.byref(v)))
@@ -443,6 +464,24 @@ class Index:
         # df source: posting sizes of the WHOLE table (a shard passes the global sizes so idf is identical everywhere)
         self._global_sizes = global_posting_sizes
         self._global_dict = None  # sharded tables: {gram bytes: table-wide posting size} over every shard's dictionary
+
+    @classmethod
+    def from_mgix(cls, data, device=0, dense_threshold=0.0, first_doc_id=0, n_docs=0):
+        """Index::LoadFromData (src/index/index_serialization.cpp:260-420): an index over the postings of a reference
+        dump, configured by the dump's own header. It holds doc ids only, so it answers everything but SORT _score."""
+        self = cls.__new__(cls)
+        cols = Columns.from_mgix(data, first_doc_id, n_docs)
+        self.ngram_size, self.kanji_ngram_size, self.cross_boundary = cols.ngram_size, cols.kanji_ngram_size, cols.cross_boundary
+        self.normalize_nfkc, self.normalize_width = cols.mgix["normalize_nfkc"], cols.mgix["normalize_width"]
+        self.normalize_lower = cols.mgix["normalize_lower"]
+        self.columns = cols
+        self.device_index = DeviceIndex(cols, device, dense_threshold, with_scoring=False)
+        self.corpus = None
+        self._text_attached = False
+        self.total_docs, self.avg_doc_length = 0, 0.0
+        self._global_sizes = None
+        self._global_dict = None
+        return self
 
     # ---- dictionary -------------------------------------------------------------------------------------------
     def posting_size(self, gram):

@@ -1,6 +1,8 @@
 """-m gpu parity tests: the HIP path (through the C ABI of libmygram_gpu.so) against the CPU oracle and the
 reference's own known-answer vectors. Integer results are compared bit-exactly; BM25 scores bit-exactly too
 (the required bar is 1e-5 relative)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -568,3 +570,33 @@ def test_many_operands_and_many_scored_terms(pair60k, monkeypatch):
     pair60k.check(qs)
     monkeypatch.setenv("MGX_FAST_PATH", "1")   # the 4-term query on and_score_kernel<4>
     pair60k.check(qs[-3:])
+
+
+def test_index_from_reference_dump_answers_like_the_postings():
+    """N2: an index created from an MGIX dump (tests/golden/mgix_v4.bin: delta lists + every Roaring container kind)
+    answers AND / OR / NOT and docid pages exactly like plain set algebra over the same posting lists."""
+    import json
+    root = os.path.dirname(os.path.abspath(__file__))
+    exp = json.load(open(os.path.join(root, "golden", "mgix_expected.json"), encoding="utf-8"))
+    idx = mg.Index.from_mgix(open(os.path.join(root, "golden", "mgix_v4.bin"), "rb").read())
+    c = idx.columns
+    sets = {}
+    for t in exp["files"]["mgix_v4.bin"]["terms"]:
+        gid = c.lookup(t)
+        sets[t] = set(c.docids[int(c.offsets[gid]):int(c.offsets[gid + 1])].tolist())
+    di = idx.device_index
+    cases = [(["ab", "bc"], []), (["ab", "cd", "qr"], []), (["cd", "ef"], []), (["ab"], ["cd"]), (["bc", "qr"], ["ab"]),
+             (["de"], []), (["zz", "ab"], [])]
+    qs = [mg.engine.Query(a, n, limit=50) for a, n in cases] + [mg.engine.Query(a, n, limit=50, descending=False) for a, n in cases]
+    got = idx.search_batch(qs)
+    for q, g in zip(qs, got):
+        want = set.intersection(*[sets[t] for t in q.terms])
+        for t in q.not_terms:
+            want -= sets[t]
+        want = sorted(want, reverse=q.descending)
+        assert g.total == len(want) and g.docs.tolist() == want[:50], (q.terms, q.not_terms, q.descending)
+    union = mg.ops.search_or(di, [c.lookup("de"), c.lookup("zz"), c.lookup("bc")]) if hasattr(mg, "ops") else None
+    if union is not None:
+        assert union.tolist() == sorted(sets["de"] | sets["zz"] | sets["bc"])
+    with pytest.raises(mg._capi.MgxError):  # no tf / doc_len in a dump: SORT _score is refused, not guessed
+        idx.search_batch([mg.engine.Query(["ab", "bc"], sort_score=True, limit=10)])

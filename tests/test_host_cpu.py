@@ -228,3 +228,57 @@ def test_index_normalizes_query_terms_like_the_reference():
     assert S.normalize_text("ﾗｲﾌﾞ ＡＢＣ") == "ライブ abc"
     assert S.normalize_text("ＡＢＣ", False, "keep", False) == "ＡＢＣ"
     assert S.normalize_text("ÀÉ Σ", True, "keep", True) == "àé σ"
+
+
+# ---- MGIX (the reference's index dump) --------------------------------------------------------------------------------
+
+def _mgix_expected():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "mgix_expected.json"), encoding="utf-8"))
+
+
+@pytest.mark.parametrize("name", ["mgix_v4.bin", "mgix_v3.bin", "mgix_v2.bin", "mgix_v1.bin"])
+def test_mgix_dump_to_columns(name):
+    """mgx_columns_from_mgix over the committed dumps (tests/golden/make_mgix.py): header fields of every format
+    version, delta lists, Roaring array / bitset / run containers, both cookies, with and without the offset header."""
+    exp = _mgix_expected()
+    f = exp["files"][name]
+    data = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+    assert len(data) == f["bytes"]
+    cols = mg.Columns.from_mgix(data)
+    assert cols.mgix["version"] == f["version"] and cols.ngram_size == f["ngram_size"]
+    assert cols.kanji_ngram_size == f["kanji_ngram_size"] and cols.cross_boundary == f["cross_boundary"]
+    assert cols.mgix["normalize_width"] == f["normalize_width"] and cols.mgix["n_terms"] == len(f["terms"])
+    assert cols.n_grams == len(f["terms"])
+    keys = [cols.gram(g) for g in range(cols.n_grams)]
+    assert keys == sorted(t.encode("utf-8") for t in f["terms"])  # the dictionary is sorted bytewise, whatever the file order
+    lo, hi = 1 << 32, 0
+    for t in f["terms"]:
+        e = exp["terms"][t]
+        gid = cols.lookup(t)
+        ids = cols.docids[int(cols.offsets[gid]):int(cols.offsets[gid + 1])]
+        assert len(ids) == e["count"] and int(ids[0]) == e["first"] and int(ids[-1]) == e["last"], t
+        assert int(ids.astype(np.uint64).sum()) == e["sum"] and int(np.bitwise_xor.reduce(ids)) == e["xor"], t
+        assert np.all(np.diff(ids.astype(np.int64)) > 0), t
+        lo, hi = min(lo, e["first"]), max(hi, e["last"])
+    assert cols.first_doc_id == lo and cols.n_docs == hi - lo + 1  # the span of the dump's ids
+    assert len(cols.tf) == 0 and len(cols.doc_len) == 0            # a dump carries doc ids only
+
+
+def test_mgix_dump_rejects_damage():
+    data = bytearray(open(os.path.join(ROOT, "tests", "golden", "mgix_v4.bin"), "rb").read())
+    bad = bytearray(data)
+    bad[len(bad) // 2] ^= 0x40  # a flipped bit anywhere fails the CRC32 trailer
+    for blob, what in [(bytes(bad), "CRC32"), (bytes(data[:-9]), "CRC32"), (b"MGIY" + bytes(data[4:]), "magic"),
+                       (bytes(data[:12]), "magic")]:
+        with pytest.raises(mg._capi.MgxError) as e:
+            mg.Columns.from_mgix(blob)
+        assert what in str(e.value), (what, str(e.value))
+    v9 = bytearray(data)
+    v9[4] = 9
+    with pytest.raises(mg._capi.MgxError) as e:
+        mg.Columns.from_mgix(bytes(v9))
+    assert e.value.code == 4
+    with pytest.raises(mg._capi.MgxError) as e:  # a caller's range that does not hold the dump's ids
+        mg.Columns.from_mgix(bytes(data), first_doc_id=1, n_docs=1000)
+    assert e.value.code == 3
