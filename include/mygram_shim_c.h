@@ -61,6 +61,20 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
 int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_docs, uint32_t* docs, double* scores,
               double* timing_ms);
 
+/* search_pipeline::MicroBatcher: the thread-safe front end. mgxs_batcher_search may be called from any number of threads at
+ * once and blocks until the query's batch has run; queries are gathered into batches of at most `max_batch`, a batch
+ * closing when full or when its first query has waited `max_delay_us`. docs / scores have room for
+ * `limit` entries. */
+typedef struct mgxs_batcher mgxs_batcher;
+int mgxs_batcher_create(mgxs_table* table, uint32_t max_batch, uint32_t max_delay_us, int depth, int planner_threads,
+                        mgxs_batcher** out);
+void mgxs_batcher_destroy(mgxs_batcher* b);
+int mgxs_batcher_search(mgxs_batcher* b, uint32_t n_terms, const char* const* terms, uint32_t limit, uint32_t offset,
+                        int sort_by_score, int descending, uint64_t* total, uint32_t* n_docs, uint32_t* docs,
+                        double* scores /* may be NULL */);
+int mgxs_batcher_stats(mgxs_batcher* b, uint64_t* batches, uint64_t* queries, uint64_t* closed_full,
+                       uint64_t* closed_by_delay);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
            "mgxs_table_set_normalization", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
-           "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait"]
+           "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait",
+           "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
 
@@ -42,6 +43,11 @@ def load():
     L.mgxs_executor_destroy.restype = None
     L.mgxs_submit.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, C.POINTER(u64)]
     L.mgxs_wait.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
+    L.mgxs_batcher_destroy.argtypes = [vp]
+    L.mgxs_batcher_destroy.restype = None
+    L.mgxs_batcher_search.argtypes = [vp, u32, vp, u32, u32, i32, i32, C.POINTER(u64), C.POINTER(u32), vp, vp]
+    L.mgxs_batcher_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     _lib = L
     return L
 
@@ -149,3 +155,36 @@ class Executor:
         _check(load().mgxs_wait(self._h, ticket, totals.ctypes.data, n_docs.ctypes.data, docs.ctypes.data,
                                 scores.ctypes.data, timing.ctypes.data))
         return out
+
+
+class Batcher:
+    """search_pipeline::MicroBatcher: search() is thread-safe and blocking (ctypes drops the GIL while it waits), queries
+    from many threads share device batches."""
+
+    def __init__(self, table, max_batch=1024, max_delay_us=200, depth=2, planner_threads=4):
+        self._table = table
+        h = C.c_void_p()
+        _check(load().mgxs_batcher_create(table._h, max_batch, max_delay_us, depth, planner_threads, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            load().mgxs_batcher_destroy(self._h)
+            self._h = None
+
+    def search(self, terms, limit=10, offset=0, sort_by_score=True, descending=True):
+        """-> (total, docs u32[n], scores f64[n])"""
+        raw = [t.encode("utf-8") if isinstance(t, str) else bytes(t) for t in terms]
+        arr = (C.c_char_p * max(len(raw), 1))(*raw)
+        total, n = C.c_uint64(), C.c_uint32()
+        docs = np.zeros(max(limit, 1), dtype=np.uint32)
+        scores = np.zeros(max(limit, 1), dtype=np.float64)
+        _check(load().mgxs_batcher_search(self._h, len(raw), C.cast(arr, C.c_void_p), limit, offset, int(sort_by_score),
+                                          int(descending), C.byref(total), C.byref(n), docs.ctypes.data,
+                                          scores.ctypes.data))
+        return int(total.value), docs[: n.value].copy(), scores[: n.value].copy()
+
+    def stats(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load().mgxs_batcher_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"batches": a.value, "queries": b.value, "closed_full": c.value, "closed_by_delay": d.value}

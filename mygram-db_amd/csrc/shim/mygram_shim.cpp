@@ -1034,5 +1034,137 @@ Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, T
   return out;
 }
 
+// ---- MicroBatcher --------------------------------------------------------------------------------------------------
+
+struct MicroBatcher::Impl {
+  using clock = std::chrono::steady_clock;
+  struct Waiter {  // one blocked Search() call
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    Expected<BatchResult, Error> result{MakeUnexpected(MakeError(ErrorCode::kInternalError, "unanswered"))};
+  };
+  struct InFlight {
+    uint64_t ticket = 0;
+    std::vector<Waiter*> waiters;
+    Error submit_error{ErrorCode::kSuccess, ""};
+  };
+  Options opt;
+  BatchExecutor executor;
+  std::mutex mu;  // the forming batch, the in-flight queue, stats
+  std::condition_variable cv_pending, cv_inflight, cv_room;
+  std::vector<BatchQuery> pending;
+  std::vector<Waiter*> pending_waiters;
+  clock::time_point first_arrival;
+  std::deque<InFlight> inflight;
+  Stats stats;
+  bool stop = false;
+  std::thread former, completer;
+
+  Impl(const index::Index& index, Options o) : opt(o), executor(index, o.executor) {}
+
+  static void Answer(Waiter* w, Expected<BatchResult, Error>&& r) {
+    std::lock_guard<std::mutex> lock(w->mu);
+    w->result = std::move(r);
+    w->done = true;
+    w->cv.notify_one();
+  }
+
+  void Form() {
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+      cv_pending.wait(lock, [&] { return stop || !pending.empty(); });
+      if (pending.empty()) return;  // (stop, and nothing left to answer)
+      // the batch closes when it is full or when its first query has waited max_delay
+      const auto deadline = first_arrival + opt.max_delay;
+      const bool full = cv_pending.wait_until(lock, deadline, [&] { return stop || pending.size() >= opt.max_batch; });
+      // no more batches in flight than the executor has slots
+      cv_room.wait(lock, [&] { return inflight.size() < static_cast<size_t>(std::max(1, opt.executor.depth)); });
+      InFlight f;
+      std::vector<BatchQuery> batch;
+      const size_t take = std::min(pending.size(), opt.max_batch);
+      batch.assign(std::make_move_iterator(pending.begin()), std::make_move_iterator(pending.begin() + take));
+      f.waiters.assign(pending_waiters.begin(), pending_waiters.begin() + take);
+      pending.erase(pending.begin(), pending.begin() + take);
+      pending_waiters.erase(pending_waiters.begin(), pending_waiters.begin() + take);
+      if (!pending.empty()) first_arrival = clock::now();  // (what did not fit starts the next batch now)
+      ++stats.batches;
+      stats.queries += take;
+      ++(full && take == opt.max_batch ? stats.closed_full : stats.closed_by_delay);
+      lock.unlock();
+      auto t = executor.Submit(std::move(batch));
+      lock.lock();
+      if (t) f.ticket = *t; else f.submit_error = t.error();
+      inflight.push_back(std::move(f));
+      cv_inflight.notify_one();
+    }
+  }
+
+  void Complete() {
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+      cv_inflight.wait(lock, [&] { return !inflight.empty() || (stop && pending.empty() && former_done); });
+      if (inflight.empty()) return;
+      InFlight f = std::move(inflight.front());
+      lock.unlock();
+      if (f.ticket == 0) {
+        for (Waiter* w : f.waiters) Answer(w, MakeUnexpected(f.submit_error));
+      } else {
+        auto r = executor.Wait(f.ticket);
+        if (!r) {
+          for (Waiter* w : f.waiters) Answer(w, MakeUnexpected(r.error()));
+        } else {
+          for (size_t i = 0; i < f.waiters.size(); ++i) Answer(f.waiters[i], std::move((*r)[i]));
+        }
+      }
+      lock.lock();
+      inflight.pop_front();  // (the slot is free again only now: Wait has returned)
+      cv_room.notify_one();
+    }
+  }
+  bool former_done = false;
+};
+
+MicroBatcher::MicroBatcher(const index::Index& index, Options options) : impl_(std::make_unique<Impl>(index, options)) {
+  impl_->former = std::thread([this] {
+    impl_->Form();
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    impl_->former_done = true;
+    impl_->cv_inflight.notify_all();
+  });
+  impl_->completer = std::thread([this] { impl_->Complete(); });
+}
+
+MicroBatcher::~MicroBatcher() {
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    impl_->stop = true;
+  }
+  impl_->cv_pending.notify_all();
+  impl_->cv_inflight.notify_all();
+  impl_->former.join();
+  impl_->completer.join();
+}
+
+Expected<BatchResult, Error> MicroBatcher::Search(BatchQuery query) {
+  Impl::Waiter w;
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    if (impl_->stop) return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "MicroBatcher is shutting down"));
+    if (impl_->pending.empty()) impl_->first_arrival = Impl::clock::now();
+    impl_->pending.push_back(std::move(query));
+    impl_->pending_waiters.push_back(&w);
+    if (impl_->pending.size() == 1 || impl_->pending.size() >= impl_->opt.max_batch) impl_->cv_pending.notify_all();
+  }
+  std::unique_lock<std::mutex> lock(w.mu);
+  w.cv.wait(lock, [&] { return w.done; });
+  return std::move(w.result);
+}
+
+MicroBatcher::Stats MicroBatcher::GetStats() const {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  return impl_->stats;
+}
+
 }  // namespace search_pipeline
 }  // namespace mygramdb

@@ -22,6 +22,7 @@
 //     mygram::utils::NormalizeTextUsesIcu() says which.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -285,7 +286,8 @@ mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> ExecuteB
 // batches go to the device in ticket order, each on its object's own stream. Wait returns a ticket's results. The host
 // therefore prepares up to `depth` batches while the device runs others: throughput is bounded by the slower of the
 // two, not by their sum, and the host side scales with its threads.
-// One submitting / waiting thread at a time (a micro-batching front end owns it).
+// Submit and Wait may run on two different threads (one submitter, one waiter: MicroBatcher below); neither is
+// re-entrant.
 class BatchExecutor {
  public:
   struct Options {
@@ -310,6 +312,36 @@ class BatchExecutor {
   mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(const std::vector<BatchQuery>& queries);
   mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(std::vector<BatchQuery>&& queries);  // (no copy)
   mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> Wait(uint64_t ticket, Timing* timing = nullptr);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+
+// The front end a server puts between its connection threads and the executor: the reference runs one
+// query per request thread (ExecuteFullPipeline per connection); the device wants them a thousand at a time. Search()
+// is thread-safe and blocking: queries from any number of threads are gathered into one batch — closed when it holds
+// `max_batch` queries or when its first query has waited `max_delay` — submitted to a BatchExecutor and answered when
+// their batch is fetched. Two threads run inside: one forms and submits batches, one waits for tickets in order and
+// hands the results out, so a batch is being formed, others are being planned / run, and one is being collected at the
+// same time.
+class MicroBatcher {
+ public:
+  struct Options {
+    size_t max_batch = 1024;
+    std::chrono::microseconds max_delay{200};
+    BatchExecutor::Options executor;
+  };
+  struct Stats {
+    uint64_t batches = 0, queries = 0;  // mean batch size = queries / batches
+    uint64_t closed_full = 0, closed_by_delay = 0;
+  };
+  MicroBatcher(const index::Index& index, Options options);
+  ~MicroBatcher();  // answers what is queued, then stops
+  MicroBatcher(const MicroBatcher&) = delete;
+  MicroBatcher& operator=(const MicroBatcher&) = delete;
+  [[nodiscard]] mygram::utils::Expected<BatchResult, mygram::utils::Error> Search(BatchQuery query);
+  [[nodiscard]] Stats GetStats() const;
 
  private:
   struct Impl;

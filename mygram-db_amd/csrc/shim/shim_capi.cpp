@@ -1,5 +1,7 @@
 // shim_capi.cpp — extern "C" face of the C++17 shim (include/mygram_shim_c.h): what bench.py and the tests bind with
 // ctypes to drive search_pipeline::BatchExecutor, i.e. to plan, compile, run and fetch fresh batches entirely in C++.
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -11,6 +13,7 @@
 using mygramdb::index::Index;
 using mygramdb::search_pipeline::BatchExecutor;
 using mygramdb::search_pipeline::BatchQuery;
+using mygramdb::search_pipeline::MicroBatcher;
 
 struct mgxs_table {
   std::unique_ptr<Index> index;
@@ -19,6 +22,10 @@ struct mgxs_executor {
   std::unique_ptr<BatchExecutor> ex;
   std::vector<BatchQuery> queries;  // re-used between submits
   uint32_t limit = 0;
+};
+
+struct mgxs_batcher {
+  std::unique_ptr<MicroBatcher> mb;
 };
 
 namespace {
@@ -168,6 +175,65 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
   }
+}
+
+int mgxs_batcher_create(mgxs_table* table, uint32_t max_batch, uint32_t max_delay_us, int depth, int planner_threads,
+                        mgxs_batcher** out) {
+  if (out) *out = nullptr;
+  if (!table || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_batcher_create: null argument");
+  try {
+    MicroBatcher::Options o;
+    o.max_batch = max_batch ? max_batch : 1024;
+    o.max_delay = std::chrono::microseconds(max_delay_us);
+    o.executor.depth = depth > 0 ? depth : 2;
+    o.executor.planner_threads = planner_threads > 0 ? planner_threads : 1;
+    auto b = std::make_unique<mgxs_batcher>();
+    b->mb = std::make_unique<MicroBatcher>(*table->index, o);
+    *out = b.release();
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+void mgxs_batcher_destroy(mgxs_batcher* b) { delete b; }
+
+int mgxs_batcher_search(mgxs_batcher* b, uint32_t n_terms, const char* const* terms, uint32_t limit, uint32_t offset,
+                        int sort_by_score, int descending, uint64_t* total, uint32_t* n_docs, uint32_t* docs,
+                        double* scores) {
+  if (!b || !total || !n_docs || (n_terms && !terms) || (limit && !docs))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_batcher_search: null argument");
+  try {
+    BatchQuery q;
+    for (uint32_t t = 0; t < n_terms; ++t) q.terms.emplace_back(terms[t]);
+    q.sort_by_score = sort_by_score != 0;
+    q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
+    q.limit = limit;
+    q.offset = offset;
+    auto r = b->mb->Search(std::move(q));
+    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
+    *total = r->total;
+    const size_t n = std::min<size_t>(r->results.size(), limit);
+    *n_docs = static_cast<uint32_t>(n);
+    for (size_t k = 0; k < n; ++k) {
+      docs[k] = r->results[k];
+      if (scores) scores[k] = k < r->scores.size() ? r->scores[k] : 0.0;
+    }
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_batcher_stats(mgxs_batcher* b, uint64_t* batches, uint64_t* queries, uint64_t* closed_full,
+                       uint64_t* closed_by_delay) {
+  if (!b) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_batcher_stats: null argument");
+  const MicroBatcher::Stats st = b->mb->GetStats();
+  if (batches) *batches = st.batches;
+  if (queries) *queries = st.queries;
+  if (closed_full) *closed_full = st.closed_full;
+  if (closed_by_delay) *closed_by_delay = st.closed_by_delay;
+  return MGX_OK;
 }
 
 }  // extern "C"

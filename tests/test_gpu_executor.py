@@ -70,3 +70,30 @@ def test_executor_refuses_more_batches_than_slots(pair):
         ex.submit(qb)
     ex.wait(t)
     ex.wait(ex.submit(qb))
+
+
+def test_micro_batcher_many_client_threads(pair):
+    """search_pipeline::MicroBatcher: 48 client threads, one blocking Search() each at a time; their queries share device
+    batches (closed by size or by delay) and every answer equals the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mygram_db_amd import _shim_capi as S
+    mb = S.Batcher(S.Table(pair.dev), max_batch=64, max_delay_us=300, depth=2, planner_threads=3)
+    term_lists = [t for b in _batches(pair, 4, 96, seed=21) for t in b]
+
+    def one(terms):
+        return mb.search(terms, limit=10)
+
+    with ThreadPoolExecutor(max_workers=48) as pool:
+        got = list(pool.map(one, term_lists))
+    n, avg = pair.N, pair.avgdl
+    for terms, (total, docs, scores) in zip(term_lists, got):
+        t, d, s = O.search_scored(pair.oidx, pair.ostore, [x.lower() for x in terms], n, avg, limit=10)
+        assert total == t and docs.tolist() == d.tolist(), terms
+        assert np.array_equal(scores, s), terms
+    st = mb.stats()
+    assert st["queries"] == len(term_lists)
+    assert st["batches"] < len(term_lists) / 4  # (48 clients in flight: batches hold many queries, not one)
+    # a lone query is answered after max_delay, not held for a full batch
+    total, docs, scores = mb.search(term_lists[0], limit=10)
+    assert total == got[0][0] and docs.tolist() == got[0][1].tolist()
+    assert mb.stats()["closed_by_delay"] >= 1
