@@ -1593,7 +1593,15 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;
       list_begin[i] = n_lists;
-      for (uint32_t t = 0; t < n_tiles; t += tiles) {
+      uint32_t t0 = 0;
+      // Fast path: a short "seed" item first (two tiles per wave), launched ahead of everything else (below): it scores
+      // its tiles unpruned and publishes the query's first k-th best score, so the long items start pruning at once.
+      static const uint32_t kSeedTiles = std::getenv("MGX_SEED_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_SEED_TILES"))) : 16u;
+      if (fast && kSeedTiles && n_tiles > 4 * kSeedTiles) {
+        items.push_back(DevItem{i, 0, kSeedTiles, n_lists++});
+        t0 = kSeedTiles;
+      }
+      for (uint32_t t = t0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), n_lists++};  // candidate lists stay grouped by query
         items.push_back(it);
       }
@@ -1650,10 +1658,15 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   }
   const uint32_t n_lists_all = n_lists;
   std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore];
-  for (const DevItem& it : items) {
-    const uint8_t w = on_wave[it.query];
-    if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
-    else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: the fast path's seed items (a query's first list), then the rest
+    for (const DevItem& it : items) {
+      const uint8_t w = on_wave[it.query];
+      const bool seed = w == 3 && it.list == list_begin[it.query] && it.tile_begin == 0 &&
+                        list_begin[it.query + 1] - list_begin[it.query] > 1 && it.n_tiles <= 16;
+      if (seed != (pass == 0)) continue;
+      if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
+      else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
+    }
   }
   if (!fastq.empty()) MGX_HIP(Upload(g.d_fast_queries, fastq.data(), fastq.size()));
   for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));

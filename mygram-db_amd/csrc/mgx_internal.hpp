@@ -144,7 +144,10 @@ struct DevIndex {
 constexpr int kFastMaxOps = 8;
 constexpr int kFastMaxScore = 5;
 constexpr uint32_t kFastPoolTf = 14;  // contribution-table pool of the wave kernel: rows tf 0..14
-constexpr int kFastBlock = 512;       // 8 autonomous waves per workgroup on one query
+#ifndef MGX_FWAVES
+#define MGX_FWAVES 8
+#endif
+constexpr int kFastBlock = 64 * MGX_FWAVES;  // autonomous waves per workgroup, all on one query
 constexpr int kFastWaves = kFastBlock / 64;
 
 enum FastOpKind : uint32_t { kFastOr = 0, kFastAnd = 1, kFastAndNot = 2 };  // (LOAD = OR into the empty accumulator)

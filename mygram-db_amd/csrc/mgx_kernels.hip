@@ -1867,7 +1867,10 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
 
 // One kernel per number of scored terms (own register allocation each); a batch launches the ones it has items for.
 template <int T>
-__global__ __launch_bounds__(kFastBlock, 6) void bitmap_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
+#ifndef MGX_FOCC
+#define MGX_FOCC 6
+#endif
+__global__ __launch_bounds__(kFastBlock, MGX_FOCC) void bitmap_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
   const DevItem it = bt.items[blockIdx.x];
   bitmap_score_body<T>(ix, bt, plan, bt.fast_queries + it.query, it);
 }

@@ -127,22 +127,40 @@ def cfg4(mg, args):
     return idx, qs, {"workload": "cfg4 share: %d docs, bigram, batch %d x 3-term AND + BM25 top-100" % (args.docs, args.batch)}
 
 
+def score5(mg, args):
+    """The 4-5-scored-term path: 10M docs, 1024 x 5-term AND (bigrams sampled by df) + BM25 top-10
+    (bitmap_score_kernel<5>; five tf gathers + five block-max rows per surviving match)."""
+    corpus = mg.Corpus.synthetic(args.docs, seed=42)
+    idx = mg.Index(corpus=corpus, ngram_size=2)
+    c = idx.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    cand = [g for g in range(c.n_grams) if b" " not in c.gram(g)]
+    w = sizes[cand].astype(np.float64)
+    w /= w.sum()
+    rng = np.random.default_rng(42)
+    qs = []
+    for i in range(args.batch):
+        pick = rng.choice(len(cand), size=5 if i % 2 else 4, replace=False, p=w)
+        qs.append(mg.engine.Query([c.gram(cand[i]).decode() for i in pick], sort_score=True, limit=10))
+    return idx, qs, {"workload": "%d docs, bigram, batch %d x 4- and 5-term AND + BM25 top-10" % (args.docs, args.batch)}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["cfg3", "cfg4", "cfg5", "cfg2doc", "text2"])
+    ap.add_argument("config", choices=["cfg3", "cfg4", "cfg5", "cfg2doc", "text2", "score5"])
     ap.add_argument("--docs", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000, "text2": 2_000_000, "cfg4": 12_500_000}[args.config]
-    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024, "text2": 1024, "cfg4": 1024}[args.config]
+    args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000, "text2": 2_000_000, "cfg4": 12_500_000, "score5": 10_000_000}[args.config]
+    args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024, "text2": 1024, "cfg4": 1024, "score5": 1024}[args.config]
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("needs an MI355X")
     mg = entry.load_package()
     t0 = time.perf_counter()
-    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5, "cfg2doc": cfg2doc, "text2": text2, "cfg4": cfg4}[args.config](mg, args)
+    idx, qs, cfg = {"cfg3": cfg3, "cfg5": cfg5, "cfg2doc": cfg2doc, "text2": text2, "cfg4": cfg4, "score5": score5}[args.config](mg, args)
     batch = idx.prepare(qs)
     setup = time.perf_counter() - t0
     for _ in range(args.warmup):
