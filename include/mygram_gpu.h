@@ -188,7 +188,11 @@ typedef struct mgx_term {
    * normalized term bytes. In a MGX_SORT_SCORE query tf is then BM25Scorer::CountTermOccurrences over the doc text
    * (bm25_scorer.cpp:27-45) and df is counted per execute as PopulateTermDocumentFrequency does
    * (search_pipeline.cpp:542-565: docs of the gram AND whose text contains the term); idf = ComputeIDF(total_docs,
-   * df) is evaluated by the library and the `idf` field is ignored. Needs mgx_index_attach_text. NULL otherwise. */
+   * df) is evaluated by the library and the `idf` field is ignored. Needs mgx_index_attach_text. NULL otherwise.
+   * n_grams == 0 with a text: a term shorter than one n-gram — its doc set is every doc whose stored text contains it
+   * (query::SearchNormalizedSubstring, src/query/substring_search.h:24-42, reached from SearchTermDocuments,
+   * search_pipeline.cpp:438-446), found by a text scan on the device; as a scored term its df is 0, as the reference's
+   * is (PopulateTermDocumentFrequency returns before counting, search_pipeline.cpp:546-549). */
   const uint8_t* text;
   uint32_t text_len;
 } mgx_term;

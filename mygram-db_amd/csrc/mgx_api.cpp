@@ -955,7 +955,29 @@ struct Compiler {
   }
   // acc = the term's doc set: AND of its grams, or "at least threshold of them"
   // (SearchTermDocuments, search_pipeline.cpp:438-446; fuzzy terms :1697-1702)
+  uint32_t RangeLeaf(uint64_t lo, uint64_t hi) {  // doc slots [lo, hi) of this shard
+    DevLeaf lf{};
+    lf.score_slot = kNoSlot;
+    lf.row = kNoRow;
+    lf.kind = kLeafRange;
+    lf.a = static_cast<uint32_t>(lo);
+    lf.b = static_cast<uint32_t>(hi);
+    q->leaves.push_back(lf);
+    return static_cast<uint32_t>(q->leaves.size() - 1);
+  }
+  // kOpVerifyText argument for ONE more pattern of the query: its index among the query's patterns | count 1 << 12
+  uint32_t OnePattern(const mgx_term& t) {
+    q->verify_patterns.emplace_back(reinterpret_cast<const char*>(t.text), t.text_len);
+    return static_cast<uint32_t>(q->verify_patterns.size() - 1) | (1u << 12);
+  }
   void LoadTerm(const mgx_term& t) {
+    if (t.n_grams == 0) {
+      // a term shorter than one n-gram: query::SearchNormalizedSubstring (src/query/substring_search.h:24-42) — every
+      // doc whose stored text contains it (SearchTermDocuments, search_pipeline.cpp:438-446)
+      Emit(kOpLoad, RangeLeaf(0, idx->dev.n_docs));
+      Emit(kOpVerifyText, OnePattern(t));
+      return;
+    }
     if (t.threshold != 0 && t.threshold < t.n_grams) {
       Emit(kOpThreshBegin);
       for (uint32_t i = 0; i < t.n_grams; ++i) Emit(kOpThreshAdd, GramLeaf(t.gram_ids[i]));
@@ -968,7 +990,14 @@ struct Compiler {
 };
 
 static int ValidateTerm(const mgx_index* idx, const mgx_term& t, const char* what) {
-  if (t.n_grams == 0 || !t.gram_ids) return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": term without grams");
+  if (t.n_grams == 0) {  // substring term: needs its text and the docs' texts
+    if (!t.text || t.text_len == 0 || t.text_len > 4096)
+      return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": a term without grams needs its normalized text (1..4096 bytes)");
+    if (!idx->dev.text)
+      return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": a term without grams (substring search) needs mgx_index_attach_text");
+    return MGX_OK;
+  }
+  if (!t.gram_ids) return Fail(MGX_ERR_INVALID_ARGUMENT, std::string(what) + ": term without grams");
   if (t.n_grams > 127) return Fail(MGX_ERR_OUT_OF_RANGE, std::string(what) + ": more than 127 grams in a term");
   for (uint32_t i = 0; i < t.n_grams; ++i)
     if (t.gram_ids[i] >= idx->n_grams && t.gram_ids[i] != MGX_GRAM_ABSENT)
@@ -994,12 +1023,12 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   {
     double dens = 1.0;
     for (uint32_t i = 0; i < in.n_terms; ++i) {
-      uint64_t mn = ~0ull;
+      uint64_t mn = in.terms[i].n_grams ? ~0ull : idx->dev.n_docs;  // (a substring term filters, it does not narrow the estimate)
       for (uint32_t g = 0; g < in.terms[i].n_grams; ++g) {
         const uint32_t id = in.terms[i].gram_ids[g];
         mn = std::min<uint64_t>(mn, id == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[id + 1] - idx->h_offsets[id]);
       }
-      dens *= static_cast<double>(mn) / static_cast<double>(idx->dev.n_docs);
+      dens *= static_cast<double>(mn) / static_cast<double>(std::max<uint32_t>(idx->dev.n_docs, 1));
     }
     out->est_density = dens;
   }
@@ -1084,7 +1113,9 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     c.Emit(kOpCount, 0);
     for (uint32_t i = 1; i < in.n_terms; ++i) {
       const mgx_term& t = in.terms[i];
-      if (t.threshold != 0 && t.threshold < t.n_grams) {
+      if (t.n_grams == 0) {  // substring term: the accumulator's docs whose text contains it (search_pipeline.cpp:817-826)
+        c.Emit(kOpVerifyText, c.OnePattern(t));
+      } else if (t.threshold != 0 && t.threshold < t.n_grams) {
         c.Emit(kOpPush);
         c.LoadTerm(t);
         c.Emit(kOpPopAnd);
@@ -1119,13 +1150,15 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   c.Emit(kOpCount, 3);
   if (in.exact_text) {
     if (!idx->dev.text) return Fail(MGX_ERR_INVALID_ARGUMENT, "exact_text without mgx_index_attach_text");
+    const uint32_t first_exact = static_cast<uint32_t>(out->verify_patterns.size());
     for (uint32_t i = 0; i < in.n_terms; ++i) {
       const mgx_term& t = in.terms[i];
       if (!t.text || t.text_len == 0 || t.text_len > 4096)
         return Fail(MGX_ERR_INVALID_ARGUMENT, "exact_text: every positive term needs its normalized text (1..4096 bytes)");
       out->verify_patterns.emplace_back(reinterpret_cast<const char*>(t.text), t.text_len);
     }
-    c.Emit(kOpVerifyText);  // (not a flat op: the query runs on the general workgroup kernel)
+    // (not a flat op: the query runs on the general workgroup kernel) argument: first pattern | count << 12
+    c.Emit(kOpVerifyText, first_exact | (in.n_terms << 12));
   }
 
   out->limit = in.limit;
@@ -1819,8 +1852,15 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         Compiler c{idx, &ds, 0};
         double dens = 1.0;
         uint64_t mn = ~0ull;
-        c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
-        for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
+        if (tt.grams.empty()) {
+          // a term shorter than one n-gram: PopulateTermDocumentFrequency returns before counting (search_pipeline.cpp:
+          // 546-549), so its df is 0 — the df query runs over the empty doc range
+          c.Emit(kOpLoad, c.RangeLeaf(0, 0));
+          mn = 0;
+        } else {
+          c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
+          for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
+        }
         for (uint32_t gid : tt.grams)
           mn = std::min<uint64_t>(mn, gid == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[gid + 1] - idx->h_offsets[gid]);
         dens = static_cast<double>(mn) / static_cast<double>(std::max<uint32_t>(idx->dev.n_docs, 1));

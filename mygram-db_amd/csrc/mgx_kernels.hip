@@ -791,8 +791,8 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
             break;
           }
           case kOpVerifyText: {
-            // exact-text post-filter: a doc stays only if its text contains every pattern (rare query shapes only —
-            // mixed-script terms under hybrid n-grams, or verify_text asked for by the caller; one doc at a time)
+            // text filter: a doc stays only if its text contains every pattern of the instruction (rare query shapes only —
+            // the exact-text post-filter of mixed-script terms / verify_text, a term shorter than one n-gram; one doc at a time)
             uint64_t bits = acc;
             while (bits) {
               const uint32_t bpos = __builtin_ctzll(bits);
@@ -800,8 +800,9 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
               const uint32_t slot = tile * kTileDocs + tid * 64 + bpos;
               const uint64_t t0 = ix.text_off[slot], t1 = ix.text_off[slot + 1];
               bool all = true;
-              for (uint32_t v = 0; all && v < q.vt_count; ++v) {
-                const DevTextTerm vt = bt.verify_terms[q.vt_begin + v];
+              const uint32_t vfirst = arg & 0xFFFu, vcount = arg >> 12;  // the patterns this instruction checks
+              for (uint32_t v = 0; all && v < vcount; ++v) {
+                const DevTextTerm vt = bt.verify_terms[q.vt_begin + vfirst + v];
                 all = text_count_occurrences(ix.text, t0, t1, text_pattern(bt.patterns + vt.pat_off, vt.pat_len), true) != 0;
               }
               if (!all) acc &= ~(1ull << bpos);

@@ -613,8 +613,12 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
     for (const auto& t : q.not_terms) {
       TermInfo ti = MakeInfo(index, im, t);
       if (ti.n_grams == 0) {
-        Fail(p, ErrorCode::kNotImplemented, "NOT term shorter than one n-gram (host path)");
-        return false;
+        // shorter than one n-gram: the docs whose text contains it (SearchTermDocuments :438-446); "" matches nothing
+        if (ti.normalized.empty()) continue;
+        p->texts.push_back(ti.normalized);
+        p->not_terms.push_back(mgx_term{nullptr, 0, 0, 0.0, reinterpret_cast<const uint8_t*>(p->texts.back().data()),
+                                        static_cast<uint32_t>(p->texts.back().size())});
+        continue;
       }
       if (ti.estimated_size == 0) continue;  // an unknown gram: the NOT term matches nothing
       p->ids.push_back(ti.gram_ids);
@@ -721,10 +725,6 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       p->empty_term_detected = true;
       return;
     }
-  for (const auto& ti : tis)
-    if (ti.n_grams == 0)
-      return Fail(p, ErrorCode::kNotImplemented,
-                  "a term shorter than one n-gram needs SearchNormalizedSubstring (host path)");
   p->ids.reserve(q.terms.size() + q.not_terms.size());
   // exact-text post-filter: the caller's verify_text decision, or a mixed-script term with an uncovered fragment
   // (search_pipeline.cpp:856-866)
@@ -736,7 +736,8 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
     p->ids.push_back(ti.gram_ids);
     mgx_term mt{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0};
     if (q.sort_by_score && ti.is_gram) mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
-    if (exact || (q.sort_by_score && !ti.is_gram)) {
+    // (a term shorter than one n-gram has no grams at all: the device scans the texts for it, SearchNormalizedSubstring)
+    if (exact || ti.n_grams == 0 || (q.sort_by_score && !ti.is_gram)) {
       p->texts.push_back(ti.normalized);
       mt.text = reinterpret_cast<const uint8_t*>(p->texts.back().data());
       mt.text_len = static_cast<uint32_t>(p->texts.back().size());

@@ -752,9 +752,9 @@ class Index:
                 shell.empty_term_detected = True  # Execute :804-810
                 shells.append(shell)
                 continue
-            if q.expr is None and any(not t.grams for t in tis):
-                raise _capi.MgxError(4, "a term shorter than one n-gram needs the substring fallback "
-                                        "(SearchNormalizedSubstring), which is not on the device path")
+            if any(not t.grams for t in tis) and (q.expr is not None or q.fuzzy):
+                raise _capi.MgxError(4, "a term shorter than one n-gram inside an expression / FUZZY query "
+                                        "(SearchNormalizedSubstring) is not on the device path")
             exact = q.expr is None and (q.verify_text or any(
                 has_uncovered_hybrid_fragment(t.normalized, self.ngram_size, self.kanji_ngram_size, self.cross_boundary)
                 for t in tis))
@@ -766,7 +766,10 @@ class Index:
                 keep.append(ids)
                 thr = t.threshold if (q.fuzzy and t.threshold < len(ids)) else 0
                 idf, text_ptr, text_len = 0.0, None, 0
-                if exact:
+                if exact or not t.grams:
+                    # (no grams at all: a term shorter than one n-gram — the device scans the texts for it,
+                    # query::SearchNormalizedSubstring, src/query/substring_search.h:24-42)
+                    self.ensure_text()
                     tb = np.frombuffer(t.normalized.encode("utf-8"), dtype=np.uint8).copy()
                     keep.append(tb)
                     text_ptr, text_len = tb.ctypes.data, len(tb)
@@ -778,20 +781,27 @@ class Index:
                         text_ptr, text_len = tb.ctypes.data, len(tb)
                     else:
                         idf = compute_idf(self.total_docs, t.df)
-                cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, idf, text_ptr, text_len)
+                cterms[j] = _capi.Term(ids.ctypes.data if len(ids) else None, len(ids), thr, idf, text_ptr, text_len)
             nts = []
             for nt in q.not_terms:
                 ti = self.term_info(nt)
                 if not ti.grams:
-                    raise _capi.MgxError(4, "NOT term shorter than one n-gram is not on the device path")
-                if ti.estimated_size == 0:
+                    if not ti.normalized:
+                        continue  # "" is contained in nothing (SearchNormalizedSubstring returns {})
+                    self.ensure_text()
+                elif ti.estimated_size == 0:
                     continue  # an unknown gram: the NOT term matches nothing
                 nts.append(ti)
             cnots = (_capi.Term * max(len(nts), 1))()
             for j, t in enumerate(nts):
                 ids = np.asarray(t.gram_ids, dtype=np.uint32)
                 keep.append(ids)
-                cnots[j] = _capi.Term(ids.ctypes.data, len(ids), 0, 0.0, None, 0)
+                text_ptr, text_len = None, 0
+                if not t.grams:  # substring NOT term
+                    tb = np.frombuffer(t.normalized.encode("utf-8"), dtype=np.uint8).copy()
+                    keep.append(tb)
+                    text_ptr, text_len = tb.ctypes.data, len(tb)
+                cnots[j] = _capi.Term(ids.ctypes.data if len(ids) else None, len(ids), 0, 0.0, text_ptr, text_len)
             cf = (_capi.Filter * max(len(q.filters), 1))()
             for j, (bid, negate) in enumerate(q.filters):
                 cf[j] = _capi.Filter(bid, int(negate))

@@ -187,6 +187,32 @@ int main() {
       std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
     }
   }
+  {  // terms shorter than one n-gram: SearchTermDocuments' substring branch (search_pipeline.cpp:438-446,
+     // src/query/substring_search.h:24-42) — positive, later, and NOT terms
+    using namespace mygramdb::search_pipeline;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "a cat");
+    index.AddDocument(2, "x ray");
+    index.AddDocument(3, "taxi x");
+    index.AddDocument(4, "dog");
+    std::vector<BatchQuery> qs(4);
+    qs[0].terms = {"x"};                 // the only term: every doc whose text contains "x"
+    qs[1].terms = {"ta", "x"};           // a later term filters the candidates
+    qs[2].terms = {"a"};
+    qs[2].not_terms = {"x"};             // a NOT term excludes by substring
+    qs[3].terms = {"Q"};                 // normalised to "q": contained in nothing
+    for (auto& q : qs) q.order = SortOrder::ASC;
+    auto r = ExecuteBatch(index, qs);
+    EXPECT(r.has_value());
+    if (r) {
+      EXPECT((*r)[0].results == (V{2, 3}) && (*r)[0].total_candidates == 2);
+      EXPECT((*r)[1].results == (V{3}) && (*r)[1].total_candidates == 1 && (*r)[1].after_intersection == 1);
+      EXPECT((*r)[2].results == (V{1}) && (*r)[2].after_intersection == 3 && (*r)[2].after_not == 1);
+      EXPECT((*r)[3].results.empty() && (*r)[3].total == 0);
+    } else {
+      std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
+    }
+  }
   {  // the same worked example on the default bigram index: "alpha" spans four n-grams, so tf comes from the text
      // (CountTermOccurrences, bm25_scorer.cpp:27-45) — identical scores
     Index index(2);

@@ -600,3 +600,31 @@ def test_index_from_reference_dump_answers_like_the_postings():
         assert union.tolist() == sorted(sets["de"] | sets["zz"] | sets["bc"])
     with pytest.raises(mg._capi.MgxError):  # no tf / doc_len in a dump: SORT _score is refused, not guessed
         idx.search_batch([mg.engine.Query(["ab", "bc"], sort_score=True, limit=10)])
+
+
+def test_terms_shorter_than_one_ngram_take_the_substring_fallback():
+    """SearchTermDocuments' other branch (search_pipeline.cpp:438-446): a term that yields no n-gram — one ASCII letter
+    on a bigram index, one kana on a hybrid index — matches by substring over the stored texts
+    (query::SearchNormalizedSubstring); positive terms (alone, first, later), NOT terms, scored (df 0), docid pages."""
+    rng = np.random.default_rng(12)
+    words = ["alpha", "beta", "gamma", "delta", "omega", "zeta", "x", "q", "か", "き", "東京", "京都", "大阪"]
+    texts = [" ".join(str(w) for w in rng.choice(words, size=int(rng.integers(2, 9)))) for _ in range(6000)]
+    p = Pair(docs=list(enumerate(texts, start=1)), ngram=2, kanji=1)
+    Q = mg.engine.Query
+    qs = [Q(["x"], limit=30), Q(["q", "alpha"], limit=30), Q(["alpha", "x"], limit=30), Q(["か"], limit=30),
+          Q(["東京", "か"], limit=30), Q(["beta"], ["x"], limit=30), Q(["x"], ["q"], limit=30), Q(["x", "q", "か"], limit=30),
+          Q(["alpha", "x"], sort_score=True, limit=15), Q(["x"], sort_score=True, limit=15),
+          Q(["か", "東京"], sort_score=True, limit=15), Q(["x"], limit=25, descending=False), Q(["z"], limit=5),
+          Q(["alpha"], ["w"], limit=30)]
+    got = p.dev.search_batch(qs)
+    hits = 0
+    for q, g in zip(qs, got):
+        total, page, scores, r = p.oracle_query(q)
+        assert g.total == total and g.docs.tolist() == page.tolist(), (q.terms, q.not_terms)
+        if q.sort_score:
+            assert np.array_equal(g.scores, scores), q.terms
+        elif not r["empty_term_detected"]:
+            for k in ("total_candidates", "after_intersection", "after_not", "after_filters"):
+                assert getattr(g, k) == r[k], (q.terms, k)
+        hits += total > 0
+    assert hits >= 11
