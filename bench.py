@@ -256,7 +256,7 @@ def main():
         ex = S.Executor(shim_table, depth=depth, planner_threads=planners, comm=comm)
         qbs = [S.QueryBatch(tb) for tb in term_batches]
         outs = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
-                 np.zeros((batch_size, 10), np.float64), np.zeros(4, np.float64)) for _ in range(depth)]
+                 np.zeros((batch_size, 10), np.float64), np.zeros(5, np.float64)) for _ in range(depth)]
 
         def run_steps(k, record):
             """k steps with `depth` batches in flight: submit step i+depth-1, then wait for step i."""
@@ -325,7 +325,7 @@ def main():
 
     if rank == 0:
         qps = batch_size * args.steps / elapsed
-        tm = np.asarray(timings) if timings else np.zeros((1, 4))
+        tm = np.asarray(timings) if timings else np.zeros((1, 5))
         line = {
             "metric": "queries/sec + p50 latency, 10M-doc bigram index, batch=1024 3-term AND",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -32,6 +32,9 @@ int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double a
 /* Index(normalize_nfkc, normalize_width, normalize_lower) of src/index/index.h:58-60 for an adopted table: how query
  * terms are normalised before n-gram generation (defaults: nfkc, "keep", lower). */
 int mgxs_table_set_normalization(mgxs_table* table, int nfkc, const char* width, int lower);
+/* Doc-range shards: grams (NUL-terminated UTF-8) of the table that this shard holds no posting for, with their table-wide
+ * posting sizes — the planner then resolves them to MGX_GRAM_ABSENT instead of ending the query on this rank only. */
+int mgxs_table_set_absent_grams(mgxs_table* table, uint64_t n, const char* const* grams, const uint64_t* sizes);
 void mgxs_table_destroy(mgxs_table* table);
 
 /* mygram::utils::NormalizeText (src/utils/string_utils.cpp:295-380): NFKC -> width ("narrow" | "wide" | "keep") ->
@@ -57,7 +60,8 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
                 uint32_t limit, uint32_t offset, int sort_by_score, int descending, uint64_t* ticket);
 /* Results of a submitted batch: per query its total (results.size() before pagination) and page length, pages packed
  * `limit` entries apart in docs / scores (scores may be NULL). timing_ms (may be NULL) receives
- * {plan, compile, enqueue, wait} host milliseconds of this batch. */
+ * {plan, compile, enqueue, wait} host milliseconds of this batch and, fifth, how many of its queries ran on the device
+ * (the rest were resolved by the planner: an unknown gram): 5 doubles. */
 int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_docs, uint32_t* docs, double* scores,
               double* timing_ms);
 

@@ -9,7 +9,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
-           "mgxs_table_set_normalization", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
+           "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
@@ -32,6 +32,7 @@ def load():
     L.mgxs_table_adopt.argtypes = [vp, vp, i32, i32, i32, C.POINTER(vp)]
     L.mgxs_table_set_global_stats.argtypes = [vp, u64, f64, vp, u64]
     L.mgxs_table_set_normalization.argtypes = [vp, i32, C.c_char_p, i32]
+    L.mgxs_table_set_absent_grams.argtypes = [vp, u64, vp, vp]
     L.mgxs_normalize_uses_icu.restype = i32
     L.mgxs_normalize_text.argtypes = [C.c_char_p, C.c_size_t, i32, C.c_char_p, i32, vp, C.c_size_t,
                                       C.POINTER(C.c_size_t)]
@@ -110,6 +111,14 @@ class Table:
             sizes = np.ascontiguousarray(index._global_sizes, dtype=np.uint64)
             _check(load().mgxs_table_set_global_stats(self._h, int(index.total_docs), float(index.avg_doc_length),
                                                       sizes.ctypes.data, len(sizes)))
+        if getattr(index, "_global_dict", None) is not None:
+            # grams only other shards hold: known to the planner with their table-wide size (MGX_GRAM_ABSENT on this shard)
+            absent = [(k, v) for k, v in index._global_dict.items() if v > 0 and index.columns.lookup(k) is None
+                      and b"\x00" not in k]
+            if absent:
+                keys = (C.c_char_p * len(absent))(*[k for k, _ in absent])
+                vals = np.asarray([v for _, v in absent], dtype=np.uint64)
+                _check(load().mgxs_table_set_absent_grams(self._h, len(absent), C.cast(keys, C.c_void_p), vals.ctypes.data))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -146,11 +155,11 @@ class Executor:
         return t.value
 
     def wait(self, ticket, out=None):
-        """-> (totals u64[n], n_docs u32[n], docs u32[n, limit], scores f64[n, limit], timing_ms f64[4])."""
+        """-> (totals u64[n], n_docs u32[n], docs u32[n, limit], scores f64[n, limit], timing_ms f64[5]: plan, compile, enqueue, wait ms + device query count)."""
         n, limit = self._shape.pop(ticket)
         if out is None:
             out = (np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n, max(limit, 1)), np.uint32),
-                   np.zeros((n, max(limit, 1)), np.float64), np.zeros(4, np.float64))
+                   np.zeros((n, max(limit, 1)), np.float64), np.zeros(5, np.float64))
         totals, n_docs, docs, scores, timing = out
         _check(load().mgxs_wait(self._h, ticket, totals.ctypes.data, n_docs.ctypes.data, docs.ctypes.data,
                                 scores.ctypes.data, timing.ctypes.data))

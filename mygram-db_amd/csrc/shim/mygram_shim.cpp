@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 
 namespace mygramdb {
 
@@ -163,6 +164,24 @@ struct Index::Impl {
   uint64_t Size(uint32_t id) const {
     return global_sizes.empty() ? view.offsets[id + 1] - view.offsets[id] : global_sizes[id];
   }
+  // The planner's view of a gram: its id for the device and its table-wide size. A gram some OTHER shard holds resolves to
+  // MGX_GRAM_ABSENT (an empty operand here) with that table-wide size, so every rank plans the same batch.
+  bool Resolve(std::string_view gram, uint32_t* id, uint64_t* size) const {
+    if (Lookup(gram, id)) {
+      *size = Size(*id);
+      return true;
+    }
+    if (!absent_grams.empty()) {
+      const auto it = absent_grams.find(std::string(gram));
+      if (it != absent_grams.end()) {
+        *id = MGX_GRAM_ABSENT;
+        *size = it->second;
+        return true;
+      }
+    }
+    return false;
+  }
+  std::unordered_map<std::string, uint64_t> absent_grams;  // grams of the table this shard has no posting for -> size
 };
 
 Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, bool cross_boundary_ngrams,
@@ -272,6 +291,8 @@ uint64_t Index::PostingSize(std::string_view term) const {  // index.cpp:580-584
   return impl_->Lookup(term, &id) ? impl_->Size(id) : 0;
 }
 uint64_t Index::EstimatePostingSize(std::string_view term) const { return PostingSize(term); }  // index.cpp:756-759
+
+void Index::SetAbsentGrams(std::unordered_map<std::string, uint64_t> grams) { impl_->absent_grams = std::move(grams); }
 
 std::string Index::SetGlobalStats(uint64_t total_docs, double avg_doc_length, std::vector<uint64_t> global_posting_sizes) {
   Finalize();
@@ -568,7 +589,8 @@ TermInfo MakeInfo(const index::Index& index, const index::Index::Impl* im, const
   uint64_t mn = UINT64_MAX;
   for (const auto& g : grams) {
     uint32_t id = 0;
-    const uint64_t ps = im->Lookup(g, &id) ? im->Size(id) : 0;
+    uint64_t ps = 0;
+    if (!im->Resolve(g, &id, &ps)) ps = 0;
     if (ps > 0) {
       mn = std::min(mn, ps);
       ti.gram_ids.push_back(id);
@@ -700,7 +722,8 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       std::vector<uint32_t> known;
       for (const auto& g : grams) {
         uint32_t id = 0;
-        if (im->Lookup(g, &id) && im->Size(id) > 0) known.push_back(id);
+        uint64_t ps = 0;
+        if (im->Resolve(g, &id, &ps) && ps > 0) known.push_back(id);
       }
       const bool empty = theta == grams.size() ? known.size() != grams.size() : known.size() < theta;
       if (empty || known.empty()) known.assign(1, MGX_GRAM_ABSENT);  // the empty doc set, as an operand
@@ -865,6 +888,7 @@ struct BatchExecutor::Impl {
       }
       if (p.on_device) slot->mq.push_back(p.q);
     }
+    slot->timing.device_queries = static_cast<uint32_t>(slot->mq.size());
     if (slot->mq.empty()) return;
     int rc;
     if (!slot->batch)

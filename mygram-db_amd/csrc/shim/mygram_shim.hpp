@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <string_view>
 #include <utility>
 #include <variant>
@@ -174,6 +175,10 @@ class Index {
   // Doc-range shards (one Index per GPU): the table-wide BM25Stats and every gram's table-wide posting size, by this
   // shard's gram ids — what idf must be computed from so that all ranks score identically. Returns "" or an error.
   std::string SetGlobalStats(uint64_t total_docs, double avg_doc_length, std::vector<uint64_t> global_posting_sizes);
+  // Doc-range shards: the grams of the TABLE this shard holds no posting for, with their table-wide sizes. The planner
+  // then treats them as known (MGX_GRAM_ABSENT: an empty operand on this shard), so every rank plans the same batch —
+  // without it a query with such a gram would end on this rank's host (empty_term_detected) and run on the others.
+  void SetAbsentGrams(std::unordered_map<std::string, uint64_t> grams);
 
   // internals shared with BM25Scorer / ResultSorter / search_pipeline
   struct Impl;
@@ -296,12 +301,12 @@ class BatchExecutor {
     // One rank of a table sharded by doc range: after every execute the shards' top-k are all-gathered
     // over this communicator (mgx_comm_create; RCCL) and merged, so Wait returns the table-wide page and total on
     // every rank. Every rank submits the same batches in the same order; the index carries the table-wide statistics
-    // (Index::SetGlobalStats), and every query gram is in every shard's dictionary (the planner resolves grams in the
-    // shard's own; mygram-db_amd/dist.py covers the general case with MGX_GRAM_ABSENT).
+    // (Index::SetGlobalStats, and Index::SetAbsentGrams for the grams only other shards hold).
     mgx_comm* comm = nullptr;
   };
   struct Timing {  // host milliseconds of one batch
     double plan_ms = 0, compile_ms = 0, enqueue_ms = 0, wait_ms = 0;
+    uint32_t device_queries = 0;  // queries of the batch that ran on the device (the rest were resolved by the planner)
   };
   BatchExecutor(const index::Index& index, Options options);
   explicit BatchExecutor(const index::Index& index) : BatchExecutor(index, Options{}) {}

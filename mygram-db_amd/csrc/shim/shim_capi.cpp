@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/mygram_shim_c.h"
@@ -95,6 +96,18 @@ int mgxs_normalize_text(const char* text, size_t len, int nfkc, const char* widt
   }
 }
 
+int mgxs_table_set_absent_grams(mgxs_table* table, uint64_t n, const char* const* grams, const uint64_t* sizes) {
+  if (!table || (n && (!grams || !sizes))) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_set_absent_grams: null argument");
+  try {
+    std::unordered_map<std::string, uint64_t> m;
+    for (uint64_t i = 0; i < n; ++i) m.emplace(grams[i], sizes[i]);
+    table->index->SetAbsentGrams(std::move(m));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 void mgxs_table_destroy(mgxs_table* table) { delete table; }
 
 int mgxs_executor_create_sharded(mgxs_table* table, int depth, int planner_threads, mgx_comm* comm, mgxs_executor** out) {
@@ -170,6 +183,7 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
       timing_ms[1] = tm.compile_ms;
       timing_ms[2] = tm.enqueue_ms;
       timing_ms[3] = tm.wait_ms;
+      timing_ms[4] = static_cast<double>(tm.device_queries);
     }
     return MGX_OK;
   } catch (const std::exception& e) {

@@ -153,6 +153,23 @@ def main():
                 assert g.total == total and g.docs.tolist() == docs.tolist() and np.array_equal(g.scores, scores), \
                     (rnd, q.terms)
             del fb
+        # the C++ planner (search_pipeline::BatchExecutor) on a shard: a gram only the OTHER shard holds must stay a device
+        # query (MGX_GRAM_ABSENT, Index::SetAbsentGrams) so that every rank's batch — and therefore its collectives — has
+        # the same shape; locally it simply matches nothing. (No communicator here: two ranks share one GPU, which RCCL
+        # refuses; what is checked is the planning every rank must agree on.)
+        from mygram_db_amd import _shim_capi as S
+        ex = S.Executor(S.Table(table.index), depth=1, planner_threads=2)
+        tl = [[g, common[0]] for g in one_sided[:6]] + [[common[0], common[1]], ["~#"]]
+        totals, n_docs, docs, scores, timing = ex.wait(ex.submit(S.QueryBatch(tl), limit=10))
+        counts = torch.tensor([int(timing[4])], dtype=torch.int64)
+        gathered = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gathered, counts)
+        assert all(int(x) == len(tl) - 1 for x in gathered), [int(x) for x in gathered]  # ("~#": unknown to the whole table)
+        tot = torch.from_numpy(totals.astype(np.int64).copy())
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)  # shards are disjoint doc ranges: local totals add up to the table's
+        for terms, t in zip(tl, tot.tolist()):
+            want = O.search_scored(oidx, ostore, terms, cols.bm25_doc_count, cols.avg_doc_length(), limit=10)[0]
+            assert t == want, (terms, t, want)
         # docid-ordered pages across the shards (the reference's default order): totals add up, pages merge by doc id
         pq = []
         for i in range(10):
