@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -390,15 +391,32 @@ std::vector<DocId> Index::SearchNot(const std::vector<DocId>& all_docs, const st
   std::sort(ids.begin(), ids.end());
   ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
   if (ids.empty()) return all_docs;
+  // std::set_difference (index.cpp:480-484) accepts a sorted all_docs WITH repeats: of m copies of a doc the union
+  // holds, m - 1 survive; of a doc it does not hold, all m. The device takes the distinct ids; repeats are put back here.
+  const bool repeats = std::adjacent_find(all_docs.begin(), all_docs.end()) != all_docs.end();
+  std::vector<DocId> distinct;
+  if (repeats) std::unique_copy(all_docs.begin(), all_docs.end(), std::back_inserter(distinct));
+  const std::vector<DocId>& in = repeats ? distinct : all_docs;
   uint32_t* out = nullptr;
   uint64_t n = 0;
-  if (mgx_not(impl_->dev, all_docs.data(), all_docs.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) !=
-      MGX_OK) {
+  if (mgx_not(impl_->dev, in.data(), in.size(), ids.data(), static_cast<uint32_t>(ids.size()), &out, &n) != MGX_OK) {
     impl_->last_error = mgx_last_error();
     SetDeviceError(impl_->last_error);
     return {};
   }
-  return Take(out, n);
+  std::vector<DocId> kept = Take(out, n);
+  if (!repeats) return kept;
+  std::vector<DocId> res;
+  size_t k = 0;
+  for (size_t i = 0; i < all_docs.size();) {
+    size_t j = i;
+    while (j < all_docs.size() && all_docs[j] == all_docs[i]) ++j;
+    while (k < kept.size() && kept[k] < all_docs[i]) ++k;
+    const bool survives = k < kept.size() && kept[k] == all_docs[i];
+    res.insert(res.end(), survives ? j - i : j - i - 1, all_docs[i]);
+    i = j;
+  }
+  return res;
 }
 
 std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& terms, size_t threshold) const {

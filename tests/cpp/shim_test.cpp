@@ -187,6 +187,14 @@ int main() {
       std::printf("ExecuteBatch error: %s\n", r.error().message().c_str());
     }
   }
+  {  // SearchNot over an all_docs with repeats: std::set_difference semantics (index.cpp:480-484)
+    Index index(1);
+    index.AddDocument(1, "ab");
+    index.AddDocument(2, "b");
+    index.AddDocument(3, "a");
+    EXPECT(index.SearchNot({1, 1, 2, 2, 3}, {"a"}) == (V{1, 2, 2}));  // one copy of doc 1 goes, doc 3 goes, doc 2 stays twice
+    EXPECT(mygramdb::index::LastDeviceError().empty());
+  }
   {  // terms shorter than one n-gram: SearchTermDocuments' substring branch (search_pipeline.cpp:438-446,
      // src/query/substring_search.h:24-42) — positive, later, and NOT terms
     using namespace mygramdb::search_pipeline;
