@@ -1464,11 +1464,19 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         if (f.blockmax) {
           f.bm_tile_stride = idx->n_bitmap_rows * 256u;
           f.bmf_tile_stride = idx->n_fine_rows * 1024u;
+          // integer form of the bound: unit = step * (largest idf / 255); W_i = ceil(idf_i / (largest idf / 255))
+          double idf_max = 0.0;
+          for (size_t t = 0; t < s.score.size(); ++t) idf_max = std::max(idf_max, s.score[t].idf);
+          const double wunit = idf_max > 0.0 ? idf_max * (1.0 + 0x1p-40) / 255.0 : 1.0;
+          f.bm_inv_unit = 1.0 / (wunit * step);
+          f.bm_wpack = f.bm_w4 = f.bm_cint = 0;
+          for (size_t t = 0; t < s.score.size(); ++t) {
+            const uint32_t w = static_cast<uint32_t>(std::min(255.0, std::ceil(s.score[t].idf / wunit)));
+            if (t < 4) f.bm_wpack |= w << (8 * t); else f.bm_w4 = w;
+          }
           for (size_t t = 0; t < s.score.size(); ++t) {
             const DevLeaf& lf = s.leaves[s.score[t].leaf];
             FastScore& fs = f.score[t];
-            // (weights rounded up: the fp32 bound must stay above the exact one)
-            fs.bm_weight = std::nextafter(static_cast<float>(s.score[t].idf * step) * (1.0f + 0x1p-20f), INFINITY);
             const uint32_t frow = f.blockmax_fine ? idx->h_fine_map[lf.b] : kNoRow;
             fs.bm_mode = frow != kNoRow ? 2u : 1u;
             fs.bm_off = frow != kNoRow ? frow * 1024u : lf.b * 256u;

@@ -160,17 +160,19 @@ struct FastScore {
   uint64_t nib;          // address of the term's tf-nibble row (DevIndex::tfnib + row * nib_row_stride)
   double idf;
   uint32_t gram, skip_row;  // exact tf lookup of a saturated nibble
-  // block-max bytes of the term (pruning): mode 0 none (its bound is inside DevFastQuery::ub_const), 1 one byte per
+  // block-max bytes of the term (pruning): mode 0 none (its bound is inside DevFastQuery::bm_cint), 1 one byte per
   // 64-doc word at blockmax + tile * bm_tile_stride + bm_off, 2 one byte per 16-doc quarter at blockmax_fine + ...
   uint32_t bm_mode, bm_off;
-  float bm_weight;       // idf * (value of one block-max unit), rounded up
-  uint32_t pad;
 };
 struct DevFastQuery {
   uint32_t n_ops, n_score, needed, cap;
   uint32_t descending, pad0;
-  float ub_const;        // pruning: the part of the score bound that does not depend on the block (terms without bytes)
-  uint32_t pad1;
+  uint32_t pad1, pad1b;
+  // pruning, integer form: a quarter's bound is bm_cint + sum_i W_i * q_i in units of 1 / bm_inv_unit (W_i = the term's
+  // idf rounded UP to 8 bits of the largest idf, q_i its block-max byte), evaluated with one v_dot4_u32_u8 per quarter
+  uint32_t bm_wpack, bm_w4;  // W_0..W_3 packed, W_4
+  uint32_t bm_cint, pad2;
+  double bm_inv_unit;        // theta * bm_inv_unit, rounded down, is the integer threshold
   double k1, b, one_minus_b, k1_plus_1, avgdl_clamped;
   const uint8_t* blockmax;       // null: score every match (SORT _score ASC, or pruning unavailable)
   const uint8_t* blockmax_fine;

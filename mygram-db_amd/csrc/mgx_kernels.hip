@@ -1466,8 +1466,9 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_lists_kernel(DevInde
 //     one byte bounding the gram's BM25 term factor over the docs of the block (build_blockmax_kernel). A lane reads
 //     the bytes of its 256 doc slots with its operands, sums idf-weighted bounds per quarter and drops the quarters
 //     whose bound is below the query's current k-th best score (its own list's, or any wave's of the query through the
-//     shared bound). The matches are still counted (total_results is exact); only survivors are enumerated, gathered
-//     and scored. On the benchmark batch about a fifth of the matches survive.
+//     shared bound) — in integers: idf weights rounded up to 8 bits, the terms' bytes transposed with v_perm_b32, one
+//     v_dot4_u32_u8 per quarter. The matches are still counted (total_results is exact); only survivors are enumerated,
+//     gathered and scored. On the benchmark batch about a fifth of the matches survive.
 //   * no per-query BM25 tables: a contribution is idf * (tf * (k1 + 1)) / (tf + K[dl]) with K[dl] = k1 * (1 - b + b *
 //     dl / avgdl) — a 2 KiB table of the BATCH (k1, b, avgdl are table constants), built on the host operation by
 //     operation like bm25_scorer.cpp:80-84 — and one correctly rounded fp64 division per (match, term) on the device:
@@ -1694,7 +1695,13 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
           if (o + 1 < n_ops) w1 = load_half(o + 1, tile, h);
           if (o + 2 < n_ops) w2 = load_half(o + 2, tile, h);
           if (h == 0 && o == 0 && bound != 0) {  // (the block-max loads are older than the operands': no extra wait)
-            const float theta = static_cast<float>(key_score(bound, true)) * (1.0f - 0x1p-20f);
+            // Integer form of the bound: a quarter survives iff sum_i W_i * q_i >= floor(theta * bm_inv_unit), W_i the
+            // idf weights rounded UP to 8 bits (the host), theta's conversion rounded DOWN: the integer bound stays above
+            // the exact one, which itself sits a whole quantisation step above any score. Per 64-doc word the terms'
+            // bytes are transposed (v_perm_b32) so that one v_dot4_u32_u8 per quarter does the weighted sum.
+            const uint32_t tint = static_cast<uint32_t>(
+                fmin(floor(key_score(bound, true) * fq->bm_inv_unit * (1.0 - 0x1p-30)), 4294967040.0));
+            const uint32_t wpack = fq->bm_wpack, w4 = fq->bm_w4, cint = fq->bm_cint;
 #pragma unroll
             for (int i = 0; i < T; ++i) {
               if (fq->score[i].bm_mode == 1u) {  // wave-uniform: a word's byte stands for its four quarters
@@ -1706,15 +1713,22 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
             uint32_t mk = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+              const uint32_t t0 = bmw[0][k], t1 = T > 1 ? bmw[T > 1 ? 1 : 0][k] : 0u, t2 = T > 2 ? bmw[T > 2 ? 2 : 0][k] : 0u,
+                             t3 = T > 3 ? bmw[T > 3 ? 3 : 0][k] : 0u;
+              // [t0.0 t1.0 t0.1 t1.1], [t0.2 t1.2 t0.3 t1.3] and the same of terms 2, 3
+              const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u), hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);
+              const uint32_t lo23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x05010400u) : 0u;
+              const uint32_t hi23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x07030602u) : 0u;
+              uint32_t qb[4];  // quarter j: the bytes of terms 0..3
+              qb[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+              qb[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+              qb[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+              qb[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                // fp32 with every rounding pushed outwards (weights up by 2^-20 on the host, the sum up by 2^-18, the
-                // threshold down by 2^-20); the exact bound itself sits a whole quantisation step above any score
-                float ub = fq->ub_const;
-#pragma unroll
-                for (int i = 0; i < T; ++i)
-                  ub += fq->score[i].bm_weight * static_cast<float>((bmw[i][k] >> (8 * j)) & 255u);
-                if (!(ub * (1.0f + 0x1p-18f) < theta)) mk |= 1u << (4 * k + j);
+                uint32_t ub = __builtin_amdgcn_udot4(qb[j], wpack, cint, false);
+                if (T > 4) ub += w4 * ((bmw[T > 4 ? 4 : 0][k] >> (8 * j)) & 255u);
+                if (ub >= tint) mk |= 1u << (4 * k + j);
               }
             }
             qmask = mk;
