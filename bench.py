@@ -183,7 +183,7 @@ def main():
     batch_size = int(os.environ.get("MGX_BENCH_BATCH", "1024"))
     cpu_seconds = float(os.environ.get("MGX_BENCH_CPU_SECONDS", "24"))
     dense = float(os.environ.get("MGX_BENCH_DENSE", "0"))
-    depth = int(os.environ.get("MGX_BENCH_DEPTH", "3"))
+    depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (3 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 4)
     planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (physical_cores()[0] - 1) // max(1, world)))
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
@@ -258,6 +258,8 @@ def main():
         outs = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
                  np.zeros((batch_size, 10), np.float64), np.zeros(5, np.float64)) for _ in range(depth)]
 
+        call_ms = [0.0, 0.0]  # time the driving thread spends inside submit / wait calls (sum over the timed steps)
+
         def run_steps(k, record):
             """k steps with `depth` batches in flight: submit step i+depth-1, then wait for step i."""
             pending = []
@@ -272,10 +274,14 @@ def main():
                     sub_t[nxt] = time.perf_counter()
                     pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10, sort_by_score=by_score)))
                     nxt += 1
+                    if record:
+                        call_ms[0] += 1e3 * (time.perf_counter() - sub_t[nxt - 1])
                 j, ticket = pending.pop(0)
+                w0 = time.perf_counter()
                 out = ex.wait(ticket, outs[j % depth])
                 if record:
                     lat.append(time.perf_counter() - sub_t[j])
+                    call_ms[1] += 1e3 * (time.perf_counter() - w0)
                     timings.append(out[4].copy())
 
         run_steps(args.warmup, False)
@@ -343,6 +349,8 @@ def main():
                 "prepare_ms": float(tm[:, 0].mean() + tm[:, 1].mean()), "plan_ms": float(tm[:, 0].mean()),
                 "compile_ms": float(tm[:, 1].mean()), "enqueue_ms": float(tm[:, 2].mean()),
                 "wait_ms": float(tm[:, 3].mean()),
+                "driver_submit_call_ms": (call_ms[0] / args.steps) if (not exchange or cxx_exchange) else None,
+                "driver_wait_call_ms": (call_ms[1] / args.steps) if (not exchange or cxx_exchange) else None,
                 "execute_ms": 1e3 * replay_elapsed / replay_steps,
                 "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
                 "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth},

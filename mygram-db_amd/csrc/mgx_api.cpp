@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <map>
 #include <cstdio>
 #include <cstdlib>
@@ -144,7 +145,26 @@ struct BatchResources {
   hipStream_t stream = nullptr;
   hipEvent_t done_ev = nullptr;
   bool copy_issued = false;
+  // mgx_batch_exchange: this rank's blob (docid pages only) and every rank's. They belong to the slot, not to one batch:
+  // a hipFree / hipMalloc per reset would synchronise the device once per step.
+  void* xchg[2] = {nullptr, nullptr};
+  size_t xchg_cap[2] = {0, 0};
+  hipError_t Exchange(int which, size_t bytes, void** out_ptr) {
+    if (xchg_cap[which] < bytes) {
+      if (xchg[which]) (void)hipFree(xchg[which]);
+      xchg[which] = nullptr;
+      xchg_cap[which] = 0;
+      const size_t cap = bytes + bytes / 4;
+      hipError_t e = DeviceMalloc(&xchg[which], cap);
+      if (e != hipSuccess) return e;
+      xchg_cap[which] = cap;
+    }
+    *out_ptr = xchg[which];
+    return hipSuccess;
+  }
   ~BatchResources() {
+    for (void* x : xchg)
+      if (x) (void)hipFree(x);
     if (stream) (void)hipStreamDestroy(stream);
     if (done_ev) (void)hipEventDestroy(done_ev);
     for (void* h : h_down)
@@ -1291,7 +1311,6 @@ struct mgx_batch {
   // by the merge kernel: [keys n*S u64 | totals n u64 | docs n*S u32 | counts n u32]  (S = top_stride)
   DevBuf d_export;
   size_t ex_off32 = 0, ex_bytes = 0;
-  DevBuf d_xchg_send, d_xchg_recv;  // mgx_batch_exchange: this rank's blob (docid pages only) and every rank's (owned: kept across resets)
   uint64_t* ex_keys() const { return d_export.as<uint64_t>(); }
   uint64_t* ex_totals(size_t n) const { return d_export.as<uint64_t>() + n * top_stride; }
   uint32_t* ex_docs() const { return reinterpret_cast<uint32_t*>(static_cast<char*>(d_export.p) + ex_off32); }
@@ -1820,6 +1839,95 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   return MGX_OK;
 }
 
+// CompileQuery over a whole batch. Queries are independent, so batches of a few hundred and more are cut into chunks for
+// a small process-wide helper pool (MGX_COMPILE_THREADS helpers, default 3, beside the calling thread): on a doc-range
+// shard the device finishes a batch in a fraction of a millisecond and the host's per-batch compile is what a rank's
+// throughput hangs on. One caller at a time uses the pool; a second concurrent caller compiles inline.
+struct CompilePool {
+  std::mutex mu, gate;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> helpers;
+  const mgx_index* idx = nullptr;
+  const mgx_query* queries = nullptr;
+  std::vector<QuerySpec>* specs = nullptr;
+  uint32_t next = 0, end = 0, pending = 0;
+  int rc = MGX_OK;
+  std::string error;
+  bool stop = false;
+  static constexpr uint32_t kChunk = 64;
+
+  void Run(std::unique_lock<std::mutex>& lock) {  // called with mu held; works until the queue is empty
+    while (next < end) {
+      const uint32_t a = next, b = std::min(end, a + kChunk);
+      next = b;
+      lock.unlock();
+      int local = MGX_OK;
+      std::string msg;
+      for (uint32_t i = a; i < b && local == MGX_OK; ++i) {
+        (*specs)[i].Clear();
+        local = CompileQuery(idx, queries[i], &(*specs)[i]);
+        if (local) msg = "query " + std::to_string(i) + ": " + g_last_error;
+      }
+      lock.lock();
+      if (local && rc == MGX_OK) {
+        rc = local;
+        error = msg;
+      }
+      pending -= b - a;
+    }
+  }
+  void Helper() {
+    std::unique_lock<std::mutex> lock(mu);
+    for (;;) {
+      cv_work.wait(lock, [&] { return stop || next < end; });
+      if (stop) return;
+      Run(lock);
+      if (pending == 0) cv_done.notify_all();
+    }
+  }
+  CompilePool() {
+    const int n = std::getenv("MGX_COMPILE_THREADS") ? atoi(std::getenv("MGX_COMPILE_THREADS")) : 3;
+    for (int i = 0; i < n; ++i) helpers.emplace_back([this] { Helper(); });
+  }
+  ~CompilePool() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : helpers) t.join();
+  }
+};
+
+static int CompileAll(const mgx_index* idx, const mgx_query* queries, uint32_t n, std::vector<QuerySpec>* specs) {
+  static CompilePool pool;
+  std::unique_lock<std::mutex> gate(pool.gate, std::try_to_lock);
+  if (n < 4 * CompilePool::kChunk || pool.helpers.empty() || !gate.owns_lock()) {
+    for (uint32_t i = 0; i < n; ++i) {
+      (*specs)[i].Clear();
+      const int rc = CompileQuery(idx, queries[i], &(*specs)[i]);
+      if (rc) {
+        SetError("query " + std::to_string(i) + ": " + g_last_error);
+        return rc;
+      }
+    }
+    return MGX_OK;
+  }
+  std::unique_lock<std::mutex> lock(pool.mu);
+  pool.idx = idx;
+  pool.queries = queries;
+  pool.specs = specs;
+  pool.next = 0;
+  pool.end = pool.pending = n;
+  pool.rc = MGX_OK;
+  pool.cv_work.notify_all();
+  pool.Run(lock);  // the caller compiles too
+  pool.cv_done.wait(lock, [&] { return pool.pending == 0; });
+  pool.end = 0;
+  if (pool.rc) SetError(pool.error);
+  return pool.rc;
+}
+
 // Compiles `specs` into batch object `b` (fresh, or just emptied by ResetBatch): every device array comes from the
 // batch's arenas, nothing is copied to the device here — the first execute ships the upload arena.
 static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& specs) {
@@ -2293,13 +2401,8 @@ int mgx_batch_prepare(mgx_index* idx, const mgx_query* queries, uint32_t n_queri
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_prepare: null argument");
   try {
     std::vector<mgx::QuerySpec> specs(n_queries);
-    for (uint32_t i = 0; i < n_queries; ++i) {
-      int rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
-      if (rc) {
-        mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
-        return rc;
-      }
-    }
+    const int rc = mgx::CompileAll(idx, queries, n_queries, &specs);
+    if (rc) return rc;
     return mgx::PrepareFromSpecs(idx, std::move(specs), out);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_prepare: ") + e.what());
@@ -2315,11 +2418,7 @@ int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queri
     int rc = MGX_OK;
     static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t i = 0; i < n_queries && rc == MGX_OK; ++i) {
-      specs[i].Clear();
-      rc = mgx::CompileQuery(idx, queries[i], &specs[i]);
-      if (rc) mgx::SetError("query " + std::to_string(i) + ": " + mgx::g_last_error);
-    }
+    rc = mgx::CompileAll(idx, queries, n_queries, &specs);
     const auto t1 = std::chrono::steady_clock::now();
     MGX_HIP(hipSetDevice(idx->device));
     mgx::ResetBatch(batch);
@@ -2610,7 +2709,7 @@ int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
   int rc = mgx::BatchStream(batch, hip_stream, &s);
   if (rc) return rc;
   MGX_HIP(hipSetDevice(batch->idx->device));
-  mgx::ResourceScope own(nullptr);  // exchange buffers are the batch object's own (kept across mgx_batch_reset)
+  if (!batch->res) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange: not a prepared batch object");
   void* blob = nullptr;
   uint64_t bytes = 0, off32 = 0;
   rc = mgx_batch_export_buffer(batch, &blob, &bytes, &off32);
@@ -2622,18 +2721,18 @@ int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
     const uint64_t elems = static_cast<uint64_t>(batch->n_queries) * stride + batch->n_queries;
     off32 = elems * 8;
     bytes = (elems * 12 + 7) / 8 * 8;
-    if (batch->d_xchg_send.bytes < bytes) MGX_HIP(batch->d_xchg_send.Alloc(bytes));
-    blob = batch->d_xchg_send.p;
+    MGX_HIP(batch->res->Exchange(0, bytes, &blob));
     rc = mgx_batch_export_topk(batch, static_cast<uint64_t*>(blob),
                                reinterpret_cast<uint32_t*>(static_cast<char*>(blob) + off32), &stride, s);
     if (rc) return rc;
   }
   const uint64_t need = bytes * static_cast<uint64_t>(comm->world);
-  if (batch->d_xchg_recv.bytes < need) MGX_HIP(batch->d_xchg_recv.Alloc(need));
+  void* recv = nullptr;
+  MGX_HIP(batch->res->Exchange(1, need, &recv));
   // one all-gather moves every rank's keys, totals, doc ids and counts (both blobs sit in one buffer per rank)
-  const int nrc = mgx::LoadRccl().AllGather(blob, batch->d_xchg_recv.p, bytes, mgx::kRcclUint8, comm->comm, s);
+  const int nrc = mgx::LoadRccl().AllGather(blob, recv, bytes, mgx::kRcclUint8, comm->comm, s);
   if (nrc != 0) return mgx::RcclFail("ncclAllGather", nrc);
-  char* g = static_cast<char*>(batch->d_xchg_recv.p);
+  char* g = static_cast<char*>(recv);
   return mgx_batch_merge_shards(batch, static_cast<uint32_t>(comm->world), reinterpret_cast<const uint64_t*>(g),
                                 bytes / 8, reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, s);
 }

@@ -595,6 +595,20 @@ struct PlannedQuery {
   std::vector<mgx_filter> filters;
   std::vector<mgx_expr_token> expr;
   std::deque<std::string> texts;  // normalized text-level terms (addresses stay valid as the deque grows)
+  // Back to the freshly constructed state WITHOUT giving memory back: an executor slot re-plans a thousand of these
+  // per batch, and constructing one allocates (the deque's map and first node alone are two mallocs).
+  void Reset() {
+    q = mgx_query{};
+    on_device = empty_term_detected = false;
+    error = ErrorCode::kSuccess;
+    error_message.clear();
+    terms.clear();
+    not_terms.clear();
+    ids.clear();
+    filters.clear();
+    expr.clear();
+    texts.clear();
+  }
 };
 
 TermInfo MakeInfo(const index::Index& index, const index::Index::Impl* im, const std::string& raw) {
@@ -860,7 +874,7 @@ struct BatchExecutor::Impl {
   Options opt;
   uint64_t total_docs = 0;
   double avgdl = 0.0;
-  enum State { kFree, kPlanning, kPlanned, kCompiled, kEnqueued, kFailed };
+  enum State { kFree, kFilling, kPlanning, kPlanned, kCompiled, kEnqueued, kFailed };
   struct Slot {
     mgx_batch* batch = nullptr;
     std::vector<BatchQuery> queries;
@@ -891,7 +905,7 @@ struct BatchExecutor::Impl {
 
   Slot* ByTicket(uint64_t ticket) {
     for (auto& s : slots)
-      if (s.state != kFree && s.ticket == ticket) return &s;
+      if (s.state != kFree && s.state != kFilling && s.ticket == ticket) return &s;
     return nullptr;
   }
 
@@ -946,8 +960,10 @@ struct BatchExecutor::Impl {
       const Chunk c = chunks.front();
       chunks.pop_front();
       lock.unlock();
-      for (size_t i = c.begin; i < c.end; ++i)
+      for (size_t i = c.begin; i < c.end; ++i) {
+        c.slot->plans[i].Reset();  // (the slot's plans are re-used from batch to batch)
         PlanQuery(index, c.slot->queries[i], total_docs, avgdl, &c.slot->plans[i]);
+      }
       lock.lock();
       if (--c.slot->chunks_left != 0) continue;
       c.slot->t_planned = clock::now();
@@ -1016,25 +1032,30 @@ BatchExecutor::~BatchExecutor() {
 Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& queries) {
   index::Index::Impl* im = impl_->index.impl();
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
-  std::unique_lock<std::mutex> lock(impl_->mu);
   Impl::Slot* slot = nullptr;
-  for (auto& s : impl_->slots)
-    if (s.state == Impl::kFree) {
-      slot = &s;
-      break;
-    }
-  if (!slot)
-    return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument,
-                                    "BatchExecutor: every slot holds an unfetched batch (Wait for one first)"));
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    for (auto& s : impl_->slots)
+      if (s.state == Impl::kFree) {
+        slot = &s;
+        break;
+      }
+    if (!slot)
+      return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument,
+                                      "BatchExecutor: every slot holds an unfetched batch (Wait for one first)"));
+    slot->state = Impl::kFilling;  // reserved: nobody else touches it until its chunks are queued
+  }
+  // (outside the lock: freeing the slot's previous queries and plans and sizing the new ones is a few thousand
+  // allocations, and the planner threads take the same lock for every chunk)
   slot->queries = std::move(queries);
-  slot->plans.clear();
-  slot->plans.resize(slot->queries.size());
+  slot->plans.resize(slot->queries.size());  // (elements are reset by the planner that takes them)
   slot->error = Error{ErrorCode::kSuccess, ""};
   slot->timing = Timing{};
   slot->t_submit = Impl::clock::now();
+  const size_t n = slot->queries.size();
+  std::lock_guard<std::mutex> lock(impl_->mu);
   slot->ticket = impl_->next_ticket++;
   slot->state = Impl::kPlanning;
-  const size_t n = slot->queries.size();
   slot->chunks_left = std::max<size_t>(1, (n + Impl::kChunk - 1) / Impl::kChunk);
   if (n == 0) impl_->chunks.push_back(Impl::Chunk{slot, 0, 0});
   for (size_t a = 0; a < n; a += Impl::kChunk) impl_->chunks.push_back(Impl::Chunk{slot, a, std::min(n, a + Impl::kChunk)});
