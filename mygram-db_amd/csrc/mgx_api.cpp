@@ -1641,11 +1641,14 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // workgroup: 4x the tiles per item (measured on the benchmark batch: 1.55 -> 1.49 ms; 8x loses to the tail).
       const bool fast = on_wave[i] == 3;
       const double per_tile = 1.0 + (score_mode || df_mode ? s.est_density * kTileDocs / (fast ? kMatchesPerUnit / 2 : kMatchesPerUnit) : 0.0);
-      uint32_t tiles = static_cast<uint32_t>((fast ? 4.0 * kItemCost : kItemCost) / per_tile);
+      // (a small shard wants shorter items than a whole table: 2x..4x the base cost as the tile count goes 77 -> 611,
+      // measured at 1.25M docs — 0.47 -> 0.39 ms — and at 10M)
+      const double fast_scale = std::min(4.0, std::max(2.0, static_cast<double>(n_tiles) / 150.0));
+      uint32_t tiles = static_cast<uint32_t>((fast ? fast_scale * kItemCost : kItemCost) / per_tile);
       tiles = std::max<uint32_t>(8, std::min<uint32_t>(tiles, fast ? 2 * kMaxTiles : kMaxTiles)) & ~7u;  // whole rounds of the waves of a workgroup
       // a small shard (few tiles per query) still wants a few workgroups per CU slot, or the launch is one ragged round
       if (score_mode) {
-        const uint64_t want_items = 4ull * 768ull;  // ~4 rounds of the 768 workgroups a launch keeps resident
+        static const uint64_t want_items = std::getenv("MGX_WANT_ITEMS") ? static_cast<uint64_t>(atoll(std::getenv("MGX_WANT_ITEMS"))) : 4ull * 768ull;  // ~4 rounds of the 768 workgroups a launch keeps resident
         const uint64_t cap = std::max<uint64_t>(8, (static_cast<uint64_t>(n_tiles) * n / want_items + 7) & ~7ull);
         tiles = static_cast<uint32_t>(std::min<uint64_t>(tiles, cap));
       }
@@ -1657,9 +1660,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // Fast path: a short "seed" item first (two tiles per wave), launched ahead of everything else (below): it scores
       // its tiles unpruned and publishes the query's first k-th best score, so the long items start pruning at once.
       static const uint32_t kSeedTiles = std::getenv("MGX_SEED_TILES") ? static_cast<uint32_t>(atoi(std::getenv("MGX_SEED_TILES"))) : 16u;
-      if (fast && kSeedTiles && n_tiles > 4 * kSeedTiles) {
-        items.push_back(DevItem{i, 0, kSeedTiles, n_lists++});
-        t0 = kSeedTiles;
+      const uint32_t seed_tiles = std::min<uint32_t>(kSeedTiles, (n_tiles / 8) & ~7u);  // (8 on a 77-tile shard)
+      if (fast && seed_tiles && n_tiles > 4 * seed_tiles) {
+        items.push_back(DevItem{i, 0, seed_tiles, n_lists++});
+        t0 = seed_tiles;
       }
       for (uint32_t t = t0; t < n_tiles; t += tiles) {
         DevItem it{i, t, std::min(tiles, n_tiles - t), n_lists++};  // candidate lists stay grouped by query
