@@ -1739,13 +1739,19 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
             const u32x4 w = u == 0 ? w0 : u == 1 ? w1 : w2;
             const uint32_t code = fq->ops[o + u].code;
             const uint32_t x[4] = {w.x, w.y, w.z, w.w};
-            const uint32_t kind = code & 15u;
+            const uint32_t kind = wave_uniform(code & 15u);
+            // (scalar branches on the wave-uniform kind: written as selects this was three ALU ops + two v_cndmask per word)
+            if (kind == kFastAnd) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              uint32_t& acc = a[h * 4 + j];
-              acc = kind == kFastOr ? (acc | x[j]) : kind == kFastAnd ? (acc & x[j]) : (acc & ~x[j]);
+              for (int j = 0; j < 4; ++j) a[h * 4 + j] &= x[j];
+            } else if (kind == kFastOr) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a[h * 4 + j] |= x[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a[h * 4 + j] &= ~x[j];
             }
-            const uint32_t cmask = code >> 8;
+            const uint32_t cmask = wave_uniform(code >> 8);
             if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
               uint32_t pc = 0;
 #pragma unroll
