@@ -786,7 +786,13 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
   if (!idx || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_memory_bytes: null argument");
   *out = idx->d_offsets.bytes + idx->d_docids.bytes + idx->d_tf.bytes + idx->d_doc_len.bytes +
          idx->d_skip_row.bytes + idx->d_tile_off.bytes + idx->d_gram_bitmaps.bytes + idx->d_filter_bitmaps.bytes +
-         idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes + idx->d_table_pool.bytes;
+         idx->d_text.bytes + idx->d_text_off.bytes + idx->d_dl8.bytes + idx->d_tfnib.bytes + idx->d_table_pool.bytes +
+         idx->d_tf_ovf_pos.bytes + idx->d_tf_ovf_val.bytes;
+  {  // the per-(k1, b, avgdl) pruning arrays built so far
+    std::lock_guard<std::mutex> lock(const_cast<mgx_index*>(idx)->table_mu);
+    for (const auto& t : idx->block_max) *out += t->d.bytes + t->d_fine.bytes;
+    for (const auto& t : idx->norm_tables) *out += t->d.bytes;
+  }
   return MGX_OK;
 }
 
