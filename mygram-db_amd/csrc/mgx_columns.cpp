@@ -446,13 +446,21 @@ bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out
     const bool is_run = has_runs && ((run_flags[i / 8] >> (i % 8)) & 1u);
     if (is_run) {
       const uint32_t n_runs = r.U16();
+      uint32_t next_free = 0;  // runs ascend and do not touch: a container yields at most 65536 ids whatever its bytes say
       for (uint32_t k = 0; k < n_runs && r.ok; ++k) {
         const uint32_t start = r.U16(), last = start + r.U16();
-        if (last > 0xFFFFu) return false;
+        if (last > 0xFFFFu || start < next_free) return false;
         for (uint32_t v = start; v <= last; ++v) out->push_back(hi | v);
+        next_free = last + 1;
       }
     } else if (cards[i] <= 4096) {
-      for (uint32_t k = 0; k < cards[i] && r.ok; ++k) out->push_back(hi | r.U16());
+      uint32_t prev = 0;
+      for (uint32_t k = 0; k < cards[i] && r.ok; ++k) {
+        const uint32_t v = r.U16();
+        if (k && v <= prev) return false;  // (sorted, distinct)
+        out->push_back(hi | v);
+        prev = v;
+      }
     } else {
       if (!r.Need(8192)) return false;
       for (uint32_t w = 0; w < 1024; ++w) {
