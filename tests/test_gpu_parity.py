@@ -628,3 +628,25 @@ def test_terms_shorter_than_one_ngram_take_the_substring_fallback():
                 assert getattr(g, k) == r[k], (q.terms, k)
         hits += total > 0
     assert hits >= 11
+
+
+def test_pruning_keeps_ties_and_page_boundaries_exact():
+    """Block-max pruning under adversarial ties: 400k docs drawn from 40 distinct texts, so thousands of docs share every
+    score and the page boundary falls inside a tie class (the docid decides); quarters whose bound EQUALS the k-th best
+    score must be kept. Pages at several offsets, both orders, 1-3 scored terms, against the oracle."""
+    rng = np.random.default_rng(77)
+    words = ["alpha", "beta", "gamma", "delta", "kappa", "sigma", "omega"]
+    protos = [" ".join(str(w) for w in rng.choice(words, size=int(rng.integers(1, 7)))) for _ in range(40)]
+    texts = [protos[int(i)] for i in rng.integers(0, len(protos), size=400_000)]
+    p = Pair(docs=list(enumerate(texts, start=1)), ngram=2, kanji=0)
+    Q = mg.engine.Query
+    qs = []
+    for terms in (["al"], ["ma", "ga"], ["ta", "be", "et"], ["ka", "pp"], ["om", "eg", "ga"], ["si", "gm"]):
+        for limit, offset in ((10, 0), (10, 5), (37, 0), (100, 11), (1, 0)):
+            qs.append(Q(terms, sort_score=True, limit=limit, offset=offset))
+        qs.append(Q(terms, sort_score=True, limit=10, descending=False))
+    got = p.dev.search_batch(qs)
+    for q, g in zip(qs, got):
+        total, page, scores, _ = p.oracle_query(q)
+        assert g.total == total and g.docs.tolist() == page.tolist(), (q.terms, q.limit, q.offset, q.descending)
+        assert np.array_equal(g.scores, scores), (q.terms, q.limit, q.offset)
