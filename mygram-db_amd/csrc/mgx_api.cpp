@@ -323,6 +323,9 @@ struct mgx_index {
     DevBuf d, d_fine;
   };
   std::vector<std::unique_ptr<BlockMax>> block_max;
+  // df of text-level terms seen so far: (term bytes, N) -> table-wide df. The index is static, so a term's df never
+  // changes: the df pass (a text scan over every candidate of the term) runs once per distinct term, not once per batch.
+  std::unordered_map<std::string, uint64_t> df_cache;
   uint32_t n_bitmap_rows = 0, n_fine_rows = 0;
   DevBuf d_fine_rows;                 // fine row -> bitmap row
   std::vector<uint32_t> h_fine_map;   // bitmap row -> fine row (kNoRow: none)
@@ -1309,6 +1312,8 @@ struct mgx_batch {
   std::vector<mgx::QuerySpec> df_specs;
   DevBuf d_patterns, d_text_terms, d_text_idf, d_text_df, d_verify_terms;
   std::vector<uint64_t> h_text_df, text_total_docs;
+  std::vector<uint64_t> text_df_known;      // per text term: its cached df, or ~0ull (the df query then counts it)
+  std::vector<std::string> text_df_key;     // per text term: the cache key
   std::vector<double> h_text_idf;
   bool df_ready = false;  // mgx_batch_count_df ran (and the caller summed the counts) for the next execute
   // score group outputs
@@ -1978,9 +1983,21 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         Compiler c{idx, &ds, 0};
         double dens = 1.0;
         uint64_t mn = ~0ull;
-        if (tt.grams.empty()) {
-          // a term shorter than one n-gram: PopulateTermDocumentFrequency returns before counting (search_pipeline.cpp:
-          // 546-549), so its df is 0 — the df query runs over the empty doc range
+        std::string ckey = tt.pattern;
+        ckey.push_back('\0');
+        ckey += std::to_string(s.total_docs);
+        uint64_t known = ~0ull;
+        {
+          std::lock_guard<std::mutex> lock(idx->table_mu);
+          const auto hit = idx->df_cache.find(ckey);
+          if (hit != idx->df_cache.end()) known = hit->second;
+        }
+        b->text_df_known.push_back(tt.grams.empty() ? 0ull : known);
+        b->text_df_key.push_back(std::move(ckey));
+        if (tt.grams.empty() || known != ~0ull) {
+          // nothing to count: a term shorter than one n-gram has df 0 (PopulateTermDocumentFrequency returns before
+          // counting, search_pipeline.cpp:546-549), a term seen before has its df in the index's cache — the df query
+          // runs over the empty doc range and the known value is put in its place when the counts are read
           c.Emit(kOpLoad, c.RangeLeaf(0, 0));
           mn = 0;
         } else {
@@ -2132,6 +2149,16 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     const size_t n_tt = b->h_text_df.size();
     MGX_HIP(hipMemcpyAsync(b->h_text_df.data(), b->d_text_df.p, n_tt * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
+    {
+      std::lock_guard<std::mutex> lock(idx->table_mu);
+      for (size_t i = 0; i < n_tt; ++i) {
+        if (b->text_df_known[i] != ~0ull) {
+          b->h_text_df[i] = b->text_df_known[i];
+        } else if (idx->df_cache.size() < (1u << 20)) {
+          idx->df_cache.emplace(b->text_df_key[i], b->h_text_df[i]);  // (table-wide already when the ranks summed it)
+        }
+      }
+    }
     for (size_t i = 0; i < n_tt; ++i) {
       // BM25Scorer::ComputeIDF, bm25_scorer.cpp:14-25
       const uint64_t total = b->text_total_docs[i];
