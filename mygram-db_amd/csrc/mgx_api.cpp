@@ -449,7 +449,7 @@ static const uint8_t* GetBlockMax(mgx_index* idx, double k1, double b, double av
   t->k1 = Bits(k1);
   t->b = Bits(b);
   t->avg = Bits(avgdl);
-  t->step = (k1 + 1.0) / 250.0;
+  t->step = (k1 + 1.0) / 253.0;  // the supremum k1 + 1 lands on 254 (build_blockmax_kernel: floor + 1)
   ResourceScope none(nullptr);
   const size_t bytes = static_cast<size_t>(idx->dev.n_tiles) * idx->n_bitmap_rows * 256u;
   if (hipSetDevice(idx->device) != hipSuccess || t->d.Alloc(bytes) != hipSuccess) {

@@ -210,8 +210,11 @@ __global__ void build_tfnib_kernel(const uint32_t* __restrict__ docids, const ui
 // over the docs of the word that hold the gram, in units of `step` (one byte; 0 = no doc of the word holds the gram).
 // A doc's score is sum_i idf_i * g_i, so sum_i idf_i * step * q_i bounds every score of the word from above; the scoring
 // kernels skip the words whose bound is below the query's current k-th best (they still count their matches).
-// q = floor(g / step) + 2: at least one whole step above g, so no rounding in g / step or in the kernels' sums can
-// bring the bound below a score. A saturated nibble (tf >= 15) takes the supremum k1 + 1, a saturated doc length
+// q = floor(g / step * (1 + 2^-40)) + 1 > g / step even after the roundings of that product (2^-53 each), so q * step
+// exceeds g by a relative 2^-41 at least — the margin the fp64 roundings of a doc's actual score (a few 2^-53) stay far
+// inside; the kernels' side of the comparison is integer arithmetic (exact) with the weights rounded up and the
+// threshold rounded down. (Until the bound went integer this was floor(g / step) + 2, a whole spare step per term: on
+// the heavy queries of the benchmark that slack let 20 % more matches through.) A saturated nibble (tf >= 15) takes the supremum k1 + 1, a saturated doc length
 // K[255] (the true length is longer, its factor smaller). Layout: [tile][row][256 words], like the gram bitmaps.
 // kFine: the rows listed in `rows` (the densest grams: every 64-doc word of theirs holds some doc with a near-maximal
 // factor, so the per-word bound prunes nothing) get one byte per 16-doc QUARTER of a word, four per word, as a u32.
@@ -250,8 +253,8 @@ __global__ __launch_bounds__(256) void build_blockmax_kernel(const uint8_t* __re
   for (int j = 0; j < 4; ++j) {
     uint32_t qv = 0;
     if (best[j] > 0.0) {
-      const double steps = floor(best[j] * inv_step);
-      qv = steps >= 253.0 ? 255u : static_cast<uint32_t>(steps) + 2u;
+      const double steps = floor(best[j] * inv_step * (1.0 + 0x1p-40));
+      qv = steps >= 254.0 ? 255u : static_cast<uint32_t>(steps) + 1u;
     }
     packed |= qv << (8 * j);
     whole = qv > whole ? qv : whole;
@@ -1525,6 +1528,82 @@ __device__ __noinline__ uint32_t fast_exact_tf(const DevIndex* ix, uint32_t gram
   return exact_tf(*ix, gram, row, slot);
 }
 
+// The block-max words of this lane's 256 doc slots of `tile`, one row per scored term: per 16-doc quarter (mode 2: four
+// u32, a byte per quarter), per 64-doc word (mode 1: one u32, expanded when looked at) or none (mode 0: zeros).
+template <int T>
+__device__ __forceinline__ void fast_load_blockmax(const DevFastQuery* __restrict__ fq, uint32_t tile, uint32_t lane,
+                                                   uint32_t (&bmw)[T][4]) {
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
+    const uint32_t mode = fq->score[i].bm_mode;
+    if (mode == 2u) {
+      const u32x4 v = reinterpret_cast<gptr_u4>(reinterpret_cast<uint64_t>(fq->blockmax_fine) +
+                                                static_cast<uint64_t>(tile) * fq->bmf_tile_stride +
+                                                fq->score[i].bm_off)[lane];
+      bmw[i][0] = v.x;
+      bmw[i][1] = v.y;
+      bmw[i][2] = v.z;
+      bmw[i][3] = v.w;
+    } else if (mode == 1u) {
+      bmw[i][0] = reinterpret_cast<gptr_u1>(reinterpret_cast<uint64_t>(fq->blockmax) +
+                                            static_cast<uint64_t>(tile) * fq->bm_tile_stride + fq->score[i].bm_off)[lane];
+    }
+  }
+}
+
+// One bit per 16-doc quarter of this lane's 256 slots: "a doc of this quarter can still reach the page" against the
+// k-th best key `bound`. Integer form: a quarter survives iff sum_i W_i * q_i >= floor(theta * bm_inv_unit), W_i the idf
+// weights rounded UP to 8 bits (the host), theta's conversion rounded DOWN: the integer bound stays above the exact one,
+// which itself sits a relative 2^-41 above any score (build_blockmax_kernel). Per 64-doc word the terms' bytes are transposed
+// (v_perm_b32) so that one v_dot4_u32_u8 per quarter does the weighted sum.
+template <int T>
+__device__ __forceinline__ uint32_t fast_quarter_mask(const DevFastQuery* __restrict__ fq, uint32_t (&bmw)[T][4],
+                                                      uint64_t bound) {
+  const uint32_t tint = static_cast<uint32_t>(
+      fmin(floor(key_score(bound, true) * fq->bm_inv_unit * (1.0 - 0x1p-30)), 4294967040.0));
+  const uint32_t wpack = fq->bm_wpack, w4 = fq->bm_w4, cint = fq->bm_cint;
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    if (fq->score[i].bm_mode == 1u) {  // wave-uniform: a word's byte stands for its four quarters
+      const uint32_t c = bmw[i][0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bmw[i][k] = ((c >> (8 * k)) & 255u) * 0x01010101u;
+    }
+  }
+  uint32_t mk = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t t0 = bmw[0][k], t1 = T > 1 ? bmw[T > 1 ? 1 : 0][k] : 0u, t2 = T > 2 ? bmw[T > 2 ? 2 : 0][k] : 0u,
+                   t3 = T > 3 ? bmw[T > 3 ? 3 : 0][k] : 0u;
+    // [t0.0 t1.0 t0.1 t1.1], [t0.2 t1.2 t0.3 t1.3] and the same of terms 2, 3
+    const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u), hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);
+    const uint32_t lo23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x05010400u) : 0u;
+    const uint32_t hi23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x07030602u) : 0u;
+    uint32_t qb[4];  // quarter j: the bytes of terms 0..3
+    qb[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+    qb[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+    qb[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    qb[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t ub = __builtin_amdgcn_udot4(qb[j], wpack, cint, false);
+      if (T > 4) ub += w4 * ((bmw[T > 4 ? 4 : 0][k] >> (8 * j)) & 255u);
+      if (ub >= tint) mk |= 1u << (4 * k + j);
+    }
+  }
+  return mk;
+}
+
+// The quarter bits of a tile once more, against a bound that moved while the tile's matches were being scored (a tile
+// with more matches than the wave's buffer holds is scored in chunks): out of line, the rare path of heavy queries.
+template <int T>
+__device__ __noinline__ uint32_t fast_remask(const DevFastQuery* fq, uint32_t tile, uint32_t lane, uint64_t bound) {
+  uint32_t bmw[T][4];
+  fast_load_blockmax<T>(fq, tile, lane, bmw);
+  return fast_quarter_mask<T>(fq, bmw, bound);
+}
+
 template <int T>
 __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan,
                                                   const DevFastQuery* __restrict__ fq, const DevItem it) {
@@ -1654,36 +1733,24 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
     const bool flush = tile >= tile_end;  // wave-uniform
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t mine = 0;
+    uint64_t bound = 0;  // the k-th best key this tile's quarter bits were made against (wave-uniform)
     if (!flush) {
       wave_topk_refresh_gbound(tk);
       // ---- pruning: one bit per 16-doc quarter of this lane's 256 slots — "can still enter the page". The block-max
       // bytes are requested first, the operands right behind them, and the bits are made while the operands fly.
       uint32_t qmask = 0xFFFFu;
-      uint64_t bound = 0;
       if (prune) {
         // the k-th best so far — this wave's own list or any wave's of the query: a quarter whose bound is below it
         // holds no doc that can enter the page (equal scores are kept: the docid decides)
         bound = tk.gbound;
         if (tk.have >= tk.needed && tk.bound_key > bound) bound = tk.bound_key;
       }
-      uint32_t bmw[T][4];  // per quarter: one u32 per 64-doc word; per word: [0] only (expanded when looked at)
+      uint32_t bmw[T][4];
+      if (bound != 0) {  // wave-uniform: nothing to prune against yet otherwise
+        fast_load_blockmax<T>(fq, tile, lane, bmw);
+      } else {
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
-        if (bound == 0) continue;  // wave-uniform: nothing to prune against yet
-        const uint32_t mode = fq->score[i].bm_mode;
-        if (mode == 2u) {
-          const u32x4 v = reinterpret_cast<gptr_u4>(reinterpret_cast<uint64_t>(fq->blockmax_fine) +
-                                                    static_cast<uint64_t>(tile) * fq->bmf_tile_stride +
-                                                    fq->score[i].bm_off)[lane];
-          bmw[i][0] = v.x;
-          bmw[i][1] = v.y;
-          bmw[i][2] = v.z;
-          bmw[i][3] = v.w;
-        } else if (mode == 1u) {
-          bmw[i][0] = reinterpret_cast<gptr_u1>(reinterpret_cast<uint64_t>(fq->blockmax) +
-                                                static_cast<uint64_t>(tile) * fq->bm_tile_stride + fq->score[i].bm_off)[lane];
-        }
+        for (int i = 0; i < T; ++i) bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
       }
       // ---- A. the operands of this lane's 256 doc slots, combined in registers; in two halves of 128 slots, so that
       //         the loads in flight hold 4 registers per operand, not 8
@@ -1694,45 +1761,8 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
           u32x4 w1 = w0, w2 = w0;
           if (o + 1 < n_ops) w1 = load_half(o + 1, tile, h);
           if (o + 2 < n_ops) w2 = load_half(o + 2, tile, h);
-          if (h == 0 && o == 0 && bound != 0) {  // (the block-max loads are older than the operands': no extra wait)
-            // Integer form of the bound: a quarter survives iff sum_i W_i * q_i >= floor(theta * bm_inv_unit), W_i the
-            // idf weights rounded UP to 8 bits (the host), theta's conversion rounded DOWN: the integer bound stays above
-            // the exact one, which itself sits a whole quantisation step above any score. Per 64-doc word the terms'
-            // bytes are transposed (v_perm_b32) so that one v_dot4_u32_u8 per quarter does the weighted sum.
-            const uint32_t tint = static_cast<uint32_t>(
-                fmin(floor(key_score(bound, true) * fq->bm_inv_unit * (1.0 - 0x1p-30)), 4294967040.0));
-            const uint32_t wpack = fq->bm_wpack, w4 = fq->bm_w4, cint = fq->bm_cint;
-#pragma unroll
-            for (int i = 0; i < T; ++i) {
-              if (fq->score[i].bm_mode == 1u) {  // wave-uniform: a word's byte stands for its four quarters
-                const uint32_t c = bmw[i][0];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) bmw[i][k] = ((c >> (8 * k)) & 255u) * 0x01010101u;
-              }
-            }
-            uint32_t mk = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const uint32_t t0 = bmw[0][k], t1 = T > 1 ? bmw[T > 1 ? 1 : 0][k] : 0u, t2 = T > 2 ? bmw[T > 2 ? 2 : 0][k] : 0u,
-                             t3 = T > 3 ? bmw[T > 3 ? 3 : 0][k] : 0u;
-              // [t0.0 t1.0 t0.1 t1.1], [t0.2 t1.2 t0.3 t1.3] and the same of terms 2, 3
-              const uint32_t lo01 = __builtin_amdgcn_perm(t1, t0, 0x05010400u), hi01 = __builtin_amdgcn_perm(t1, t0, 0x07030602u);
-              const uint32_t lo23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x05010400u) : 0u;
-              const uint32_t hi23 = T > 2 ? __builtin_amdgcn_perm(t3, t2, 0x07030602u) : 0u;
-              uint32_t qb[4];  // quarter j: the bytes of terms 0..3
-              qb[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
-              qb[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
-              qb[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-              qb[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                uint32_t ub = __builtin_amdgcn_udot4(qb[j], wpack, cint, false);
-                if (T > 4) ub += w4 * ((bmw[T > 4 ? 4 : 0][k] >> (8 * j)) & 255u);
-                if (ub >= tint) mk |= 1u << (4 * k + j);
-              }
-            }
-            qmask = mk;
-          }
+          // (the block-max loads are older than the operands': no extra wait)
+          if (h == 0 && o == 0 && bound != 0) qmask = fast_quarter_mask<T>(fq, bmw, bound);
 #pragma unroll
           for (int u = 0; u < 3; ++u) {
             if (o + u >= n_ops) break;  // wave-uniform
@@ -1814,6 +1844,26 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
 #endif
         g0 += n;
       }
+#ifndef MGX_NO_REMASK
+      // A tile with more matches than the buffer holds (a heavy query) is scored in chunks: the page's bound has
+      // usually moved meanwhile, and the matches still in a[] are held against the new one before they are enumerated.
+      if (more && prune) {
+        wave_topk_refresh_gbound(tk);
+        uint64_t nb = tk.gbound;
+        if (tk.have >= tk.needed && tk.bound_key > nb) nb = tk.bound_key;
+        if (nb > bound) {
+          bound = nb;
+          const uint32_t qm = fast_remask<T>(fq, tile, lane, nb);
+          mine = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t m2 = qm >> (2 * j);
+            a[j] &= ((m2 & 1u) ? 0x0000FFFFu : 0u) | ((m2 & 2u) ? 0xFFFF0000u : 0u);
+            mine += __popc(a[j]);
+          }
+        }
+      }
+#endif
       if (g0 != 0) {  // move the (< kFastRound) leftover to the front: sources sit at >= kFastRound, destinations below
         const uint32_t left = pend - g0;
         uint32_t v[kFastPerLane];
