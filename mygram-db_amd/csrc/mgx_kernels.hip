@@ -1520,6 +1520,12 @@ FastPlan PlanFast(uint32_t max_cap, const double* ktab) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1)))* gptr_u4;
 typedef const uint32_t __attribute__((address_space(1)))* gptr_u1;
+// A query's resolved description, read through the CONSTANT address space: the kernel never writes it, and only there
+// does the compiler fetch its (wave-uniform) fields with scalar loads. Through a generic pointer every `fq->field`
+// inside the tile loop became a vector load + s_waitcnt vmcnt(0) + v_readfirstlane — the kernel's own stores and atomics
+// forbid the "not clobbered" proof scalar loads need — i.e. a serialized L2 round trip per field group, about ten per
+// tile visit in front of the operand loads.
+typedef const DevFastQuery __attribute__((address_space(4)))* FastQueryPtr;
 
 // The cold corner of scoring, out of line so that its needs (posting arrays, skip rows, the overflow table) stay out of
 // the hot loop's registers: the exact tf of a saturated nibble (tf >= 15). `ix` is the index's descriptor in device
@@ -1531,7 +1537,7 @@ __device__ __noinline__ uint32_t fast_exact_tf(const DevIndex* ix, uint32_t gram
 // The block-max words of this lane's 256 doc slots of `tile`, one row per scored term: per 16-doc quarter (mode 2: four
 // u32, a byte per quarter), per 64-doc word (mode 1: one u32, expanded when looked at) or none (mode 0: zeros).
 template <int T>
-__device__ __forceinline__ void fast_load_blockmax(const DevFastQuery* __restrict__ fq, uint32_t tile, uint32_t lane,
+__device__ __forceinline__ void fast_load_blockmax(const FastQueryPtr fq, uint32_t tile, uint32_t lane,
                                                    uint32_t (&bmw)[T][4]) {
 #pragma unroll
   for (int i = 0; i < T; ++i) {
@@ -1558,7 +1564,7 @@ __device__ __forceinline__ void fast_load_blockmax(const DevFastQuery* __restric
 // which itself sits a relative 2^-41 above any score (build_blockmax_kernel). Per 64-doc word the terms' bytes are transposed
 // (v_perm_b32) so that one v_dot4_u32_u8 per quarter does the weighted sum.
 template <int T>
-__device__ __forceinline__ uint32_t fast_quarter_mask(const DevFastQuery* __restrict__ fq, uint32_t (&bmw)[T][4],
+__device__ __forceinline__ uint32_t fast_quarter_mask(const FastQueryPtr fq, uint32_t (&bmw)[T][4],
                                                       uint64_t bound) {
   const uint32_t tint = static_cast<uint32_t>(
       fmin(floor(key_score(bound, true) * fq->bm_inv_unit * (1.0 - 0x1p-30)), 4294967040.0));
@@ -1598,7 +1604,7 @@ __device__ __forceinline__ uint32_t fast_quarter_mask(const DevFastQuery* __rest
 // The quarter bits of a tile once more, against a bound that moved while the tile's matches were being scored (a tile
 // with more matches than the wave's buffer holds is scored in chunks): out of line, the rare path of heavy queries.
 template <int T>
-__device__ __noinline__ uint32_t fast_remask(const DevFastQuery* fq, uint32_t tile, uint32_t lane, uint64_t bound) {
+__device__ __noinline__ uint32_t fast_remask(const FastQueryPtr fq, uint32_t tile, uint32_t lane, uint64_t bound) {
   uint32_t bmw[T][4];
   fast_load_blockmax<T>(fq, tile, lane, bmw);
   return fast_quarter_mask<T>(fq, bmw, bound);
@@ -1606,7 +1612,7 @@ __device__ __noinline__ uint32_t fast_remask(const DevFastQuery* fq, uint32_t ti
 
 template <int T>
 __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan,
-                                                  const DevFastQuery* __restrict__ fq, const DevItem it) {
+                                                  const FastQueryPtr fq, const DevItem it) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const FastOffsets fo = carve_fast(plan);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = wave_uniform(tid >> 6);
@@ -1720,9 +1726,10 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
 
   // This lane's 16 bytes of half `h` of operand `o` for `tile` (issued and not waited for)
   auto load_half = [&](uint32_t o, uint32_t tile, uint32_t h) {
-    const FastOp op = fq->ops[o];
-    const uint64_t base = op.base + ((op.code & 16u) ? reinterpret_cast<uint64_t>(ix.filter_bitmaps) : 0ull) +
-                          static_cast<uint64_t>(tile) * op.tile_stride;
+    const uint64_t op_base = fq->ops[o].base;
+    const uint32_t op_code = fq->ops[o].code, op_stride = fq->ops[o].tile_stride;
+    const uint64_t base = op_base + ((op_code & 16u) ? reinterpret_cast<uint64_t>(ix.filter_bitmaps) : 0ull) +
+                          static_cast<uint64_t>(tile) * op_stride;
     const gptr_u4 p = reinterpret_cast<gptr_u4>(base) + lane * 2 + h;
     return p[0];
   };
@@ -1943,7 +1950,8 @@ template <int T>
 #endif
 __global__ __launch_bounds__(kFastBlock, MGX_FOCC) void bitmap_score_kernel(DevIndex ix, DevBatch bt, FastPlan plan) {
   const DevItem it = bt.items[blockIdx.x];
-  bitmap_score_body<T>(ix, bt, plan, bt.fast_queries + it.query, it);
+  bitmap_score_body<T>(ix, bt, plan,
+                       reinterpret_cast<FastQueryPtr>(reinterpret_cast<uint64_t>(bt.fast_queries + it.query)), it);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -985,10 +985,11 @@ struct BatchExecutor::Impl {
       });
       if (stop) return;
       lock.unlock();
+      const auto t_begin = clock::now();  // (a planned batch may have waited for this thread: not compile time)
       Compile(slot);
       slot->t_compiled = clock::now();
       slot->timing.plan_ms = std::chrono::duration<double, std::milli>(slot->t_planned - slot->t_submit).count();
-      slot->timing.compile_ms = std::chrono::duration<double, std::milli>(slot->t_compiled - slot->t_planned).count();
+      slot->timing.compile_ms = std::chrono::duration<double, std::milli>(slot->t_compiled - t_begin).count();
       lock.lock();
       slot->state = slot->error.code() == ErrorCode::kSuccess ? kCompiled : kFailed;
       EnqueueReady();
