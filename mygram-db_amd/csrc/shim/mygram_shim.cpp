@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -864,7 +865,7 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
 // ---- BatchExecutor ------------------------------------------------------------------------------------------------
 //
 // Submit only queues: a pool of workers plans the batch in chunks of queries (several batches at once when several are
-// queued); one dispatcher thread compiles planned batches (mgx_batch_reset: host work, one object per slot) and puts
+// queued); dispatcher threads (two) compile planned batches (mgx_batch_reset: host work, one object per slot) and put
 // them on the device strictly in ticket order — on a sharded table each execute is followed by a collective that every
 // rank must issue in the same order. Wait blocks until its ticket is on the device, then fetches.
 
@@ -874,7 +875,7 @@ struct BatchExecutor::Impl {
   Options opt;
   uint64_t total_docs = 0;
   double avgdl = 0.0;
-  enum State { kFree, kFilling, kPlanning, kPlanned, kCompiled, kEnqueued, kFailed };
+  enum State { kFree, kFilling, kPlanning, kPlanned, kCompiling, kCompiled, kEnqueued, kFailed };
   struct Slot {
     mgx_batch* batch = nullptr;
     std::vector<BatchQuery> queries;
@@ -893,9 +894,9 @@ struct BatchExecutor::Impl {
   };
   static constexpr size_t kChunk = 64;
   std::vector<Slot> slots;
-  uint64_t next_ticket = 1, next_enqueue = 1;
+  uint64_t next_ticket = 1, next_compile = 1, next_enqueue = 1;
   std::vector<std::thread> workers;
-  std::thread dispatcher;
+  std::vector<std::thread> dispatchers;
   std::mutex mu;  // slots' state, the chunk queue, the enqueue turn
   std::condition_variable cv_work, cv_state;
   std::deque<Chunk> chunks;
@@ -972,18 +973,22 @@ struct BatchExecutor::Impl {
     }
   }
 
-  // One thread compiles and enqueues, ticket after ticket: the compile step walks the same arenas and pinned blocks
-  // every time (they stay in its caches; compiling on whichever planner finished last cost 2-3x), and the device
-  // order — which a sharded table's collectives need identical on every rank — is the loop's own order.
+  // Dedicated threads compile, ticket after ticket (the compile step walks the same arenas and pinned blocks every time:
+  // on whichever planner finished last it cost 2-3x). Two of them take alternate tickets — compiling a batch is ~0.5 ms
+  // of one thread, which on a small shard (0.3 ms of device per batch) was the step — and whoever finishes puts every
+  // batch that is ready on the device IN TICKET ORDER (EnqueueReady, under the lock): the order a sharded table's
+  // collectives need identical on every rank.
   void Dispatch() {
     std::unique_lock<std::mutex> lock(mu);
     for (;;) {
       Slot* slot = nullptr;
       cv_state.wait(lock, [&] {
-        slot = ByTicket(next_enqueue);
+        slot = ByTicket(next_compile);
         return stop || (slot && slot->state == kPlanned);
       });
       if (stop) return;
+      slot->state = kCompiling;
+      ++next_compile;
       lock.unlock();
       const auto t_begin = clock::now();  // (a planned batch may have waited for this thread: not compile time)
       Compile(slot);
@@ -1003,7 +1008,9 @@ BatchExecutor::BatchExecutor(const index::Index& index, Options options) : impl_
   impl_->avgdl = index.Bm25AvgDocLength();
   impl_->slots.resize(static_cast<size_t>(std::max(1, options.depth)));
   for (int t = 0; t < std::max(1, options.planner_threads); ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
-  impl_->dispatcher = std::thread([this] { impl_->Dispatch(); });
+  static const int kDispatchers = std::getenv("MGX_DISPATCHERS") ? atoi(std::getenv("MGX_DISPATCHERS")) : 2;
+  const int n_dispatchers = std::max(1, std::min(kDispatchers, std::max(1, options.depth)));
+  for (int t = 0; t < n_dispatchers; ++t) impl_->dispatchers.emplace_back([this] { impl_->Dispatch(); });
 }
 
 BatchExecutor::~BatchExecutor() {
@@ -1012,7 +1019,9 @@ BatchExecutor::~BatchExecutor() {
     // batches still in the pipeline reach the device first: a collective half-issued would hang the other ranks
     impl_->cv_state.wait(lock, [&] {
       for (auto& s : impl_->slots)
-        if (s.state == Impl::kPlanning || s.state == Impl::kPlanned || s.state == Impl::kCompiled) return false;
+        if (s.state == Impl::kPlanning || s.state == Impl::kPlanned || s.state == Impl::kCompiling ||
+            s.state == Impl::kCompiled)
+          return false;
       return true;
     });
     impl_->stop = true;
@@ -1020,7 +1029,7 @@ BatchExecutor::~BatchExecutor() {
   impl_->cv_work.notify_all();
   impl_->cv_state.notify_all();
   for (auto& w : impl_->workers) w.join();
-  impl_->dispatcher.join();
+  for (auto& d : impl_->dispatchers) d.join();
   for (auto& s : impl_->slots) {
     if (s.state == Impl::kEnqueued && s.batch && !s.mq.empty()) {
       mgx_result_view v{};
