@@ -1534,27 +1534,21 @@ __device__ __noinline__ uint32_t fast_exact_tf(const DevIndex* ix, uint32_t gram
   return exact_tf(*ix, gram, row, slot);
 }
 
-// The block-max words of this lane's 256 doc slots of `tile`, one row per scored term: per 16-doc quarter (mode 2: four
-// u32, a byte per quarter), per 64-doc word (mode 1: one u32, expanded when looked at) or none (mode 0: zeros).
+// The block-max bytes of this lane's 256 doc slots of `tile`, one 16-byte load per scored term and NO control flow, so
+// that the T loads and the operand loads behind them are in flight together (with a branch per mode the compiler parked
+// an s_waitcnt vmcnt(0) between the terms and in front of the operand loads: three serialized round trips per visit).
+// Mode 2 (a byte per 16-doc quarter): the lane's own four words. Mode 1 (a byte per 64-doc word, 256 bytes per tile row):
+// the 16 bytes that hold this lane's four — lanes 4j..4j+3 read the same 16 — picked apart in fast_quarter_mask.
 template <int T>
-__device__ __forceinline__ void fast_load_blockmax(const FastQueryPtr fq, uint32_t tile, uint32_t lane,
-                                                   uint32_t (&bmw)[T][4]) {
+__device__ __forceinline__ void fast_load_blockmax(const FastQueryPtr fq, uint32_t tile, uint32_t lane, u32x4 (&raw)[T]) {
+  const uint64_t bm = reinterpret_cast<uint64_t>(fq->blockmax), bmf = reinterpret_cast<uint64_t>(fq->blockmax_fine);
+  const uint32_t st = fq->bm_tile_stride, stf = fq->bmf_tile_stride;
 #pragma unroll
   for (int i = 0; i < T; ++i) {
-    bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
-    const uint32_t mode = fq->score[i].bm_mode;
-    if (mode == 2u) {
-      const u32x4 v = reinterpret_cast<gptr_u4>(reinterpret_cast<uint64_t>(fq->blockmax_fine) +
-                                                static_cast<uint64_t>(tile) * fq->bmf_tile_stride +
-                                                fq->score[i].bm_off)[lane];
-      bmw[i][0] = v.x;
-      bmw[i][1] = v.y;
-      bmw[i][2] = v.z;
-      bmw[i][3] = v.w;
-    } else if (mode == 1u) {
-      bmw[i][0] = reinterpret_cast<gptr_u1>(reinterpret_cast<uint64_t>(fq->blockmax) +
-                                            static_cast<uint64_t>(tile) * fq->bm_tile_stride + fq->score[i].bm_off)[lane];
-    }
+    const bool fine = fq->score[i].bm_mode == 2u;  // wave-uniform
+    const uint64_t row = (fine ? bmf : bm) + static_cast<uint64_t>(tile) * (fine ? stf : st) + fq->score[i].bm_off;
+    const uint32_t off = fine ? lane << 4 : (lane >> 2) << 4;
+    raw[i] = *reinterpret_cast<gptr_u4>(row + off);
   }
 }
 
@@ -1564,17 +1558,28 @@ __device__ __forceinline__ void fast_load_blockmax(const FastQueryPtr fq, uint32
 // which itself sits a relative 2^-41 above any score (build_blockmax_kernel). Per 64-doc word the terms' bytes are transposed
 // (v_perm_b32) so that one v_dot4_u32_u8 per quarter does the weighted sum.
 template <int T>
-__device__ __forceinline__ uint32_t fast_quarter_mask(const FastQueryPtr fq, uint32_t (&bmw)[T][4],
+__device__ __forceinline__ uint32_t fast_quarter_mask(const FastQueryPtr fq, uint32_t lane, const u32x4 (&raw)[T],
                                                       uint64_t bound) {
   const uint32_t tint = static_cast<uint32_t>(
       fmin(floor(key_score(bound, true) * fq->bm_inv_unit * (1.0 - 0x1p-30)), 4294967040.0));
   const uint32_t wpack = fq->bm_wpack, w4 = fq->bm_w4, cint = fq->bm_cint;
+  uint32_t bmw[T][4];
 #pragma unroll
   for (int i = 0; i < T; ++i) {
-    if (fq->score[i].bm_mode == 1u) {  // wave-uniform: a word's byte stands for its four quarters
-      const uint32_t c = bmw[i][0];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bmw[i][k] = ((c >> (8 * k)) & 255u) * 0x01010101u;
+    bmw[i][0] = raw[i].x;
+    bmw[i][1] = raw[i].y;
+    bmw[i][2] = raw[i].z;
+    bmw[i][3] = raw[i].w;
+    const uint32_t mode = fq->score[i].bm_mode;
+    if (mode == 1u) {  // wave-uniform: this lane's four bytes are dword (lane & 3); a word's byte stands for its four quarters
+      const uint32_t l3 = lane & 3u;
+      const uint32_t c = l3 == 0u ? raw[i].x : l3 == 1u ? raw[i].y : l3 == 2u ? raw[i].z : raw[i].w;
+      bmw[i][0] = __builtin_amdgcn_perm(0u, c, 0x00000000u);
+      bmw[i][1] = __builtin_amdgcn_perm(0u, c, 0x01010101u);
+      bmw[i][2] = __builtin_amdgcn_perm(0u, c, 0x02020202u);
+      bmw[i][3] = __builtin_amdgcn_perm(0u, c, 0x03030303u);
+    } else if (mode != 2u) {
+      bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
     }
   }
   uint32_t mk = 0;
@@ -1605,9 +1610,9 @@ __device__ __forceinline__ uint32_t fast_quarter_mask(const FastQueryPtr fq, uin
 // with more matches than the wave's buffer holds is scored in chunks): out of line, the rare path of heavy queries.
 template <int T>
 __device__ __noinline__ uint32_t fast_remask(const FastQueryPtr fq, uint32_t tile, uint32_t lane, uint64_t bound) {
-  uint32_t bmw[T][4];
-  fast_load_blockmax<T>(fq, tile, lane, bmw);
-  return fast_quarter_mask<T>(fq, bmw, bound);
+  u32x4 raw[T];
+  fast_load_blockmax<T>(fq, tile, lane, raw);
+  return fast_quarter_mask<T>(fq, lane, raw, bound);
 }
 
 template <int T>
@@ -1752,54 +1757,57 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
         bound = tk.gbound;
         if (tk.have >= tk.needed && tk.bound_key > bound) bound = tk.bound_key;
       }
-      uint32_t bmw[T][4];
-      if (bound != 0) {  // wave-uniform: nothing to prune against yet otherwise
-        fast_load_blockmax<T>(fq, tile, lane, bmw);
-      } else {
+      u32x4 raw[T];
 #pragma unroll
-        for (int i = 0; i < T; ++i) bmw[i][0] = bmw[i][1] = bmw[i][2] = bmw[i][3] = 0;
-      }
+      for (int i = 0; i < T; ++i) raw[i] = u32x4{0u, 0u, 0u, 0u};
+      if (prune) fast_load_blockmax<T>(fq, tile, lane, raw);  // (also before the first bound exists: no branch on it)
       // ---- A. the operands of this lane's 256 doc slots, combined in registers; in two halves of 128 slots, so that
-      //         the loads in flight hold 4 registers per operand, not 8
+      //         a load is 16 bytes per lane. The first three operands (both halves: six loads) are requested back to back
+      //         and without control flow between them (an operand the query does not have re-reads its last one: same
+      //         address, no new traffic), so that they — and the block-max loads in front of them — are ONE round trip; a
+      //         wave-uniform branch or a register copy between two loads made the compiler wait for the first before it
+      //         issued the second (1.03 -> 0.90 ms), and the halves one after the other were two round trips (-> 0.87).
+      auto combine = [&](int h, uint32_t o, const u32x4 w) {
+        const uint32_t code = fq->ops[o].code;
+        const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+        const uint32_t kind = wave_uniform(code & 15u);
+        // (scalar branches on the wave-uniform kind: written as selects this was three ALU ops + two v_cndmask per word)
+        if (kind == kFastAnd) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[h * 4 + j] &= x[j];
+        } else if (kind == kFastOr) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[h * 4 + j] |= x[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[h * 4 + j] &= ~x[j];
+        }
+        const uint32_t cmask = wave_uniform(code >> 8);
+        if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
+          uint32_t pc = 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pc += __popc(a[h * 4 + j]);
+          if (cmask & 1u) cnt0 += pc;
+          if (cmask & 2u) cnt1 += pc;
+          if (cmask & 4u) cnt2 += pc;
+          if (cmask & 8u) cnt3 += pc;
+        }
+      };
+      const uint32_t o1 = min(1u, n_ops - 1u), o2 = min(2u, n_ops - 1u);
+      u32x4 w[2][3];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        for (uint32_t o = 0; o < n_ops; o += 3) {  // three operands' loads in flight together
-          const u32x4 w0 = load_half(o, tile, h);
-          u32x4 w1 = w0, w2 = w0;
-          if (o + 1 < n_ops) w1 = load_half(o + 1, tile, h);
-          if (o + 2 < n_ops) w2 = load_half(o + 2, tile, h);
-          // (the block-max loads are older than the operands': no extra wait)
-          if (h == 0 && o == 0 && bound != 0) qmask = fast_quarter_mask<T>(fq, bmw, bound);
+        w[h][0] = load_half(0, tile, h);
+        w[h][1] = load_half(o1, tile, h);
+        w[h][2] = load_half(o2, tile, h);
+      }
+      if (bound != 0) qmask = fast_quarter_mask<T>(fq, lane, raw, bound);
 #pragma unroll
-          for (int u = 0; u < 3; ++u) {
-            if (o + u >= n_ops) break;  // wave-uniform
-            const u32x4 w = u == 0 ? w0 : u == 1 ? w1 : w2;
-            const uint32_t code = fq->ops[o + u].code;
-            const uint32_t x[4] = {w.x, w.y, w.z, w.w};
-            const uint32_t kind = wave_uniform(code & 15u);
-            // (scalar branches on the wave-uniform kind: written as selects this was three ALU ops + two v_cndmask per word)
-            if (kind == kFastAnd) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) a[h * 4 + j] &= x[j];
-            } else if (kind == kFastOr) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) a[h * 4 + j] |= x[j];
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) a[h * 4 + j] &= ~x[j];
-            }
-            const uint32_t cmask = wave_uniform(code >> 8);
-            if (cmask) {  // funnel counters taken after this operand (search_pipeline.h:58-65)
-              uint32_t pc = 0;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) pc += __popc(a[h * 4 + j]);
-              if (cmask & 1u) cnt0 += pc;
-              if (cmask & 2u) cnt1 += pc;
-              if (cmask & 4u) cnt2 += pc;
-              if (cmask & 8u) cnt3 += pc;
-            }
-          }
-        }
+      for (int h = 0; h < 2; ++h) {
+        combine(h, 0, w[h][0]);
+        if (n_ops > 1u) combine(h, 1, w[h][1]);
+        if (n_ops > 2u) combine(h, 2, w[h][2]);
+        for (uint32_t o = 3; o < n_ops; ++o) combine(h, o, load_half(o, tile, h));  // (rare: one at a time)
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) cnt_res += __popc(a[j]);  // every match counts ...
