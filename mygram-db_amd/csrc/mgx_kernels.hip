@@ -1487,14 +1487,18 @@ __global__ __launch_bounds__(kWaveBlock, 6) void wave_score_lists_kernel(DevInde
 #endif
 constexpr int kFastPerLane = MGX_FPL;               // matches per lane scored in one round: their gathers fly together
 constexpr uint32_t kFastRound = 64 * kFastPerLane;  // matches per round
+// Surviving 32-doc words wait as (first doc slot, bits) pairs until 64 of them can be expanded by 64 lanes at once: up to
+// 63 left from earlier tiles plus the 256 a half tile can add.
+constexpr uint32_t kFastPairs = 320;
 
 struct FastOffsets {
-  uint32_t ktab, ring, tk_keys, tk_docs, misc, total;
+  uint32_t ktab, pairs, ring, tk_keys, tk_docs, misc, total;
 };
 __host__ __device__ inline FastOffsets carve_fast(const FastPlan& p) {
   FastOffsets o;
   uint32_t at = 0;
   o.ktab = at;     at += 256 * 8;
+  o.pairs = at;    at += kFastWaves * kFastPairs * 8;
   o.ring = at;     at += kFastWaves * p.ring * 4;
   o.tk_keys = at;  at += kFastWaves * 2 * p.max_cap * 8;
   o.tk_docs = at;  at += kFastWaves * 2 * p.max_cap * 4;
@@ -1623,6 +1627,7 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = wave_uniform(tid >> 6);
   double* const ktab = reinterpret_cast<double*>(smem + fo.ktab);
   uint32_t* const ring = reinterpret_cast<uint32_t*>(smem + fo.ring) + wave * plan.ring;
+  uint2* const pairs = reinterpret_cast<uint2*>(smem + fo.pairs) + wave * kFastPairs;
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + fo.misc);
   const uint32_t n_ops = fq->n_ops;
   const bool desc = fq->descending != 0;
@@ -1666,6 +1671,7 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
 
   uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0, cnt_res = 0;
   uint32_t pend = 0;  // matches waiting in the ring (wave-uniform)
+  uint32_t np = 0;    // pairs waiting to be expanded (wave-uniform)
 
   // scores ring[g0 .. g0+n), n <= kFastRound: one match per lane and step, kFastPerLane steps whose T + 1 byte gathers
   // are all requested before the first is looked at
@@ -1744,7 +1750,6 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
   for (uint32_t tile = tile_begin + wave;; tile += kFastWaves) {
     const bool flush = tile >= tile_end;  // wave-uniform
     uint32_t a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t mine = 0;
     uint64_t bound = 0;  // the k-th best key this tile's quarter bits were made against (wave-uniform)
     if (!flush) {
       wave_topk_refresh_gbound(tk);
@@ -1818,80 +1823,109 @@ __device__ __forceinline__ void bitmap_score_body(const DevIndex& ix, const DevB
           a[j] &= ((m2 & 1u) ? 0x0000FFFFu : 0u) | ((m2 & 2u) ? 0xFFFF0000u : 0u);
         }
       }
+      if (MGX_ABLATE(bt, 2u)) {  // (ablation: operands + counts + pruning only)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) mine += __popc(a[j]);
-      if (MGX_ABLATE(bt, 2u)) mine = 0;  // (ablation: operands + counts + pruning only)
+        for (int j = 0; j < 8; ++j) a[j] = 0;
+      }
     }
 
-    // ---- B. append the surviving matches (doc slots) to the wave's buffer; C. score every full round -----------------
+    // ---- B. queue the surviving 32-doc words as (first doc slot, bits) pairs — a ballot and a compacted write per word,
+    //         nothing per match; C. whenever 64 pairs wait, every lane expands ONE pair into the slot buffer and the full
+    //         rounds are scored. (Expanding per tile visit, as this kernel first did, ran the per-lane bit loops with a
+    //         handful of lanes busy — after pruning most visits leave a few matches in a few lanes — and cost a prefix
+    //         sum per visit.)
     const uint32_t slot0 = tile * kTileDocs + lane * 256u;
-    for (;;) {
-      uint32_t n_new;
-      const uint32_t my_first = wave_excl_scan_total(mine, &n_new);
-      bool more = false;  // wave-uniform: bits left in a[] after this round
-      if (n_new != 0) {
-        const uint32_t space = plan.ring - pend;
-        uint32_t r = my_first;
-        mine = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          uint32_t x = a[j];
-          while (x != 0 && r < space) {
-            ring[pend + r] = slot0 + j * 32 + static_cast<uint32_t>(__builtin_ctz(x));
-            x &= x - 1;
-            ++r;
-          }
-          a[j] = x;
-          mine += __popc(x);
-        }
-        more = n_new > space;
-        pend = more ? plan.ring : pend + n_new;
-        wave_lds_sync();
-      }
-      const bool fin = flush && !more;  // the wave's last pass: the partial round is scored too
-      uint32_t g0 = 0;
-      for (;;) {
-        const uint32_t n = min(pend - g0, kFastRound);
-        if (n == 0 || (n < kFastRound && !fin)) break;
-        if (!MGX_ABLATE(bt, 1u)) score_round(g0, n);  // (ablation: enumerate, do not score)
-#ifdef MGX_ABLATION
-        if (MGX_ABLATE(bt, 64u) && lane == 0) cnt3 += n;  // (debug: after_filters reports the matches that were scored)
-#endif
-        g0 += n;
-      }
+    bool scored = false;  // wave-uniform: a round was scored since this tile's quarter bits were made
+#pragma nounroll
+    for (uint32_t part = 0; part < 2u; ++part) {
+      if (!flush) {
 #ifndef MGX_NO_REMASK
-      // A tile with more matches than the buffer holds (a heavy query) is scored in chunks: the page's bound has
-      // usually moved meanwhile, and the matches still in a[] are held against the new one before they are enumerated.
-      if (more && prune) {
-        wave_topk_refresh_gbound(tk);
-        uint64_t nb = tk.gbound;
-        if (tk.have >= tk.needed && tk.bound_key > nb) nb = tk.bound_key;
-        if (nb > bound) {
-          bound = nb;
-          const uint32_t qm = fast_remask<T>(fq, tile, lane, nb);
-          mine = 0;
+        // The page's bound has moved while the first half's matches were scored (a heavy tile): the second half is held
+        // against the new one before it is queued.
+        if (part != 0u && scored && prune) {
+          wave_topk_refresh_gbound(tk);
+          uint64_t nb = tk.gbound;
+          if (tk.have >= tk.needed && tk.bound_key > nb) nb = tk.bound_key;
+          if (nb > bound) {
+            bound = nb;
+            const uint32_t qm = fast_remask<T>(fq, tile, lane, nb);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const uint32_t m2 = qm >> (2 * j);
-            a[j] &= ((m2 & 1u) ? 0x0000FFFFu : 0u) | ((m2 & 2u) ? 0xFFFF0000u : 0u);
-            mine += __popc(a[j]);
+            for (int j = 4; j < 8; ++j) {
+              const uint32_t m2 = qm >> (2 * j);
+              a[j] &= ((m2 & 1u) ? 0x0000FFFFu : 0u) | ((m2 & 2u) ? 0xFFFF0000u : 0u);
+            }
+          }
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = part != 0u ? a[4 + j] : a[j];
+          const uint64_t m = __ballot(w != 0u);
+          if (m != 0) {  // wave-uniform
+            if (w != 0u) {
+              const uint32_t at = np + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+              pairs[at] = make_uint2(slot0 + (part * 4u + j) * 32u, w);
+            }
+            np += static_cast<uint32_t>(__popcll(m));
           }
         }
       }
+      for (;;) {  // batches of 64 pairs, newest first (the order of matches is immaterial)
+        if (np < 64u && !(flush && (np != 0u || pend != 0u))) break;
+        const uint32_t take = min(np, 64u);
+        wave_lds_sync();
+        uint32_t base = 0, bits = 0;
+        if (lane < take) {
+          const uint2 pv = pairs[np - take + lane];
+          base = pv.x;
+          bits = pv.y;
+        }
+        np -= take;
+        for (;;) {  // ... expanded in chunks the slot buffer has room for
+          uint32_t n_new;
+          const uint32_t my_first = wave_excl_scan_total(static_cast<uint32_t>(__popc(bits)), &n_new);
+          bool more = false;  // wave-uniform: bits of this batch left for the next chunk
+          if (n_new != 0) {
+            const uint32_t space = plan.ring - pend;
+            uint32_t r = my_first;
+            while (bits != 0 && r < space) {
+              ring[pend + r] = base + static_cast<uint32_t>(__builtin_ctz(bits));
+              bits &= bits - 1;
+              ++r;
+            }
+            more = n_new > space;
+            pend = more ? plan.ring : pend + n_new;
+            wave_lds_sync();
+          }
+          const bool fin = flush && !more && np == 0u;  // the wave's last chunk: the partial round is scored too
+          uint32_t g0 = 0;
+          for (;;) {
+            const uint32_t n = min(pend - g0, kFastRound);
+            if (n == 0 || (n < kFastRound && !fin)) break;
+            if (!MGX_ABLATE(bt, 1u)) score_round(g0, n);  // (ablation: enumerate, do not score)
+#ifdef MGX_ABLATION
+            if (MGX_ABLATE(bt, 64u) && lane == 0) cnt3 += n;  // (debug: after_filters reports the matches that were scored)
 #endif
-      if (g0 != 0) {  // move the (< kFastRound) leftover to the front: sources sit at >= kFastRound, destinations below
-        const uint32_t left = pend - g0;
-        uint32_t v[kFastPerLane];
+            g0 += n;
+            scored = true;
+          }
+          if (g0 != 0) {  // move the (< kFastRound) leftover to the front: sources sit at >= kFastRound, destinations below
+            const uint32_t left = pend - g0;
+            uint32_t v[kFastPerLane];
 #pragma unroll
-        for (int m = 0; m < kFastPerLane; ++m) v[m] = m * 64 + lane < left ? ring[g0 + m * 64 + lane] : 0u;
-        wave_lds_sync();
+            for (int m = 0; m < kFastPerLane; ++m) v[m] = m * 64 + lane < left ? ring[g0 + m * 64 + lane] : 0u;
+            wave_lds_sync();
 #pragma unroll
-        for (int m = 0; m < kFastPerLane; ++m)
-          if (m * 64 + lane < left) ring[m * 64 + lane] = v[m];
-        pend = left;
-        wave_lds_sync();
+            for (int m = 0; m < kFastPerLane; ++m)
+              if (m * 64 + lane < left) ring[m * 64 + lane] = v[m];
+            pend = left;
+            wave_lds_sync();
+          }
+          if (!more) break;
+        }
       }
-      if (!more) break;
+      if (flush) break;
     }
     if (flush) break;
   }
