@@ -183,7 +183,9 @@ def main():
     batch_size = int(os.environ.get("MGX_BENCH_BATCH", "1024"))
     cpu_seconds = float(os.environ.get("MGX_BENCH_CPU_SECONDS", "24"))
     dense = float(os.environ.get("MGX_BENCH_DENSE", "0"))
-    depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (3 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 4)
+    # batches in flight: a batch spends ~1.3 ms of host stages (submit, plan, compile, enqueue, collect) around its device
+    # time, so a small shard (0.3 ms of device per batch) needs six slots to keep the device busy, the whole table four
+    depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (4 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 6)
     planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (physical_cores()[0] - 1) // max(1, world)))
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
@@ -261,28 +263,44 @@ def main():
         call_ms = [0.0, 0.0]  # time the driving thread spends inside submit / wait calls (sum over the timed steps)
 
         def run_steps(k, record):
-            """k steps with `depth` batches in flight: submit step i+depth-1, then wait for step i."""
-            pending = []
+            """k steps with `depth` batches in flight. Two host threads drive the executor, as its interface intends (one
+            submitter, one waiter — search_pipeline::MicroBatcher does the same): building 1024 BatchQuery objects and
+            unpacking 1024 BatchResults are each ~0.1 ms of host work per step, and on a small shard (0.3 ms of device per
+            batch) one thread doing both in turn was the step."""
+            import queue
+            import threading
+            in_flight = threading.Semaphore(depth)
+            tickets = queue.Queue()
             sub_t = {}
-            nxt = 0
-            for _ in range(min(depth - 1, k)):
-                sub_t[nxt] = time.perf_counter()
-                pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10, sort_by_score=by_score)))
-                nxt += 1
-            for i in range(k):
-                if nxt < k:
-                    sub_t[nxt] = time.perf_counter()
-                    pending.append((nxt, ex.submit(qbs[nxt % len(qbs)], limit=10, sort_by_score=by_score)))
-                    nxt += 1
-                    if record:
-                        call_ms[0] += 1e3 * (time.perf_counter() - sub_t[nxt - 1])
-                j, ticket = pending.pop(0)
+            failure = []
+
+            def submitter():
+                try:
+                    for j in range(k):
+                        in_flight.acquire()
+                        sub_t[j] = time.perf_counter()
+                        tickets.put((j, ex.submit(qbs[j % len(qbs)], limit=10, sort_by_score=by_score)))
+                        if record:
+                            call_ms[0] += 1e3 * (time.perf_counter() - sub_t[j])
+                except BaseException as e:  # noqa: BLE001 (handed to the waiting thread)
+                    failure.append(e)
+                    tickets.put(None)
+
+            th = threading.Thread(target=submitter, daemon=True)
+            th.start()
+            for _ in range(k):
+                item = tickets.get()
+                if item is None:
+                    raise failure[0]
+                j, ticket = item
                 w0 = time.perf_counter()
                 out = ex.wait(ticket, outs[j % depth])
+                in_flight.release()
                 if record:
                     lat.append(time.perf_counter() - sub_t[j])
                     call_ms[1] += 1e3 * (time.perf_counter() - w0)
                     timings.append(out[4].copy())
+            th.join()
 
         run_steps(args.warmup, False)
         sync()

@@ -1361,10 +1361,30 @@ struct mgx_batch {
 
 namespace mgx {
 
+// MGX_TRACE_HOST: where a batch's host time goes (microseconds per section, printed by mgx_batch_reset every 64 batches)
+static std::atomic<uint64_t> g_section_us[8];
+static const char* const kSectionNames[8] = {"queries+leaves", "fast-path resolution", "table uploads", "wave tables",
+                                              "items", "launch order", "item uploads", "rest of PrepareInto"};
+struct SectionTimer {
+  static bool On() {
+    static const bool on = std::getenv("MGX_TRACE_HOST") != nullptr;
+    return on;
+  }
+  std::chrono::steady_clock::time_point t;
+  SectionTimer() { if (On()) t = std::chrono::steady_clock::now(); }
+  void Mark(int section) {
+    if (!On()) return;
+    const auto now = std::chrono::steady_clock::now();
+    g_section_us[section] += std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+    t = now;
+  }
+};
+
 static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const std::vector<QuerySpec>& specs) {
   const bool score_mode = mode == kModeScore, df_mode = mode == kModeTextDf, page_mode = mode == kModeDocPage;
   const uint32_t n = static_cast<uint32_t>(g.qids.size());
   if (n == 0) return MGX_OK;
+  SectionTimer sec;
   std::vector<DevQuery> dq(n);
   std::vector<DevLeaf> leaves;
   std::vector<uint32_t> prog;
@@ -1431,6 +1451,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     if (!df_mode) b->list_bytes += 4 * s.list_postings;
   }
   g.plan = PlanLds(max_leaves, max_lds_leaves, max_score, max_stack, max_instr, max_cap, score_mode || df_mode);
+  sec.Mark(0);
   std::vector<uint8_t> on_wave(n, 0);  // 0 general kernel, 1 wave kernel, 2 wave kernel with list operands, 3 fast path
   std::vector<DevFastQuery> fastq;
   std::vector<uint64_t> wave_tables;
@@ -1598,11 +1619,13 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   }
   if (g.plan.bytes > 160 * 1024)
     return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
+  sec.Mark(1);
   MGX_HIP(Upload(g.d_queries, dq.data(), dq.size()));
   MGX_HIP(Upload(g.d_leaves, leaves.data(), leaves.size()));
   MGX_HIP(Upload(g.d_prog, prog.data(), prog.size()));
   MGX_HIP(Upload(g.d_score, score.data(), score.size()));
   MGX_HIP(Upload(g.d_explicit, expl.data(), expl.size(), 4));
+  sec.Mark(2);
   // [n][8] counters followed by [n] pruning bounds: one memset clears both before every execute
   if (score_mode) {
     uint32_t max_limit = 1;
@@ -1633,6 +1656,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   std::vector<uint32_t> ident(n);
   for (uint32_t i = 0; i < n; ++i) ident[i] = i;
   MGX_HIP(Upload(g.d_ident, ident.data(), n));
+  sec.Mark(3);
   // ---- work items: cut every query into runs of tiles of about equal estimated cost ------------------------------
   // cost of one tile ~ 1 (operand fetch, program) + matches/128 (enumeration + scoring); a workgroup gets ~48 units.
   std::vector<DevItem> items;
@@ -1683,6 +1707,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
     list_begin[n] = n_lists;
     item_begin[n] = static_cast<uint32_t>(items.size());
+    sec.Mark(4);
     // Launch order: by doc band (kSortTiles tiles), so concurrent workgroups share operand tiles in L2/MALL; inside a
     // band by the query's largest gram (its bitmap and tf column are the lines the band re-reads most), dealt so that
     // workgroup j — which runs on XCD j % 8 under round-robin dispatch, every XCD with its own L2 — gets a contiguous
@@ -1757,6 +1782,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
     }
   }
+  sec.Mark(5);
   if (!fastq.empty()) MGX_HIP(Upload(g.d_fast_queries, fastq.data(), fastq.size()));
   for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));
   MGX_HIP(Upload(g.d_items_wave_lists, items_wave_lists.data(), items_wave_lists.size()));
@@ -1765,6 +1791,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   MGX_HIP(Upload(g.d_items, items_block.data(), items_block.size()));
   MGX_HIP(Upload(g.d_items_wave, items_wave.data(), items_wave.size()));
   MGX_HIP(Upload(g.d_list_begin, list_begin.data(), list_begin.size()));
+  sec.Mark(6);
   if (std::getenv("MGX_VERBOSE"))
     fprintf(stderr,
             "[mgx] %s group: %u queries; fast path %zu items (lds %u B, ring %u), wave kernel %u items (lds %u B), "
@@ -1929,7 +1956,9 @@ struct CompilePool {
 };
 
 static int CompileAll(const mgx_index* idx, const mgx_query* queries, uint32_t n, std::vector<QuerySpec>* specs) {
-  static CompilePool pool;
+  // one pool per calling thread: an executor's dispatcher threads compile different batches at the same time, and a
+  // shared pool handed its helpers to one of them while the other compiled its 1024 queries alone (4x the time)
+  static thread_local CompilePool pool;
   std::unique_lock<std::mutex> gate(pool.gate, std::try_to_lock);
   if (n < 4 * CompilePool::kChunk || pool.helpers.empty() || !gate.owns_lock()) {
     for (uint32_t i = 0; i < n; ++i) {
@@ -2481,9 +2510,12 @@ int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queri
       const auto t2 = std::chrono::steady_clock::now();
       us_compile += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
       us_into += std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
-      if (++n % 64 == 0)
+      if (++n % 64 == 0) {
         fprintf(stderr, "[mgx] reset x64: CompileQuery loop %.3f ms, reset + PrepareInto %.3f ms per batch\n",
                 us_compile.exchange(0) / 64e3, us_into.exchange(0) / 64e3);
+        for (int k = 0; k < 8; ++k)
+          fprintf(stderr, "[mgx]   %-24s %.3f ms\n", mgx::kSectionNames[k], mgx::g_section_us[k].exchange(0) / 64e6);
+      }
     }
     return rc;
   } catch (const std::exception& e) {

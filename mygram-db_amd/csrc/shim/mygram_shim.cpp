@@ -5,8 +5,10 @@
 #include "../mgx_text.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
@@ -809,10 +811,15 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
 
 // results of one fetched batch -> BatchResult objects, in the order the queries were given
 void Collect(const std::vector<PlannedQuery>& plans, const mgx_result_view& v, std::vector<BatchResult>* out) {
-  out->assign(plans.size(), BatchResult{});
+  out->resize(plans.size());  // (elements a caller hands back keep their vectors' storage: WaitInto)
   size_t k = 0;
   for (size_t qi = 0; qi < plans.size(); ++qi) {
     BatchResult& o = (*out)[qi];
+    o.results.clear();
+    o.scores.clear();
+    o.total = 0;
+    o.total_candidates = o.after_intersection = o.after_not = o.after_filters = 0;
+    o.empty_term_detected = false;
     if (!plans[qi].on_device) {
       o.empty_term_detected = plans[qi].empty_term_detected;
       continue;
@@ -865,7 +872,7 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
 // ---- BatchExecutor ------------------------------------------------------------------------------------------------
 //
 // Submit only queues: a pool of workers plans the batch in chunks of queries (several batches at once when several are
-// queued); dispatcher threads (two) compile planned batches (mgx_batch_reset: host work, one object per slot) and put
+// queued); dispatcher threads (three) compile planned batches (mgx_batch_reset: host work, one object per slot) and put
 // them on the device strictly in ticket order — on a sharded table each execute is followed by a collective that every
 // rank must issue in the same order. Wait blocks until its ticket is on the device, then fetches.
 
@@ -901,6 +908,7 @@ struct BatchExecutor::Impl {
   std::condition_variable cv_work, cv_state;
   std::deque<Chunk> chunks;
   bool stop = false;
+  bool enqueuing = false;  // a dispatcher is inside EnqueueReady's loop (guarded by mu)
 
   Impl(const index::Index& ix, Options o) : index(ix), opt(o) {}
 
@@ -913,6 +921,8 @@ struct BatchExecutor::Impl {
   // host side of one batch after planning: the device queries, compiled into the slot's batch object
   void Compile(Slot* slot) {
     index::Index::Impl* im = index.impl();
+    static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
+    const auto t_in = clock::now();
     slot->mq.clear();
     for (const auto& p : slot->plans) {
       if (p.error != ErrorCode::kSuccess) {
@@ -923,6 +933,11 @@ struct BatchExecutor::Impl {
     }
     slot->timing.device_queries = static_cast<uint32_t>(slot->mq.size());
     if (slot->mq.empty()) return;
+    if (kTrace) {
+      static std::atomic<uint64_t> n{0}, us{0};
+      us += std::chrono::duration_cast<std::chrono::microseconds>(clock::now() - t_in).count();
+      if (++n % 64 == 0) fprintf(stderr, "[shim] gather of the planned queries: %.3f ms per batch\n", us.exchange(0) / 64e3);
+    }
     int rc;
     if (!slot->batch)
       rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
@@ -931,12 +946,18 @@ struct BatchExecutor::Impl {
     if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
   }
 
-  // device side, in ticket order (called with mu held; the calls below only enqueue)
-  void EnqueueReady() {
+  // device side, in ticket order. Called with mu held; the HIP calls themselves (they only enqueue, but a batch is a
+  // dozen of them: ~0.1 ms) run with mu RELEASED — planners, Submit and Wait all take mu — and `enqueuing` keeps them in
+  // one thread at a time: whoever finds it set leaves its batch to that thread, which looks again (under mu) after
+  // every batch it has put on the device.
+  void EnqueueReady(std::unique_lock<std::mutex>& lock) {
+    if (enqueuing) return;
+    enqueuing = true;
     for (;;) {
       Slot* slot = ByTicket(next_enqueue);
-      if (!slot || (slot->state != kCompiled && slot->state != kFailed)) return;
+      if (!slot || (slot->state != kCompiled && slot->state != kFailed)) break;
       if (slot->state == kCompiled && !slot->mq.empty()) {
+        lock.unlock();
         const auto t0 = clock::now();
         void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
         int rc = mgx_batch_stream(slot->batch, &stream);
@@ -946,11 +967,13 @@ struct BatchExecutor::Impl {
         if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
         if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
         slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
+        lock.lock();
       }
       slot->state = slot->error.code() == ErrorCode::kSuccess && slot->state == kCompiled ? kEnqueued : kFailed;
       ++next_enqueue;
       cv_state.notify_all();
     }
+    enqueuing = false;
   }
 
   void Work() {
@@ -974,9 +997,9 @@ struct BatchExecutor::Impl {
   }
 
   // Dedicated threads compile, ticket after ticket (the compile step walks the same arenas and pinned blocks every time:
-  // on whichever planner finished last it cost 2-3x). Two of them take alternate tickets — compiling a batch is ~0.5 ms
+  // on whichever planner finished last it cost 2-3x). Three of them take tickets in turn — compiling a batch is ~0.5 ms
   // of one thread, which on a small shard (0.3 ms of device per batch) was the step — and whoever finishes puts every
-  // batch that is ready on the device IN TICKET ORDER (EnqueueReady, under the lock): the order a sharded table's
+  // batch that is ready on the device IN TICKET ORDER (EnqueueReady: one thread at a time): the order a sharded table's
   // collectives need identical on every rank.
   void Dispatch() {
     std::unique_lock<std::mutex> lock(mu);
@@ -997,7 +1020,7 @@ struct BatchExecutor::Impl {
       slot->timing.compile_ms = std::chrono::duration<double, std::milli>(slot->t_compiled - t_begin).count();
       lock.lock();
       slot->state = slot->error.code() == ErrorCode::kSuccess ? kCompiled : kFailed;
-      EnqueueReady();
+      EnqueueReady(lock);
     }
   }
 };
@@ -1008,7 +1031,7 @@ BatchExecutor::BatchExecutor(const index::Index& index, Options options) : impl_
   impl_->avgdl = index.Bm25AvgDocLength();
   impl_->slots.resize(static_cast<size_t>(std::max(1, options.depth)));
   for (int t = 0; t < std::max(1, options.planner_threads); ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
-  static const int kDispatchers = std::getenv("MGX_DISPATCHERS") ? atoi(std::getenv("MGX_DISPATCHERS")) : 2;
+  static const int kDispatchers = std::getenv("MGX_DISPATCHERS") ? atoi(std::getenv("MGX_DISPATCHERS")) : 3;
   const int n_dispatchers = std::max(1, std::min(kDispatchers, std::max(1, options.depth)));
   for (int t = 0; t < n_dispatchers; ++t) impl_->dispatchers.emplace_back([this] { impl_->Dispatch(); });
 }
@@ -1057,7 +1080,7 @@ Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& querie
   }
   // (outside the lock: freeing the slot's previous queries and plans and sizing the new ones is a few thousand
   // allocations, and the planner threads take the same lock for every chunk)
-  slot->queries = std::move(queries);
+  slot->queries.swap(queries);  // (the caller gets the slot's previous batch back: storage to build its next one in)
   slot->plans.resize(slot->queries.size());  // (elements are reset by the planner that takes them)
   slot->error = Error{ErrorCode::kSuccess, ""};
   slot->timing = Timing{};
@@ -1078,17 +1101,24 @@ Expected<uint64_t, Error> BatchExecutor::Submit(const std::vector<BatchQuery>& q
 }
 
 Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, Timing* timing) {
+  std::vector<BatchResult> out;
+  const Error e = WaitInto(ticket, &out, timing);
+  if (e.code() != ErrorCode::kSuccess) return MakeUnexpected(e);
+  return out;
+}
+
+Error BatchExecutor::WaitInto(uint64_t ticket, std::vector<BatchResult>* results, Timing* timing) {
+  std::vector<BatchResult>& out = *results;
   std::unique_lock<std::mutex> lock(impl_->mu);
   Impl::Slot* s = ticket ? impl_->ByTicket(ticket) : nullptr;
-  if (!s) return MakeUnexpected(MakeError(ErrorCode::kInvalidArgument, "BatchExecutor::Wait: unknown ticket"));
+  if (!s) return MakeError(ErrorCode::kInvalidArgument, "BatchExecutor::Wait: unknown ticket");
   impl_->cv_state.wait(lock, [&] { return s->state == Impl::kEnqueued || s->state == Impl::kFailed; });
   if (s->state == Impl::kFailed) {
     const Error e = s->error;
     s->state = Impl::kFree;
-    return MakeUnexpected(e);
+    return e;
   }
   lock.unlock();  // (the slot is this caller's until it is freed below)
-  std::vector<BatchResult> out;
   mgx_result_view v{};
   const auto t0 = Impl::clock::now();
   if (!s->mq.empty()) {
@@ -1097,7 +1127,7 @@ Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, T
       const Error e = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
       lock.lock();
       s->state = Impl::kFree;
-      return MakeUnexpected(e);
+      return e;
     }
   }
   Collect(s->plans, v, &out);
@@ -1105,7 +1135,7 @@ Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, T
   if (timing) *timing = s->timing;
   lock.lock();
   s->state = Impl::kFree;
-  return out;
+  return Error{ErrorCode::kSuccess, ""};
 }
 
 // ---- MicroBatcher --------------------------------------------------------------------------------------------------

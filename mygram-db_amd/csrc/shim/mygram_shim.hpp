@@ -315,8 +315,13 @@ class BatchExecutor {
   BatchExecutor& operator=(const BatchExecutor&) = delete;
   // -> ticket. Fails (kInvalidArgument) when all `depth` slots hold unfetched batches.
   mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(const std::vector<BatchQuery>& queries);
-  mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(std::vector<BatchQuery>&& queries);  // (no copy)
+  // (no copy; on return `queries` holds the BatchQuery objects of an EARLIER batch — storage a serving loop builds its
+  // next batch in without allocating; clear() or overwrite them)
+  mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(std::vector<BatchQuery>&& queries);
   mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> Wait(uint64_t ticket, Timing* timing = nullptr);
+  // Wait into a vector the caller keeps from batch to batch (its elements' vectors are re-used: no allocation in steady
+  // state); the returned Error's code is kSuccess on success.
+  mygram::utils::Error WaitInto(uint64_t ticket, std::vector<BatchResult>* results, Timing* timing = nullptr);
 
  private:
   struct Impl;

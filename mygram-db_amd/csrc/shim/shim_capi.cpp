@@ -22,6 +22,7 @@ struct mgxs_table {
 struct mgxs_executor {
   std::unique_ptr<BatchExecutor> ex;
   std::vector<BatchQuery> queries;  // re-used between submits
+  std::vector<mygramdb::search_pipeline::BatchResult> results;  // re-used between waits
   uint32_t limit = 0;
 };
 
@@ -142,17 +143,22 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
     ex->queries.resize(n_queries);
     size_t at = 0;
     for (uint32_t i = 0; i < n_queries; ++i) {
-      BatchQuery& q = ex->queries[i];
-      q.terms.clear();
-      for (uint32_t t = 0; t < n_terms[i]; ++t) q.terms.emplace_back(terms[at++]);
+      BatchQuery& q = ex->queries[i];  // (possibly an earlier batch's object: every field is set again)
+      q.terms.resize(n_terms[i]);
+      for (uint32_t t = 0; t < n_terms[i]; ++t) q.terms[t].assign(terms[at++]);
+      q.ast.reset();
+      q.not_terms.clear();
+      q.filters.clear();
+      q.fuzzy_max_distance = 0;
+      q.verify_text = false;
+      q.bm25 = mygramdb::index::BM25Params{};
       q.sort_by_score = sort_by_score != 0;
       q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
       q.limit = limit;
       q.offset = offset;
     }
     ex->limit = limit;
-    auto r = ex->ex->Submit(std::move(ex->queries));
-    ex->queries.clear();
+    auto r = ex->ex->Submit(std::move(ex->queries));  // (hands an earlier batch's objects back: built into again above)
     if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
     *ticket = *r;
     return MGX_OK;
@@ -166,9 +172,9 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
   if (!ex || !totals || !n_docs || !docs) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_wait: null argument");
   try {
     BatchExecutor::Timing tm;
-    auto r = ex->ex->Wait(ticket, &tm);
-    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
-    const auto& res = *r;
+    const auto err = ex->ex->WaitInto(ticket, &ex->results, &tm);
+    if (err.code() != mygram::utils::ErrorCode::kSuccess) return Fail(static_cast<int>(err.code()), err.message());
+    const auto& res = ex->results;
     for (size_t i = 0; i < res.size(); ++i) {
       totals[i] = res[i].total;
       const size_t n = res[i].results.size();
