@@ -391,6 +391,28 @@ int main() {
         EXPECT((*rb)[0].scores.size() == 1 && (*rb)[0].scores[0] == (*ra)[0].scores[1]);
       }
     }
+    // the allocation-free serving loop: Submit(vector&&) hands an earlier batch's objects back, WaitInto fills a vector
+    // the caller keeps (entries of a previous, LARGER batch must not leak into a smaller one)
+    std::vector<BatchQuery> build;
+    std::vector<BatchResult> kept;
+    for (int round = 0; round < 4; ++round) {
+      const bool big = round % 2 == 0;
+      build.resize(big ? 2 : 1);
+      for (auto& q : build) q = BatchQuery{};
+      build[0].terms = {"learning"};
+      build[0].sort_by_score = true;
+      build[0].limit = 10;
+      if (big) build[1].terms = {"cats"};
+      auto t = ex.Submit(std::move(build));
+      EXPECT(t.has_value());
+      if (!t) break;
+      const auto err = ex.WaitInto(*t, &kept);
+      EXPECT(err.code() == mygram::utils::ErrorCode::kSuccess);
+      EXPECT(kept.size() == (big ? 2u : 1u));
+      EXPECT(kept[0].total == 2 && kept[0].results.size() == 2 && kept[0].scores.size() == 2);
+      if (big) EXPECT(kept[1].results == (V{3}));
+    }
+    EXPECT(ex.WaitInto(12345, &kept).code() != mygram::utils::ErrorCode::kSuccess);  // unknown ticket
   }
   {  // No silent empty result (the reference tests its own allocation failure path,
      // tests/index/posting_list_test.cpp:188-228): with device allocations failing, the reference-signature methods
