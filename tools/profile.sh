@@ -18,7 +18,9 @@ run() { # name, rocprofv3 options...
   (cd /tmp && rocprofv3 "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1) || echo "pass $name failed"
   echo "pass $name done"
 }
-run stats --stats
+# (one batch in flight for the duration pass: with the default four, launches of different batches overlap on the device
+#  and stretch each other — the trace then averages 1.3 ms for a kernel that takes 0.86 ms alone)
+MGX_BENCH_DEPTH=${MGX_BENCH_DEPTH:-1} run stats --stats
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 run sq2 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_WAVES
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum
