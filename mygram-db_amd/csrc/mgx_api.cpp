@@ -2213,7 +2213,12 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
   }
   if (!b->score.qids.empty()) {
     mgx_batch::Group& g = b->score;
-    MGX_HIP(hipMemsetAsync(b->d_score_out.p, 0, b->so_override, s));
+    size_t clear_bytes = b->so_override;
+#ifdef MGX_ABLATION
+    // (timing experiment: keep the pruning bounds of the batch's previous execute = "the final bound known from the start")
+    if (std::getenv("MGX_KEEP_BOUNDS")) clear_bytes = b->score.qids.size() * 8 * 8;
+#endif
+    MGX_HIP(hipMemsetAsync(b->d_score_out.p, 0, clear_bytes, s));
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
