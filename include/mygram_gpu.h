@@ -320,6 +320,20 @@ int mgx_comm_create(const uint8_t* id, int rank, int world, int device, mgx_comm
 void mgx_comm_destroy(mgx_comm* comm);
 int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
 int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
+/* mgx_batch_execute for a shard of a table (every rank calls it for the same batch, in the same order; follow it with
+ * mgx_batch_exchange): SORT _score batches run their seed items first, all-gather the seeds' best keys (ONE small
+ * ncclAllGather: offset+limit keys per query and rank) and raise every query's pruning bound to the (offset+limit)-th best
+ * key of the union before the rest of the batch runs — a shard's own matches give a weak bound (top-k is a property of
+ * the whole table). The shard's LOCAL page may then hold fewer than offset+limit docs: those it lacks are on no rank's
+ * share of the table-wide page; totals and funnel counters are unaffected. Other batches: as mgx_batch_execute. The
+ * exchange is entered (by every rank or by none: the decision uses the queries and the world size only) for tables cut
+ * at least eight ways into shards of a million docs and more; MGX_SEED_EXCHANGE=1/0 forces it on/off. */
+int mgx_batch_execute_sharded(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
+/* The same with the caller's transport (a test's gloo all-gather, MPI, ...): `gather` must fill all[r * bytes ..] with
+ * rank r's `mine` for every rank (both are DEVICE buffers of the batch; the call may enqueue on hip_stream or block) and
+ * return MGX_OK. */
+typedef int (*mgx_gather_fn)(void* user, const void* mine, void* all, uint64_t bytes, void* hip_stream);
+int mgx_batch_execute_gather(mgx_batch* batch, int world, mgx_gather_fn gather, void* user, void* hip_stream);
 /* Text-level terms across shards: df must be table-wide before idf is taken. mgx_batch_count_df enqueues only the df
  * pass of the batch's text-level terms; mgx_batch_df_buffer exposes the DEVICE array of their counts (u64 per DISTINCT
  * term of the batch, in order of first appearance — the same on every shard), which the caller sums over ranks in place (one RCCL all-reduce); the next

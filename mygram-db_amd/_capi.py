@@ -15,6 +15,9 @@ GRAM_ABSENT = 0xFFFFFFFF
 SORT_DOCID, SORT_SCORE = 0, 1
 
 # every symbol include/mygram_gpu.h and include/mygram_tools.h declare
+# int (*mgx_gather_fn)(void* user, const void* mine, void* all, uint64_t bytes, void* hip_stream)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
 EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
     "mgx_columns_build", "mgx_columns_from_mgix", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
@@ -22,7 +25,7 @@ EXPORTS = [
     "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy",
-    "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
+    "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_execute_sharded", "mgx_batch_execute_gather", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
     "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth", "mgxt_fail_device_allocs",
 ]
@@ -141,6 +144,8 @@ def load():
     L.mgx_comm_destroy.argtypes = [vp]
     L.mgx_comm_destroy.restype = None
     L.mgx_batch_exchange.argtypes = [vp, vp, vp]
+    L.mgx_batch_execute_sharded.argtypes = [vp, vp, vp]
+    L.mgx_batch_execute_gather.argtypes = [vp, C.c_int, GATHER_FN, vp, vp]
     L.mgx_batch_exchange_df.argtypes = [vp, vp, vp]
     L.mgx_batch_algorithmic_bytes.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgx_batch_kernel_time_ms.argtypes = [vp, C.POINTER(f64), C.POINTER(u32)]

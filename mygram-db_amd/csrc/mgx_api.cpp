@@ -147,8 +147,8 @@ struct BatchResources {
   bool copy_issued = false;
   // mgx_batch_exchange: this rank's blob (docid pages only) and every rank's. They belong to the slot, not to one batch:
   // a hipFree / hipMalloc per reset would synchronise the device once per step.
-  void* xchg[2] = {nullptr, nullptr};
-  size_t xchg_cap[2] = {0, 0};
+  void* xchg[4] = {nullptr, nullptr, nullptr, nullptr};  // 0/1: the top-k exchange, 2/3: the seed-bound exchange
+  size_t xchg_cap[4] = {0, 0, 0, 0};
   hipError_t Exchange(int which, size_t bytes, void** out_ptr) {
     if (xchg_cap[which] < bytes) {
       if (xchg[which]) (void)hipFree(xchg[which]);
@@ -1298,6 +1298,10 @@ struct mgx_batch {
     // score mode, fast path (bitmap_score_kernel<T>): resolved query descriptors and one item list per number of scored terms
     mgx::FastPlan fplan{};
     mgx::DevBatch dev_fast[mgx::kFastMaxScore]{};
+    uint32_t n_seed_fast[mgx::kFastMaxScore] = {0, 0, 0, 0, 0};  // seed items at the front of d_items_fast[t]
+    uint32_t seed_k = 0;       // keys per query in the seed-bound exchange (0: none; rank-independent, see UploadGroup)
+    uint64_t seed_table_docs = 0;  // table-wide doc count of those queries (BM25 N): the exchange pays on large shards only
+    DevBuf d_has_seed;         // [n] u8: the query's first candidate list is a seed item's
     DevBuf d_fast_queries, d_items_fast[mgx::kFastMaxScore];
     // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
     mgx::DevBatch dev_page_wave{}, dev_page_block{};
@@ -1772,6 +1776,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   }
   const uint32_t n_lists_all = n_lists;
   std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore];
+  std::vector<uint8_t> has_seed(n, 0);
+  uint32_t seed_k = 0;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0: the fast path's seed items (a query's first list), then the rest
     for (const DevItem& it : items) {
       const uint8_t w = on_wave[it.query];
@@ -1780,8 +1786,27 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       if (seed != (pass == 0)) continue;
       if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
       else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
+      if (seed && fastq[it.query].blockmax != 0) has_seed[it.query] = 1;  // (a query that prunes: its seed's keys are worth sharing)
+    }
+    if (pass == 0)
+      for (int t = 0; t < kFastMaxScore; ++t) g.n_seed_fast[t] = static_cast<uint32_t>(items_fast[t].size());
+  }
+  // The shape of the seed-key exchange of a sharded table must be the same on every rank, whatever this shard's own
+  // index looks like (a gram may be a bitmap here and a list there, a shard a tile shorter): it is made from the QUERIES
+  // alone — keys per query = the largest page of the group's SORT _score DESC queries that fit the fast path's lists —
+  // and a query without a seed on this rank contributes zeros.
+  g.seed_table_docs = 0;
+  if (score_mode) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const QuerySpec& sp = specs[g.qids[i]];
+      if (sp.reverse != 0 && dq[i].needed != 0 && dq[i].needed <= 128u) {
+        seed_k = std::max(seed_k, dq[i].needed);
+        g.seed_table_docs = std::max<uint64_t>(g.seed_table_docs, sp.total_docs);
+      }
     }
   }
+  g.seed_k = seed_k;
+  if (seed_k) MGX_HIP(Upload(g.d_has_seed, has_seed.data(), has_seed.size()));
   sec.Mark(5);
   if (!fastq.empty()) MGX_HIP(Upload(g.d_fast_queries, fastq.data(), fastq.size()));
   for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));
@@ -2167,7 +2192,17 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
   return MGX_OK;
 }
 
-static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
+// Sharded tables: between a score group's seed launch and its main launch, every rank's seed keys are all-gathered (by
+// the caller's transport: RCCL in mgx_batch_execute_sharded, anything in mgx_batch_execute_gather) and each query's bound
+// is raised to the needed-th best of their union.
+struct SeedGather {
+  int world = 1;
+  mgx_gather_fn fn = nullptr;
+  void* user = nullptr;
+};
+static int SeedBoundExchange(mgx_batch* b, mgx_batch::Group& g, const SeedGather& sg, hipStream_t s);
+
+static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullptr) {
   mgx_index* idx = b->idx;
   MGX_HIP(hipSetDevice(idx->device));
   {
@@ -2240,8 +2275,30 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s) {
     }
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
     MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side));
-    for (int t = 0; t < kFastMaxScore; ++t)
-      MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
+    // (both conditions are the same on every rank: the collective is entered by all or by none)
+    static const uint64_t kMinShardDocs = std::getenv("MGX_SEED_EXCHANGE_MIN_DOCS") ? static_cast<uint64_t>(atoll(std::getenv("MGX_SEED_EXCHANGE_MIN_DOCS"))) : 1000000ull;
+    if (sg && sg->fn && g.seed_k != 0 && g.seed_table_docs / static_cast<uint64_t>(sg->world) >= kMinShardDocs) {
+      // doc-range shards: a shard's own matches give a weak bound (a 1.25M-doc shard scores 22 % of its matches where
+      // the whole table scores 7 %); the seeds of ALL shards together are a sample of the whole table
+      for (int t = 0; t < kFastMaxScore; ++t) {
+        DevBatch seeds = g.dev_fast[t];
+        seeds.n_items = g.n_seed_fast[t];
+        MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, seeds, g.fplan, s));
+      }
+      {
+        const int rc = SeedBoundExchange(b, g, *sg, s);
+        if (rc) return rc;
+      }
+      for (int t = 0; t < kFastMaxScore; ++t) {
+        DevBatch rest = g.dev_fast[t];
+        rest.items += g.n_seed_fast[t];
+        rest.n_items -= g.n_seed_fast[t];
+        MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, rest, g.fplan, s));
+      }
+    } else {
+      for (int t = 0; t < kFastMaxScore; ++t)
+        MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
+    }
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
     if (side != s) {
       MGX_HIP(hipEventRecord(b->res->join_ev, side));
@@ -2823,6 +2880,57 @@ int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
   char* g = static_cast<char*>(recv);
   return mgx_batch_merge_shards(batch, static_cast<uint32_t>(comm->world), reinterpret_cast<const uint64_t*>(g),
                                 bytes / 8, reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, s);
+}
+
+namespace mgx {
+static int SeedBoundExchange(mgx_batch* b, mgx_batch::Group& g, const SeedGather& sg, hipStream_t s) {
+  const uint32_t n = static_cast<uint32_t>(g.qids.size()), k = g.seed_k;
+  const uint64_t bytes = static_cast<uint64_t>(n) * k * 8;
+  void* mine = nullptr;
+  void* all = nullptr;
+  MGX_HIP(b->res->Exchange(2, bytes, &mine));
+  MGX_HIP(b->res->Exchange(3, bytes * static_cast<uint64_t>(sg.world), &all));
+  MGX_LAUNCH(LaunchPackSeedKeys(g.d_list_begin.as<uint32_t>(), g.d_has_seed.as<uint8_t>(), g.dev.cand_keys, g.dev.cand_n,
+                                g.dev.cand_stride, n, k, static_cast<uint64_t*>(mine), s));
+  if (std::getenv("MGX_VERBOSE"))
+    fprintf(stderr, "[mgx] seed-bound exchange: %u queries x %u keys, world %d\n", n, k, sg.world);
+  const int grc = sg.fn(sg.user, mine, all, bytes, s);
+  if (grc != MGX_OK) return grc == MGX_ERR_INTERNAL && !g_last_error.empty() ? grc : Fail(grc, "the seed-key all-gather failed");
+  MGX_LAUNCH(LaunchApplySeedBounds(static_cast<const uint64_t*>(all), static_cast<uint32_t>(sg.world), n, k, g.dev.queries,
+                                   g.dev.bounds, s));
+  return MGX_OK;
+}
+static int RcclGather(void* user, const void* mine, void* all, uint64_t bytes, void* hip_stream) {
+  const int nrc = LoadRccl().AllGather(mine, all, bytes, kRcclUint8, user, static_cast<hipStream_t>(hip_stream));
+  return nrc != 0 ? RcclFail("ncclAllGather (seed keys)", nrc) : MGX_OK;
+}
+}  // namespace mgx
+
+int mgx_batch_execute_gather(mgx_batch* batch, int world, mgx_gather_fn gather, void* user, void* hip_stream) {
+  if (!batch || !gather || world < 1) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_execute_gather: bad argument");
+  try {
+    hipStream_t s = nullptr;
+    int rc = mgx::BatchStream(batch, hip_stream, &s);
+    if (rc) return rc;
+    mgx::SeedGather sg;
+    sg.world = world;
+    sg.fn = gather;
+    sg.user = user;
+    // Splitting the launch costs ~0.03 ms per batch (the main items wait for every seed, two small kernels, the
+    // collective) and buys a bound made from world x 8 tiles instead of 8: measured on one GPU only the cost shows
+    // (0.375 -> 0.405 ms per step on a 1.25M-doc shard), and the ceiling of any better start is 24 % of that shard's
+    // kernel — so by default only tables cut at least eight ways take it. MGX_SEED_EXCHANGE=1 / 0 forces.
+    static const int forced = std::getenv("MGX_SEED_EXCHANGE") ? atoi(std::getenv("MGX_SEED_EXCHANGE")) : -1;
+    const bool on = forced >= 0 ? forced != 0 : world >= 8;
+    return mgx::ExecuteImpl(batch, s, on ? &sg : nullptr);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_execute_gather: ") + e.what());
+  }
+}
+
+int mgx_batch_execute_sharded(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
+  if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_execute_sharded: null argument");
+  return mgx_batch_execute_gather(batch, comm->world, &mgx::RcclGather, comm->comm, hip_stream);
 }
 
 int mgx_batch_algorithmic_bytes(mgx_batch* batch, uint64_t* list_bytes, uint64_t* score_bytes,

@@ -2920,6 +2920,77 @@ int LaunchBitmapScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, 
   }
 }
 
+// ---- seed-bound exchange of a sharded table (mgx_batch_execute_sharded) -----------------------------------------------
+// out[q][k]: the best min(k, cand_n) keys of query q's seed list (its first candidate list, best first), 0 beyond — and
+// all 0 for a query without a seed.
+__global__ __launch_bounds__(256) void pack_seed_keys_kernel(const uint32_t* __restrict__ list_begin,
+                                                             const uint8_t* __restrict__ has_seed,
+                                                             const uint64_t* __restrict__ cand_keys,
+                                                             const uint32_t* __restrict__ cand_n, uint32_t cand_stride,
+                                                             uint32_t n, uint32_t k, uint64_t* __restrict__ out) {
+  const uint64_t idx = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= static_cast<uint64_t>(n) * k) return;
+  const uint32_t q = static_cast<uint32_t>(idx / k), j = static_cast<uint32_t>(idx % k);
+  uint64_t v = 0;
+  if (has_seed[q]) {
+    const uint32_t list = list_begin[q];
+    if (j < cand_n[list] && j < cand_stride) v = cand_keys[static_cast<uint64_t>(list) * cand_stride + j];
+  }
+  out[idx] = v;
+}
+
+// One wave per query. all[r][q][k]: rank r's seed keys of query q, best first, zeros at the end. The query's bound is
+// raised to the needed-th best key of the union: at least `needed` docs of the TABLE score that or better, so a doc with
+// a strictly smaller key is on no rank's share of the page (equal keys are kept everywhere: the docid decides in the merge).
+__global__ __launch_bounds__(64) void apply_seed_bounds_kernel(const uint64_t* __restrict__ all, uint32_t world, uint32_t n,
+                                                               uint32_t k, const DevQuery* __restrict__ queries,
+                                                               unsigned long long* __restrict__ bounds) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  if (q >= n) return;
+  const uint32_t needed = queries[q].needed;
+  if (needed == 0 || needed > k * world) return;
+  uint64_t best = 0;
+  for (uint32_t c = lane; c < world * k; c += 64) {
+    const uint64_t x = all[(static_cast<uint64_t>(c / k) * n + q) * k + c % k];
+    if (x == 0) continue;
+    uint32_t count = 0;  // keys of the union that are >= x
+    for (uint32_t r = 0; r < world; ++r) {
+      const uint64_t* lst = all + (static_cast<uint64_t>(r) * n + q) * k;  // descending, zeros last
+      uint32_t lo = 0, hi = k;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (lst[mid] >= x) lo = mid + 1; else hi = mid;
+      }
+      count += lo;
+    }
+    if (count >= needed && x > best) best = x;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint64_t o = __shfl_down(best, d, 64);
+    best = o > best ? o : best;
+  }
+  if (lane == 0 && best != 0) atomicMax(&bounds[q], static_cast<unsigned long long>(best));
+}
+
+int LaunchPackSeedKeys(const uint32_t* list_begin, const uint8_t* has_seed, const uint64_t* cand_keys, const uint32_t* cand_n,
+                       uint32_t cand_stride, uint32_t n, uint32_t k, uint64_t* out, hipStream_t s) {
+  const uint64_t total = static_cast<uint64_t>(n) * k;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(pack_seed_keys_kernel, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, s, list_begin,
+                     has_seed, cand_keys, cand_n, cand_stride, n, k, out);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchApplySeedBounds(const uint64_t* all, uint32_t world, uint32_t n, uint32_t k, const DevQuery* queries,
+                          unsigned long long* bounds, hipStream_t s) {
+  if (n == 0 || k == 0) return 0;
+  hipLaunchKernelGGL(apply_seed_bounds_kernel, dim3(n), dim3(64), 0, s, all, world, n, k, queries, bounds);
+  MGX_KCHECK();
+  return 0;
+}
+
 // read-only streaming probe: the box's attainable HBM read bandwidth, the second roofline denominator of bench.py
 typedef uint32_t probe_vec4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read_probe_kernel(const probe_vec4* __restrict__ src, uint64_t n_vec, uint32_t* sink) {

@@ -33,6 +33,11 @@ int LaunchExportPages(const DevQuery* queries, uint32_t n, uint32_t stride, cons
                       const uint64_t* totals, uint64_t* blob64, uint32_t* blob32, hipStream_t s);
 int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_queries, uint64_t pitch, uint64_t* out,
                     hipStream_t s);
+// seed-bound exchange of a sharded table: pack every query's seed keys / raise its bound to the needed-th best of all ranks'
+int LaunchPackSeedKeys(const uint32_t* list_begin, const uint8_t* has_seed, const uint64_t* cand_keys, const uint32_t* cand_n,
+                       uint32_t cand_stride, uint32_t n, uint32_t k, uint64_t* out, hipStream_t s);
+int LaunchApplySeedBounds(const uint64_t* all, uint32_t world, uint32_t n, uint32_t k, const DevQuery* queries,
+                          unsigned long long* bounds, hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
                     uint64_t* totals, hipStream_t s);
 int LaunchExpand(const uint64_t* rbits, const uint64_t* tile_start, const uint64_t* totals, const uint64_t* take,

@@ -963,7 +963,8 @@ struct BatchExecutor::Impl {
         int rc = mgx_batch_stream(slot->batch, &stream);
         mgx_comm* comm = opt.comm;
         if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
-        if (rc == MGX_OK) rc = mgx_batch_execute(slot->batch, stream);                    // asynchronous
+        if (rc == MGX_OK)                                                                 // asynchronous
+          rc = comm ? mgx_batch_execute_sharded(slot->batch, comm, stream) : mgx_batch_execute(slot->batch, stream);
         if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
         if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
         slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();

@@ -89,6 +89,13 @@ class Comm:
             self._h = None
 
 
+def _device_bytes(ptr, nbytes):
+    """uint8 torch view of `nbytes` of library-owned device memory at `ptr` (current device), without a copy."""
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=torch.device("cuda", torch.cuda.current_device()))
+
+
 class ShardedTable:
     """One rank's shard of a table plus the global statistics every rank agrees on."""
 
@@ -163,7 +170,7 @@ class ShardedTable:
                 self.comm = Comm()
             if batch.n:
                 batch.exchange_df(self.comm, stream)
-            batch.execute(stream)
+            batch.execute_sharded(self.comm, stream)
             if batch.n:
                 batch.exchange(self.comm, stream)
             return
@@ -180,7 +187,23 @@ class ShardedTable:
                     h = df.cpu()
                     dist.all_reduce(h, op=dist.ReduceOp.SUM)
                     df.copy_(h)
-        batch.execute(stream)
+        if exchange and batch.n:
+            # the seed keys' all-gather of mgx_batch_execute_sharded, through torch.distributed (gloo stages through host
+            # memory: the CPU rehearsal; the device buffers are the batch's own)
+            def gather(mine_ptr, all_ptr, nbytes):
+                torch.cuda.current_stream().synchronize()
+                mine_t = _device_bytes(mine_ptr, nbytes)
+                all_t = _device_bytes(all_ptr, nbytes * self.world)
+                if dist.get_backend() == "nccl":
+                    dist.all_gather_into_tensor(all_t, mine_t)
+                else:
+                    parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+                    dist.all_gather(parts, mine_t.cpu())
+                    all_t.copy_(torch.cat(parts))
+                torch.cuda.current_stream().synchronize()
+            batch.execute_gather(self.world, gather, stream)
+        else:
+            batch.execute(stream)
         if not exchange:
             return
         off32, nbytes, mine, copy, gathered = self._buffers(batch)

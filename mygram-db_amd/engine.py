@@ -360,6 +360,32 @@ class PreparedBatch:
         if self._h:
             check(load().mgx_batch_execute(self._h, stream))
 
+    def execute_sharded(self, comm, stream=None):
+        """mgx_batch_execute_sharded: execute on a shard of a table — the seeds' best keys of every rank are all-gathered
+        (RCCL) and raise each query's pruning bound before the rest of the batch runs; follow with exchange()."""
+        if self._h:
+            check(load().mgx_batch_execute_sharded(self._h, comm._h, stream))
+
+    def execute_gather(self, world, gather, stream=None):
+        """mgx_batch_execute_gather: the same with the caller's all-gather, gather(mine_ptr, all_ptr, nbytes) -> None
+        (device pointers; rank r's block goes to all_ptr + r * nbytes)."""
+        if not self._h:
+            return
+        failure = []
+
+        def _cb(_user, mine, all_, nbytes, _stream):
+            try:
+                gather(mine, all_, nbytes)
+                return 0
+            except BaseException as e:  # noqa: BLE001 (re-raised below: no exception may cross the C frame)
+                failure.append(e)
+                return 7
+        fn = _capi.GATHER_FN(_cb)
+        rc = load().mgx_batch_execute_gather(self._h, world, fn, None, stream)
+        if failure:
+            raise failure[0]
+        check(rc)
+
     def fetch(self):
         """-> list[SearchResult] in the order the queries were given (host-resolved queries included)."""
         v = _capi.ResultView()
