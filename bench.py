@@ -23,6 +23,7 @@ MGX_BENCH_DEPTH (batches in flight), MGX_BENCH_PLANNERS (host planner threads).
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import sys
@@ -87,6 +88,32 @@ def physical_cores():
     return max(1, len(seen)), len(allowed)
 
 
+def cpu_quota():
+    """CPUs' worth of time this container may use per period (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited:
+    a GPU box shows all 256 logical CPUs of its host to every tenant but schedules only its share of them."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def usable_cores():
+    """Threads worth running: the physical cores of the affinity set, capped by the container's CPU quota."""
+    cores = physical_cores()[0]
+    quota = cpu_quota()
+    return max(1, min(cores, int(math.ceil(quota)))) if quota else cores
+
+
 def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
     """The CPU oracle (oracle/mygram_oracle.c: a C restatement of the reference's per-query path — df by text scan of
     every term's candidates, Execute, ScoreDocuments with tf by text scan, SortByScore) on the host cores of this box:
@@ -98,7 +125,8 @@ def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
     oidx = O.Index.from_csr(2, 0, True, c.key_bytes, c.key_off, c.offsets, c.docids)
     ostore = O.DocumentStore.from_arrays(corpus.text_bytes, corpus.text_off)
     n, avg = table.index.total_docs, table.index.avg_doc_length
-    cores, logical = physical_cores()
+    visible, logical = physical_cores()
+    cores = usable_cores()
 
     def one(i):
         t0 = time.perf_counter()
@@ -126,7 +154,7 @@ def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
     qps1 = done / dt1
     # all cores: enough queries for >= ~seconds*0.65 of wall time, at least 256 when they fit
     budget = max(seconds * 0.65, 1.0)
-    want = int(min(len(term_lists) - done, max(4 * cores, min(256, qps1 * cores * budget))))
+    want = int(min(len(term_lists) - done, max(4 * cores, min(512, qps1 * cores * budget))))
     want = max(want, min(len(term_lists) - done, cores))
     latn = []
     t0 = time.perf_counter()
@@ -136,13 +164,14 @@ def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
             check(i, r)
     dtn = time.perf_counter() - t0
     latn.sort()
-    return {"value": want / dtn, "unit": "queries/s", "cores": cores, "threads": cores, "logical_cpus": logical,
-            "cpu_model": cpu_model(), "kind": "port",
+    return {"value": want / dtn, "unit": "queries/s", "cores": cores, "threads": cores, "physical_cores_visible": visible,
+            "logical_cpus": logical, "cpu_quota": cpu_quota(), "cpu_model": cpu_model(), "kind": "port",
             "value_1_thread": qps1, "queries_1_thread": done, "queries_all_cores": want,
             "p50_ms_per_query": 1e3 * latn[len(latn) // 2], "p99_ms_per_query": 1e3 * latn[min(len(latn) - 1, int(len(latn) * 0.99))],
             "p50_ms_per_query_1_thread": 1e3 * statistics.median(lat1),
             "sample": "batch 0 of the benchmark (same 10M-doc corpus, same 3-term AND + BM25 top-10): %d queries on 1 "
-                      "thread (%.1f s), then %d queries on %d threads = one per physical core (%.1f s); per query: df "
+                      "thread (%.1f s), then %d queries on %d threads = one per core this container may use (its "
+                      "cgroup CPU quota, or the physical cores of its affinity set) (%.1f s); per query: df "
                       "by text scan of every term's candidates + Execute + ScoreDocuments (tf by text scan) + "
                       "SortByScore, as search_pipeline.cpp:2004-2019 + search_handler.cpp:454-470 do" %
                       (done, dt1, want, cores, dtn),
@@ -186,7 +215,7 @@ def main():
     # batches in flight: a batch spends ~1.3 ms of host stages (submit, plan, compile, enqueue, collect) around its device
     # time, so a small shard (0.3 ms of device per batch) needs six slots to keep the device busy, the whole table four
     depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (4 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 6)
-    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (physical_cores()[0] - 1) // max(1, world)))
+    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (usable_cores() - 1) // max(1, world)))
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
     # the intersection-only path (mgx::wave_count_kernel + page emit), docid-DESC pages of 10
