@@ -2919,9 +2919,10 @@ int mgx_batch_execute_gather(mgx_batch* batch, int world, mgx_gather_fn gather, 
     // Splitting the launch costs ~0.03 ms per batch (the main items wait for every seed, two small kernels, the
     // collective) and buys a bound made from world x 8 tiles instead of 8: measured on one GPU only the cost shows
     // (0.375 -> 0.405 ms per step on a 1.25M-doc shard), and the ceiling of any better start is 24 % of that shard's
-    // kernel — so by default only tables cut at least eight ways take it. MGX_SEED_EXCHANGE=1 / 0 forces.
-    static const int forced = std::getenv("MGX_SEED_EXCHANGE") ? atoi(std::getenv("MGX_SEED_EXCHANGE")) : -1;
-    const bool on = forced >= 0 ? forced != 0 : world >= 8;
+    // kernel: expected to be worth single-digit percents at eight shards, minus a second point per batch
+    // where ranks wait for each other. It cannot be measured on one GPU, so it is OPT-IN: MGX_SEED_EXCHANGE=1.
+    static const int forced = std::getenv("MGX_SEED_EXCHANGE") ? atoi(std::getenv("MGX_SEED_EXCHANGE")) : 0;
+    const bool on = forced != 0;
     return mgx::ExecuteImpl(batch, s, on ? &sg : nullptr);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_execute_gather: ") + e.what());
