@@ -333,10 +333,12 @@ def main():
 
         run_steps(args.warmup, False)
         sync()
+        cpu0 = time.process_time()
         t0 = time.perf_counter()
         run_steps(args.steps, True)
         sync()
         elapsed = time.perf_counter() - t0
+        host_cpu_ms = 1e3 * (time.process_time() - cpu0) / max(1, args.steps)  # CPU time of ALL threads of this rank
     else:
         ex_batches = batches
 
@@ -398,6 +400,7 @@ def main():
                 "wait_ms": float(tm[:, 3].mean()),
                 "driver_submit_call_ms": (call_ms[0] / args.steps) if (not exchange or cxx_exchange) else None,
                 "driver_wait_call_ms": (call_ms[1] / args.steps) if (not exchange or cxx_exchange) else None,
+                "host_cpu_ms_per_step": host_cpu_ms if (not exchange or cxx_exchange) else None,
                 "execute_ms": 1e3 * replay_elapsed / replay_steps,
                 "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
                 "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth},
