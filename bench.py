@@ -215,7 +215,7 @@ def main():
     # batches in flight: a batch spends ~1.3 ms of host stages (submit, plan, compile, enqueue, collect) around its device
     # time, so a small shard (0.3 ms of device per batch) needs six slots to keep the device busy, the whole table four
     depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (4 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 6)
-    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(16, (usable_cores() - 1) // max(1, world)))
+    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, (usable_cores() - 1) // max(1, world)))  # (8 plan a batch in 0.15-0.2 ms; 15 only add contention on a 16-CPU box)
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
     # the intersection-only path (mgx::wave_count_kernel + page emit), docid-DESC pages of 10
