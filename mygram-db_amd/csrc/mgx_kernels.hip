@@ -660,6 +660,19 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     }
     return tile_end;
   };
+  // What thread l < n_leaves needs about ITS leaf in every tile, fetched once: the posting range of the gram and its
+  // per-tile offset row (three dependent loads in front of a barrier, per tile, became two independent ones).
+  uint64_t my_l0 = 0, my_l1 = 0;
+  const uint32_t* my_tile_off = nullptr;
+  if (tid < n_leaves) {
+    const DevLeaf lf = leaf[tid];
+    if (lf.kind == kLeafList || lf.kind == kLeafGramBitmap) {
+      my_l0 = ix.offsets[lf.a];
+      my_l1 = ix.offsets[lf.a + 1];
+      const uint32_t row = ix.skip_row[lf.a];
+      if (row != kNoRow) my_tile_off = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+    }
+  }
   for (uint32_t tile = next_tile(tile_begin); tile < tile_end; tile = next_tile(tile + 1)) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     if (MODE == kModeScore) wave_topk_refresh_gbound(tk);
@@ -681,23 +694,19 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       const DevLeaf lf = leaf[tid];
       uint64_t a = 0, b = 0;
       if (lf.kind == kLeafList) {
-        const uint64_t l0 = ix.offsets[lf.a], l1 = ix.offsets[lf.a + 1];
-        const uint32_t row = ix.skip_row[lf.a];
-        if (row != kNoRow) {
-          const uint32_t* r = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
-          a = l0 + r[tile];
-          b = l0 + r[tile + 1];
+        if (my_tile_off) {
+          a = my_l0 + my_tile_off[tile];
+          b = my_l0 + my_tile_off[tile + 1];
         } else {
-          a = lower_bound_u32(ix.docids, l0, l1, tile_first);
-          b = lower_bound_u32(ix.docids, a, l1, tile_first + kTileDocs);
+          a = lower_bound_u32(ix.docids, my_l0, my_l1, tile_first);
+          b = lower_bound_u32(ix.docids, a, my_l1, tile_first + kTileDocs);
         }
       } else if (lf.kind == kLeafExplicit) {
         a = lower_bound_u32(bt.explicit_pool, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
         b = lower_bound_u32(bt.explicit_pool, a, static_cast<uint64_t>(lf.a) + lf.b, tile_first + kTileDocs);
       } else if (lf.kind == kLeafGramBitmap) {
         // rank base for tf lookups: postings of the gram before this tile
-        const uint32_t row = ix.skip_row[lf.a];
-        a = ix.offsets[lf.a] + ix.tile_off[static_cast<uint64_t>(row) * (ix.n_tiles + 1) + tile];
+        a = my_l0 + (my_tile_off ? my_tile_off[tile] : 0u);
       }
       seg_lo[tid] = a;
       seg_hi[tid] = b;
