@@ -618,6 +618,28 @@ TermInfo MakeInfo(const index::Index& index, const index::Index::Impl* im, const
   // GenerateTermInfos, search_pipeline.cpp:569-603
   TermInfo ti;
   ti.normalized = index.NormalizeText(raw);
+  {
+    // the commonest term of an n-gram index is exactly one n-gram of ASCII letters / digits: GenerateQueryNgrams would
+    // return that one string (no whitespace to split at, no CJK run for the kanji size) — same answers without building
+    // a vector of strings
+    const int n = index.GetNgramSize();
+    bool one_gram = n > 0 && ti.normalized.size() == static_cast<size_t>(n);
+    for (size_t i = 0; one_gram && i < ti.normalized.size(); ++i) {
+      const unsigned char c = static_cast<unsigned char>(ti.normalized[i]);
+      one_gram = (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z');
+    }
+    if (one_gram) {
+      uint32_t id = 0;
+      uint64_t ps = 0;
+      if (!im->Resolve(ti.normalized, &id, &ps)) ps = 0;
+      ti.n_grams = 1;
+      if (ps > 0) ti.gram_ids.push_back(id);
+      ti.estimated_size = ps;
+      ti.is_gram = true;
+      ti.df = ps;
+      return ti;
+    }
+  }
   auto grams = GenerateQueryNgrams(ti.normalized, index.GetNgramSize(), im->query_kanji, index.GetCrossBoundaryNgrams());
   DeduplicateSorted(grams);
   ti.n_grams = grams.size();
