@@ -5,8 +5,8 @@ One step = one FRESH batch of 1024 queries, end to end, in C++ (search_pipeline:
 libmygram_shim.so): per-query planning as ExecuteFullPipeline's regular branch does it (normalise, n-grams, dictionary
 lookup, estimated sizes, sort, idf — src/server/search_pipeline.cpp:2004-2014) -> query compilation + item scheduling
 (mgx_batch_reset) -> one asynchronous upload of the batch -> kernels (set algebra + fused BM25 + per-workgroup top-k,
-merge) -> results copied to pinned host memory -> BatchResult objects. Two batches are in flight: the host plans
-batch i+1 while the device runs batch i. 32 distinct batches are cycled; nothing of a batch is cached between steps.
+merge) -> results copied to pinned host memory -> BatchResult objects. Four batches are in flight (six on a shard): the
+host plans and compiles the next ones while the device runs one. 32 distinct batches are cycled; nothing of a batch is cached between steps.
 The index is resident in HBM; the query strings are resident in host memory (they are what a front end hands over).
 `value` is that end-to-end rate. The kernel-replay rate of round 1 (prepared batches re-executed) is reported beside it
 as `replay_qps`, and the dominant kernel's duration comes from HIP events around it in the replay loop.
@@ -114,6 +114,32 @@ def usable_cores():
     return max(1, min(cores, int(math.ceil(quota)))) if quota else cores
 
 
+def name_thread(name):
+    """prctl(PR_SET_NAME) for the calling thread (so that thread_cpu_ms can tell the driver's threads from the runtime's)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).prctl(15, name.encode()[:15], 0, 0, 0)
+    except (OSError, AttributeError):
+        pass
+
+
+def thread_cpu_ms():
+    """CPU time of every thread of this process so far, by thread name (ms): /proc/self/task/<tid>/schedstat holds the
+    nanoseconds the thread has run. The host layer names its threads (mgx-plan, mgx-dispatch, mgx-compile)."""
+    out = {}
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open("/proc/self/task/%s/comm" % tid).read().strip()
+                ns = int(open("/proc/self/task/%s/schedstat" % tid).read().split()[0])
+            except (OSError, ValueError, IndexError):
+                continue
+            out[name] = out.get(name, 0.0) + ns / 1e6
+    except OSError:
+        pass
+    return out
+
+
 def cpu_baseline(mg, table, corpus, term_lists, gpu_rows, seconds):
     """The CPU oracle (oracle/mygram_oracle.c: a C restatement of the reference's per-query path — df by text scan of
     every term's candidates, Execute, ScoreDocuments with tf by text scan, SortByScore) on the host cores of this box:
@@ -214,7 +240,12 @@ def main():
     dense = float(os.environ.get("MGX_BENCH_DENSE", "0"))
     # batches in flight: a batch spends ~1.3 ms of host stages (submit, plan, compile, enqueue, collect) around its device
     # time, so a small shard (0.3 ms of device per batch) needs six slots to keep the device busy, the whole table four
-    depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (4 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 6)
+    # (round 3: with the host stages at ~0.5 ms per batch and batches running first-in-first-out on the device, TWO in
+    # flight keep the whole table's device busy — 1.17M q/s at 1.7 ms p50 against 1.22M at 3.4 ms with four time-sliced
+    # ones; a 1.25M-doc shard, 0.26 ms of device per batch, still wants six, time-sliced: 0.27 vs 0.29 ms per step)
+    sharded_run = int(os.environ.get("WORLD_SIZE", "1")) > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
+    depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (6 if sharded_run else 2)
+    fifo = (os.environ.get("MGX_BENCH_FIFO", "") or ("0" if sharded_run else "1")) != "0"
     planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, (usable_cores() - 1) // max(1, world)))  # (8 plan a batch in 0.15-0.2 ms; 15 only add contention on a 16-CPU box)
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
@@ -227,6 +258,7 @@ def main():
     table = mdist.ShardedTable(corpus, first_doc_id=1 + before, device=local_rank, ngram_size=2, kanji_ngram_size=0,
                                dense_threshold=dense)
     cols = table.index.columns
+    table.index.device_index.set_batch_order(fifo)
     term_batches = make_queries(mg, table, N_DISTINCT_BATCHES, batch_size)
     setup_s = time.perf_counter() - t_setup
 
@@ -286,6 +318,10 @@ def main():
         comm = mdist.Comm() if cxx_exchange else None  # RCCL communicator behind the C ABI (mgx_comm_create)
         ex = S.Executor(shim_table, depth=depth, planner_threads=planners, comm=comm)
         qbs = [S.QueryBatch(tb) for tb in term_batches]
+        # setup (outside the clock, before the driver's own warm-up steps): every slot's arenas, pinned blocks, streams and
+        # helper threads exist before the first step — BatchExecutor::Warm runs one sample batch through each slot and
+        # discards the results; the timed steps still plan, compile and run every batch from scratch
+        ex.warm(qbs[-1], limit=10, sort_by_score=by_score, rounds=3)
         outs = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
                  np.zeros((batch_size, 10), np.float64), np.zeros(5, np.float64)) for _ in range(depth)]
 
@@ -304,6 +340,7 @@ def main():
             failure = []
 
             def submitter():
+                name_thread("bench-submit")
                 try:
                     for j in range(k):
                         in_flight.acquire()
@@ -331,14 +368,19 @@ def main():
                     timings.append(out[4].copy())
             th.join()
 
+        name_thread("bench-wait")
         run_steps(args.warmup, False)
         sync()
         cpu0 = time.process_time()
+        thr0 = thread_cpu_ms()
         t0 = time.perf_counter()
         run_steps(args.steps, True)
         sync()
         elapsed = time.perf_counter() - t0
         host_cpu_ms = 1e3 * (time.process_time() - cpu0) / max(1, args.steps)  # CPU time of ALL threads of this rank
+        thr1 = thread_cpu_ms()
+        host_cpu_by_thread = {k: round((v - thr0.get(k, 0.0)) / max(1, args.steps), 4) for k, v in thr1.items()
+                              if v - thr0.get(k, 0.0) > 0.0005 * args.steps}
     else:
         ex_batches = batches
 
@@ -401,9 +443,11 @@ def main():
                 "driver_submit_call_ms": (call_ms[0] / args.steps) if (not exchange or cxx_exchange) else None,
                 "driver_wait_call_ms": (call_ms[1] / args.steps) if (not exchange or cxx_exchange) else None,
                 "host_cpu_ms_per_step": host_cpu_ms if (not exchange or cxx_exchange) else None,
+                "host_cpu_ms_per_step_by_thread": host_cpu_by_thread if (not exchange or cxx_exchange) else None,
                 "execute_ms": 1e3 * replay_elapsed / replay_steps,
                 "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
-                "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth},
+                "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth,
+                "batch_order": "fifo" if fifo else "concurrent"},
             "config": {"workload": ("10M-doc synthetic ASCII corpus (seed 42), bigram index, 3-term AND + BM25 top-10, "
                                     "batch=1024 (BASELINE.json configs[1])") if by_score else
                                    ("PROFILING VARIANT, not the headline: the same batches without scoring "
@@ -436,6 +480,8 @@ def main():
                                  "profiles/r02_*_summary.json with the build it was taken on, not replayed here"},
             "cpu_baseline": cpu,
         }
+        if os.environ.get("MGX_BENCH_SERIES"):  # rehearsal: per-step host timings (plan, compile, enqueue, wait ms)
+            line["series"] = {"timings": np.round(tm[:, :4], 3).tolist(), "latency_ms": [round(1e3 * x, 3) for x in lat]}
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -156,6 +156,15 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out);
 /* Registers one FilterIndex (column,value) doc set (src/storage/filter_index.h:39-124) as a device bitmap usable
  * as a filter operand; docids ascending, inside the owned range. */
 int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id);
+/* How batches that are in flight at the same time (one stream per batch object) share the device.
+ * MGX_ORDER_FIFO (default): the main kernels of a batch start when those of the batch enqueued before it on this index
+ * have finished — first in, first out, so a batch's latency is its own kernel time plus what was queued ahead of it;
+ * uploads, clears, merges and result copies still overlap the previous batch. MGX_ORDER_CONCURRENT: no ordering — the
+ * device time-slices all batches in flight (a few percent more throughput at four batches in flight, every batch
+ * finishing after roughly depth x kernel time). */
+#define MGX_ORDER_FIFO 0u
+#define MGX_ORDER_CONCURRENT 1u
+int mgx_index_set_batch_order(mgx_index* idx, uint32_t order);
 /* Keeps the NORMALIZED text of the shard's docs resident in HBM (what DocumentStore::VisitNormalizedTextsFor hands
  * to BM25Scorer::ScoreDocuments, document_store_retrieval.cpp:289-322), by local slot: doc first_doc_id + i is
  * text_bytes[text_off[i] .. text_off[i+1]). Needed by text-level scored terms (mgx_term.text). Host arrays are copied. */

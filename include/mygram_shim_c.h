@@ -52,6 +52,13 @@ int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs
 int mgxs_executor_create_sharded(mgxs_table* table, int depth, int planner_threads, mgx_comm* comm, mgxs_executor** out);
 void mgxs_executor_destroy(mgxs_executor* ex);
 
+/* BatchExecutor::Warm — setup, outside any timed loop: runs the sample batch (same arguments as mgxs_submit) through
+ * every slot `rounds` times and discards the results, so that the slots' device arenas, pinned blocks, streams, the
+ * compile helper threads and the index's per-parameter tables exist before the first real batch. No batch may be in
+ * flight. */
+int mgxs_executor_warm(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                       uint32_t limit, uint32_t offset, int sort_by_score, int descending, int rounds);
+
 /* One batch of plain conjunctive queries (query::Query with search_text + and_terms): query i has n_terms[i] raw term
  * strings, taken in order from `terms` (NUL-terminated UTF-8). All queries share limit / offset / sort / order
  * (SORT _score DESC LIMIT 10 is the benchmark's shape). Plans on the host, compiles into a re-used batch object and

@@ -22,7 +22,7 @@ EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
     "mgx_columns_build", "mgx_columns_from_mgix", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
-    "mgx_index_add_filter_bitmap", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
+    "mgx_index_add_filter_bitmap", "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy",
     "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_execute_sharded", "mgx_batch_execute_gather", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
@@ -134,6 +134,7 @@ def load():
     L.mgx_batch_execute.argtypes = [vp, vp]
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
     L.mgx_index_attach_text.argtypes = [vp, vp, vp]
+    L.mgx_index_set_batch_order.argtypes = [vp, C.c_uint32]
     L.mgx_batch_count_df.argtypes = [vp, vp]
     L.mgx_batch_df_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]

@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
-           "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_submit", "mgxs_wait",
+           "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
+           "mgxs_submit", "mgxs_wait",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -43,6 +44,7 @@ def load():
     L.mgxs_executor_destroy.argtypes = [vp]
     L.mgxs_executor_destroy.restype = None
     L.mgxs_submit.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, C.POINTER(u64)]
+    L.mgxs_executor_warm.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, i32]
     L.mgxs_wait.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
     L.mgxs_batcher_destroy.argtypes = [vp]
@@ -146,6 +148,12 @@ class Executor:
         if getattr(self, "_h", None):
             load().mgxs_executor_destroy(self._h)
             self._h = None
+
+    def warm(self, qb, limit=10, offset=0, sort_by_score=True, descending=True, rounds=2):
+        """BatchExecutor::Warm: setup outside any timed loop — every slot's arenas, pinned blocks, streams and helper
+        threads are created by running `qb` through each slot `rounds` times; results are discarded."""
+        _check(load().mgxs_executor_warm(self._h, qb.n, qb.n_terms.ctypes.data, C.cast(qb.terms, C.c_void_p), limit, offset,
+                                         int(sort_by_score), int(descending), rounds))
 
     def submit(self, qb, limit=10, offset=0, sort_by_score=True, descending=True):
         t = C.c_uint64()

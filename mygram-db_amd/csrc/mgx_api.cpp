@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -144,6 +145,7 @@ struct BatchResources {
   // waits for batch i alone while batch i+1 already runs.
   hipStream_t stream = nullptr;
   hipEvent_t done_ev = nullptr;
+  hipEvent_t main_ev = nullptr;  // recorded behind the score group's main launches: the next batch's main launches wait for it
   bool copy_issued = false;
   // mgx_batch_exchange: this rank's blob (docid pages only) and every rank's. They belong to the slot, not to one batch:
   // a hipFree / hipMalloc per reset would synchronise the device once per step.
@@ -167,6 +169,7 @@ struct BatchResources {
       if (x) (void)hipFree(x);
     if (stream) (void)hipStreamDestroy(stream);
     if (done_ev) (void)hipEventDestroy(done_ev);
+    if (main_ev) (void)hipEventDestroy(main_ev);
     for (void* h : h_down)
       if (h) (void)hipHostFree(h);
     if (fork_ev) (void)hipEventDestroy(fork_ev);
@@ -309,6 +312,26 @@ struct mgx_index {
   std::unordered_map<TableKey, uint32_t, TableKeyHash> table_slot;
   DevBuf d_table_pool;
   uint32_t table_cap = 0, table_used = 0, table_dl = 0;
+  // New tables are built ON THE DEVICE (build_contrib_tables_kernel) on the index's table stream: the compile step of a
+  // batch only reserves the slot and queues a 40-byte job (a fresh serving process meets new (gram, idf) pairs in almost
+  // every batch until its working set exists; 3840 divisions + a blocking 30 KB copy per table were most of those
+  // batches' compile time). The next execute ships the queued jobs through a pinned ring, launches the build and waits
+  // for table_ev on its own stream — a no-op once the tables are there.
+  hipStream_t table_stream = nullptr;
+  hipEvent_t table_ev = nullptr;
+  mgx::TableJob* job_ring = nullptr;  // pinned, kJobRing jobs; the device twin holds the same offsets
+  DevBuf d_job_ring;
+  uint32_t job_ring_at = 0;
+  std::vector<mgx::TableJob> pending_jobs;  // under table_mu
+  // Batches of a serving loop run on their own streams, and the device would time-slice the main kernels of all batches
+  // in flight: every batch then finishes after (batches in flight) x (kernel time). The main launches of a batch
+  // therefore wait for the main launches of the batch enqueued before it on this index (chain_ev: that batch's
+  // BatchResources::main_ev) — first in, first out; uploads, clears, the merge and the result copy still overlap the
+  // previous batch's kernels. Guarded by table_mu.
+  hipEvent_t chain_ev = nullptr;
+  std::atomic<int> fifo{1};  // mgx_index_set_batch_order
+  bool table_ev_recorded = false;
+  static constexpr uint32_t kJobRing = 4096;
   size_t table_doubles() const { return static_cast<size_t>(mgx::kFastPoolTf + 1) * table_dl; }
   // K[dl] = k1 * (1 - b + b * dl / avgdl), dl 0..255, per (k1, b, avgdl) of a batch (group_score_kernel)
   struct NormTable {
@@ -323,8 +346,9 @@ struct mgx_index {
     DevBuf d, d_fine;
   };
   std::vector<std::unique_ptr<BlockMax>> block_max;
-  // df of text-level terms seen so far: (term bytes, N) -> table-wide df. The index is static, so a term's df never
-  // changes: the df pass (a text scan over every candidate of the term) runs once per distinct term, not once per batch.
+  // df of text-level terms seen so far: (term bytes, N) -> THIS SHARD's count (a shard of a table sums the ranks' counts
+  // per batch, mgx_batch_exchange_df). The index is static, so the count never changes: the df pass (a text scan over
+  // every candidate of the term) runs once per distinct term, not once per batch.
   std::unordered_map<std::string, uint64_t> df_cache;
   uint32_t n_bitmap_rows = 0, n_fine_rows = 0;
   DevBuf d_fine_rows;                 // fine row -> bitmap row
@@ -364,29 +388,48 @@ static uint64_t GetContributionTable(mgx_index* idx, uint32_t bm_row, double idf
   if (hit != idx->table_slot.end())
     return reinterpret_cast<uint64_t>(idx->d_table_pool.as<double>() + static_cast<size_t>(hit->second) * nd);
   if (idx->table_used == idx->table_cap) return 0;
-  // bm25_scorer.cpp:80-84 operation by operation (this file is compiled with -ffp-contract=off), so an entry is
-  // bit-identical to the direct evaluation; row 0 (a term the doc lacks) is +0.0
-  std::vector<double> t(nd, 0.0);
-  const double one_minus_b = 1.0 - b, k1_plus_1 = k1 + 1.0, avg = std::max(avgdl, 1.0);
-  for (uint32_t tfi = 1; tfi <= kFastPoolTf; ++tfi) {
-    for (uint32_t dli = 0; dli < idx->table_dl; ++dli) {
-      const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
-      const double length_norm = one_minus_b + b * dl / avg;
-      const double numerator = tf * k1_plus_1;
-      const double denominator = tf + k1 * length_norm;
-      t[static_cast<size_t>(tfi) * idx->table_dl + dli] = idf * numerator / denominator;
-    }
-  }
   const uint32_t slot = idx->table_used;
   double* dst = idx->d_table_pool.as<double>() + static_cast<size_t>(slot) * nd;
-  if (hipSetDevice(idx->device) != hipSuccess ||
-      hipMemcpy(dst, t.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
+  idx->pending_jobs.push_back(TableJob{idf, k1, b, avgdl, slot, 0});  // built by the next execute (FlushTableJobs)
   idx->table_used++;
   idx->table_slot.emplace(key, slot);
   return reinterpret_cast<uint64_t>(dst);
+}
+
+// Ships the queued table jobs and launches their build on the table stream; the caller then waits for table_ev on its
+// own stream. Called with table_mu held.
+static hipError_t FlushTableJobs(mgx_index* idx) {
+  if (idx->pending_jobs.empty()) return hipSuccess;
+  hipError_t e;
+  if (!idx->job_ring) {
+    ResourceScope none(nullptr);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&idx->job_ring), mgx_index::kJobRing * sizeof(TableJob),
+                           hipHostMallocDefault)) != hipSuccess ||
+        (e = idx->d_job_ring.Alloc(mgx_index::kJobRing * sizeof(TableJob))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&idx->table_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&idx->table_ev, hipEventDisableTiming)) != hipSuccess)
+      return e;
+  }
+  size_t done = 0;
+  while (done < idx->pending_jobs.size()) {
+    const uint32_t n = static_cast<uint32_t>(std::min<size_t>(idx->pending_jobs.size() - done, mgx_index::kJobRing));
+    if (idx->job_ring_at + n > mgx_index::kJobRing) {  // wrap: the ring's earlier copies must have left
+      if ((e = hipStreamSynchronize(idx->table_stream)) != hipSuccess) return e;
+      idx->job_ring_at = 0;
+    }
+    TableJob* stage = idx->job_ring + idx->job_ring_at;
+    TableJob* dev = idx->d_job_ring.as<TableJob>() + idx->job_ring_at;
+    std::memcpy(stage, idx->pending_jobs.data() + done, n * sizeof(TableJob));
+    if ((e = hipMemcpyAsync(dev, stage, n * sizeof(TableJob), hipMemcpyHostToDevice, idx->table_stream)) != hipSuccess) return e;
+    const int le = LaunchBuildContribTables(dev, n, idx->table_dl, idx->d_table_pool.as<double>(), idx->table_stream);
+    if (le != 0) return static_cast<hipError_t>(le);
+    idx->job_ring_at += n;
+    done += n;
+  }
+  idx->pending_jobs.clear();
+  if ((e = hipEventRecord(idx->table_ev, idx->table_stream)) != hipSuccess) return e;
+  idx->table_ev_recorded = true;
+  return hipSuccess;
 }
 
 // Device address of K[0..255], K[dl] = k1 * ((1 - b) + b * dl / max(avgdl, 1)): the doc-length half of the BM25
@@ -773,6 +816,12 @@ void mgx_index_destroy(mgx_index* idx) {
   (void)hipSetDevice(idx->device);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   if (idx->side_stream) (void)hipStreamDestroy(idx->side_stream);
+  if (idx->table_stream) {
+    (void)hipStreamSynchronize(idx->table_stream);
+    (void)hipStreamDestroy(idx->table_stream);
+  }
+  if (idx->table_ev) (void)hipEventDestroy(idx->table_ev);
+  if (idx->job_ring) (void)hipHostFree(idx->job_ring);
   delete idx;
 }
 
@@ -796,6 +845,12 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out) {
     for (const auto& t : idx->block_max) *out += t->d.bytes + t->d_fine.bytes;
     for (const auto& t : idx->norm_tables) *out += t->d.bytes;
   }
+  return MGX_OK;
+}
+
+int mgx_index_set_batch_order(mgx_index* idx, uint32_t order) {
+  if (!idx || order > MGX_ORDER_CONCURRENT) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_batch_order: bad argument");
+  idx->fifo.store(order == MGX_ORDER_FIFO ? 1 : 0);
   return MGX_OK;
 }
 
@@ -1315,8 +1370,12 @@ struct mgx_batch {
   Group textdf;
   std::vector<mgx::QuerySpec> df_specs;
   DevBuf d_patterns, d_text_terms, d_text_idf, d_text_df, d_verify_terms;
-  std::vector<uint64_t> h_text_df, text_total_docs;
-  std::vector<uint64_t> text_df_known;      // per text term: its cached df, or ~0ull (the df query then counts it)
+  // d_text_df is the array ranks all-reduce in place (table-wide df after the reduction); d_text_df_local keeps this
+  // shard's own counts — the only thing the index's df cache ever holds, so what a rank contributes to the reduction is
+  // the same whether a term's count came from the cache or from the df pass
+  DevBuf d_text_df_local, d_text_df_known;
+  std::vector<uint64_t> h_text_df, h_text_df_local, text_total_docs;
+  std::vector<uint64_t> text_df_known;      // per text term: its cached LOCAL df, or ~0ull (the df query then counts it)
   std::vector<std::string> text_df_key;     // per text term: the cache key
   std::vector<double> h_text_idf;
   bool df_ready = false;  // mgx_batch_count_df ran (and the caller summed the counts) for the next execute
@@ -1968,7 +2027,11 @@ struct CompilePool {
   }
   CompilePool() {
     const int n = std::getenv("MGX_COMPILE_THREADS") ? atoi(std::getenv("MGX_COMPILE_THREADS")) : 3;
-    for (int i = 0; i < n; ++i) helpers.emplace_back([this] { Helper(); });
+    for (int i = 0; i < n; ++i)
+      helpers.emplace_back([this] {
+        pthread_setname_np(pthread_self(), "mgx-compile");
+        Helper();
+      });
   }
   ~CompilePool() {
     {
@@ -2064,8 +2127,9 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         b->text_df_key.push_back(std::move(ckey));
         if (tt.grams.empty() || known != ~0ull) {
           // nothing to count: a term shorter than one n-gram has df 0 (PopulateTermDocumentFrequency returns before
-          // counting, search_pipeline.cpp:546-549), a term seen before has its df in the index's cache — the df query
-          // runs over the empty doc range and the known value is put in its place when the counts are read
+          // counting, search_pipeline.cpp:546-549), a term seen before has this shard's count in the index's cache — the
+          // df query runs over the empty doc range and the known LOCAL value takes its place on the device
+          // (gather_df_kernel), before any rank sums the counts
           c.Emit(kOpLoad, c.RangeLeaf(0, 0));
           mn = 0;
         } else {
@@ -2100,7 +2164,10 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
       MGX_HIP(Upload(b->d_text_terms, tts.data(), tts.size()));
       MGX_HIP(b->d_text_idf.Alloc(static_cast<size_t>(n_tt) * sizeof(double)));
       MGX_HIP(b->d_text_df.Alloc(static_cast<size_t>(n_tt) * sizeof(uint64_t)));
+      MGX_HIP(b->d_text_df_local.Alloc(static_cast<size_t>(n_tt) * sizeof(uint64_t)));
+      MGX_HIP(Upload(b->d_text_df_known, b->text_df_known.data(), b->text_df_known.size()));
       b->h_text_df.assign(n_tt, 0);
+      b->h_text_df_local.assign(n_tt, 0);
       b->h_text_idf.assign(n_tt, 0.0);
       for (uint32_t i = 0; i < n_tt; ++i) b->textdf.qids.push_back(i);
     }
@@ -2151,7 +2218,9 @@ static int IssueResultCopy(mgx_batch* b, hipStream_t s) {
     MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
   if (!b->score.qids.empty())
     MGX_HIP(hipMemcpyAsync(b->h_score_out, b->d_score_out.p, b->so_bytes, hipMemcpyDeviceToHost, s));
-  if (!b->res->done_ev) MGX_HIP(hipEventCreateWithFlags(&b->res->done_ev, hipEventDisableTiming));
+  if (!b->res->done_ev) {
+    MGX_HIP(hipEventCreateWithFlags(&b->res->done_ev, hipEventDisableTiming));
+  }
   MGX_HIP(hipEventRecord(b->res->done_ev, s));
   b->res->copy_issued = true;
   return MGX_OK;
@@ -2186,9 +2255,10 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
   MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
   MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, true, s));
   MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s));
-  // counter slot 5 of every df query -> contiguous u64 array (the buffer ranks all-reduce)
-  MGX_HIP(hipMemcpy2DAsync(b->d_text_df.p, sizeof(uint64_t), g.d_counters.as<unsigned long long>() + 5,
-                           8 * sizeof(uint64_t), sizeof(uint64_t), g.qids.size(), hipMemcpyDeviceToDevice, s));
+  // counter slot 5 of every df query (or the cached local count) -> the local array and the buffer ranks all-reduce
+  MGX_LAUNCH(LaunchGatherDf(g.d_counters.as<unsigned long long>(), b->d_text_df_known.as<uint64_t>(),
+                            static_cast<uint32_t>(g.qids.size()), b->d_text_df_local.as<uint64_t>(),
+                            b->d_text_df.as<uint64_t>(), s));
   return MGX_OK;
 }
 
@@ -2210,6 +2280,11 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     if (rc) return rc;
   }
   b->merged_shards = false;
+  {  // contribution tables built while this (or any earlier) batch was compiled travel on the index's table stream
+    std::lock_guard<std::mutex> lock(idx->table_mu);
+    MGX_HIP(FlushTableJobs(idx));
+    if (idx->table_ev_recorded) MGX_HIP(hipStreamWaitEvent(s, idx->table_ev, 0));
+  }
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (b->timing) {
     MGX_HIP(hipEventCreate(&ev0));
@@ -2226,16 +2301,16 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     b->df_ready = false;
     const size_t n_tt = b->h_text_df.size();
     MGX_HIP(hipMemcpyAsync(b->h_text_df.data(), b->d_text_df.p, n_tt * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipMemcpyAsync(b->h_text_df_local.data(), b->d_text_df_local.p, n_tt * sizeof(uint64_t),
+                           hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     {
+      // h_text_df is what idf is taken from (summed over the ranks when the caller reduced it); the cache learns this
+      // shard's own counts only, and a cached count is never put in the place of a reduced one
       std::lock_guard<std::mutex> lock(idx->table_mu);
-      for (size_t i = 0; i < n_tt; ++i) {
-        if (b->text_df_known[i] != ~0ull) {
-          b->h_text_df[i] = b->text_df_known[i];
-        } else if (idx->df_cache.size() < (1u << 20)) {
-          idx->df_cache.emplace(b->text_df_key[i], b->h_text_df[i]);  // (table-wide already when the ranks summed it)
-        }
-      }
+      for (size_t i = 0; i < n_tt; ++i)
+        if (b->text_df_known[i] == ~0ull && idx->df_cache.size() < (1u << 20))
+          idx->df_cache.emplace(b->text_df_key[i], b->h_text_df_local[i]);
     }
     for (size_t i = 0; i < n_tt; ++i) {
       // BM25Scorer::ComputeIDF, bm25_scorer.cpp:14-25
@@ -2256,6 +2331,13 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     MGX_HIP(hipMemsetAsync(b->d_score_out.p, 0, clear_bytes, s));
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev0, s));
+    }
+    static const bool kChainEnv = !(std::getenv("MGX_CHAIN") && atoi(std::getenv("MGX_CHAIN")) == 0);
+    const bool kChain = kChainEnv && idx->fifo.load(std::memory_order_relaxed) != 0;
+    if (kChain && b->res_owned) {
+      if (!b->res->main_ev) MGX_HIP(hipEventCreateWithFlags(&b->res->main_ev, hipEventDisableTiming));
+      std::lock_guard<std::mutex> lock(idx->table_mu);
+      if (idx->chain_ev && idx->chain_ev != b->res->main_ev) MGX_HIP(hipStreamWaitEvent(s, idx->chain_ev, 0));
     }
     uint32_t n_fast = 0;
     for (int t = 0; t < kFastMaxScore; ++t) n_fast += g.dev_fast[t].n_items;
@@ -2307,6 +2389,11 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     if (b->timing) {
       MGX_HIP(hipEventRecord(ev1, s));
       timed = true;
+    }
+    if (kChain && b->res_owned) {
+      std::lock_guard<std::mutex> lock(idx->table_mu);
+      MGX_HIP(hipEventRecord(b->res->main_ev, s));
+      idx->chain_ev = b->res->main_ev;
     }
     const uint32_t n = static_cast<uint32_t>(g.qids.size());
     MGX_LAUNCH(LaunchMergeTopK(g.dev.queries, g.d_ident.as<uint32_t>(), n, 0, g.dev.cand_keys, g.dev.cand_docs,
@@ -2375,8 +2462,22 @@ static int FetchImpl(mgx_batch* b, mgx_result_view* out) {
   const double* page_scores = nullptr;
   const unsigned long long* override_tot = nullptr;
   if (b->res && b->res->copy_issued) {
-    // the copies were enqueued behind the kernels: wait for THIS batch's event only (a later batch may be running)
-    MGX_HIP(hipEventSynchronize(b->res->done_ev));
+    // the copies were enqueued behind the kernels: wait for THIS batch's event only (a later batch may be running).
+    // hipEventSynchronize keeps a core busy for the whole wait (with or without hipEventBlockingSync on this runtime:
+    // measured 0.85 ms of CPU per 0.85 ms step); a serving loop keeps several batches in flight, so the collecting
+    // thread naps between queries of the event instead — tens of microseconds of added latency per batch, no CPU.
+    // MGX_WAIT_POLICY=spin restores the busy wait (a caller with one batch in flight who wants the last microseconds).
+    static const bool spin = std::getenv("MGX_WAIT_POLICY") != nullptr && std::string(std::getenv("MGX_WAIT_POLICY")) == "spin";
+    if (spin) {
+      MGX_HIP(hipEventSynchronize(b->res->done_ev));
+    } else {
+      for (;;) {
+        const hipError_t q = hipEventQuery(b->res->done_ev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return Fail(MGX_ERR_INTERNAL, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+    }
   } else {
     if (!b->page.qids.empty())
       MGX_HIP(hipMemcpyAsync(b->h_page_out, b->d_page_out.p, b->po_bytes, hipMemcpyDeviceToHost, s));
@@ -2572,11 +2673,13 @@ int mgx_batch_reset(mgx_batch* batch, const mgx_query* queries, uint32_t n_queri
       const auto t2 = std::chrono::steady_clock::now();
       us_compile += std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
       us_into += std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
-      if (++n % 64 == 0) {
-        fprintf(stderr, "[mgx] reset x64: CompileQuery loop %.3f ms, reset + PrepareInto %.3f ms per batch\n",
-                us_compile.exchange(0) / 64e3, us_into.exchange(0) / 64e3);
+      static const uint64_t period = std::max(1, atoi(std::getenv("MGX_TRACE_HOST")) > 1 ? atoi(std::getenv("MGX_TRACE_HOST")) : 64);
+      if (++n % period == 0) {
+        const double per = static_cast<double>(period);
+        fprintf(stderr, "[mgx] reset x%llu: CompileQuery loop %.3f ms, reset + PrepareInto %.3f ms per batch\n",
+                static_cast<unsigned long long>(period), us_compile.exchange(0) / (per * 1e3), us_into.exchange(0) / (per * 1e3));
         for (int k = 0; k < 8; ++k)
-          fprintf(stderr, "[mgx]   %-24s %.3f ms\n", mgx::kSectionNames[k], mgx::g_section_us[k].exchange(0) / 64e6);
+          fprintf(stderr, "[mgx]   %-24s %.3f ms\n", mgx::kSectionNames[k], mgx::g_section_us[k].exchange(0) / (per * 1e6));
       }
     }
     return rc;
@@ -2984,6 +3087,10 @@ void mgx_batch_destroy(mgx_batch* batch) {
   for (auto& ev : batch->events) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
+  }
+  if (batch->res_owned && batch->res_owned->main_ev) {  // (the index must not chain a later batch to a dead event)
+    std::lock_guard<std::mutex> lock(batch->idx->table_mu);
+    if (batch->idx->chain_ev == batch->res_owned->main_ev) batch->idx->chain_ev = nullptr;
   }
   delete batch;
 }

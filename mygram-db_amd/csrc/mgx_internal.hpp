@@ -188,6 +188,13 @@ struct FastPlan {
   uint32_t bytes, pad;
   const double* ktab;  // [256] K[dl] = k1 * (1 - b + b * dl / avgdl) of the batch's (k1, b, avgdl)
 };
+// One contribution table of the wave kernel's pool, to be built on the device (build_contrib_tables_kernel):
+// pool[slot][tf][dl] = idf * (tf * (k1 + 1)) / (tf + k1 * ((1 - b) + b * dl / max(avgdl, 1))) — bm25_scorer.cpp:80-84
+// operation by operation in fp64 (the device code is compiled with -ffp-contract=off like the host's).
+struct TableJob {
+  double idf, k1, b, avgdl;
+  uint32_t slot, pad;
+};
 FastPlan PlanFast(uint32_t max_cap, const double* ktab);
 uint32_t FastTableDl(uint32_t max_doc_len);  // tdl of an index's contribution-table pool
 

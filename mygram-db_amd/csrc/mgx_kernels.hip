@@ -3000,6 +3000,59 @@ int LaunchApplySeedBounds(const uint64_t* all, uint32_t world, uint32_t n, uint3
   return 0;
 }
 
+// Contribution tables of the wave kernel's pool, one workgroup per table (see TableJob). Built here instead of on the
+// host: a fresh serving process meets new (gram, idf) pairs in almost every batch until its working set exists, and
+// 3840 fp64 divisions + a 30 KB copy per table sat in the compile step of those batches.
+__global__ __launch_bounds__(256) void build_contrib_tables_kernel(const TableJob* __restrict__ jobs, uint32_t table_dl,
+                                                                   double* __restrict__ pool) {
+  const TableJob j = jobs[blockIdx.x];
+  const uint32_t nd = (kFastPoolTf + 1) * table_dl;
+  double* t = pool + static_cast<uint64_t>(j.slot) * nd;
+  const double one_minus_b = 1.0 - j.b, k1_plus_1 = j.k1 + 1.0, avg = j.avgdl > 1.0 ? j.avgdl : 1.0;  // std::max(avgdl, 1.0)
+  for (uint32_t e = threadIdx.x; e < nd; e += 256) {
+    const uint32_t tfi = e / table_dl, dli = e - tfi * table_dl;
+    double v = 0.0;  // row 0 (a term the doc lacks) is +0.0
+    if (tfi != 0) {
+      const double dl = static_cast<double>(dli), tf = static_cast<double>(tfi);
+      const double length_norm = one_minus_b + j.b * dl / avg;
+      const double numerator = tf * k1_plus_1;
+      const double denominator = tf + j.k1 * length_norm;
+      v = j.idf * numerator / denominator;
+    }
+    t[e] = v;
+  }
+}
+
+int LaunchBuildContribTables(const TableJob* jobs, uint32_t n_jobs, uint32_t table_dl, double* pool, hipStream_t s) {
+  if (n_jobs == 0 || table_dl == 0) return 0;
+  hipLaunchKernelGGL(build_contrib_tables_kernel, dim3(n_jobs), dim3(256), 0, s, jobs, table_dl, pool);
+  MGX_KCHECK();
+  return 0;
+}
+
+// df pass of the text-level terms (CountDfImpl): slot 5 of every df query's counters is this shard's LOCAL count; a term
+// whose local count the index already knows (its df query ran over the empty range) takes the known value. Both the
+// local array (what the index caches) and the exchange array (what ranks all-reduce in place) receive it, so a rank's
+// contribution to the reduction never depends on what its cache happened to hold.
+__global__ __launch_bounds__(256) void gather_df_kernel(const unsigned long long* __restrict__ counters,
+                                                        const uint64_t* __restrict__ known, uint32_t n,
+                                                        uint64_t* __restrict__ local, uint64_t* __restrict__ exchange) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = known[i];
+  const uint64_t v = k != ~0ull ? k : counters[static_cast<uint64_t>(i) * 8 + 5];
+  local[i] = v;
+  exchange[i] = v;
+}
+
+int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, uint32_t n, uint64_t* local,
+                   uint64_t* exchange, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(gather_df_kernel, dim3((n + 255) / 256), dim3(256), 0, s, counters, known, n, local, exchange);
+  MGX_KCHECK();
+  return 0;
+}
+
 // read-only streaming probe: the box's attainable HBM read bandwidth, the second roofline denominator of bench.py
 typedef uint32_t probe_vec4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read_probe_kernel(const probe_vec4* __restrict__ src, uint64_t n_vec, uint32_t* sink) {

@@ -38,6 +38,9 @@ int LaunchPackSeedKeys(const uint32_t* list_begin, const uint8_t* has_seed, cons
                        uint32_t cand_stride, uint32_t n, uint32_t k, uint64_t* out, hipStream_t s);
 int LaunchApplySeedBounds(const uint64_t* all, uint32_t world, uint32_t n, uint32_t k, const DevQuery* queries,
                           unsigned long long* bounds, hipStream_t s);
+int LaunchBuildContribTables(const TableJob* jobs, uint32_t n_jobs, uint32_t table_dl, double* pool, hipStream_t s);
+int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, uint32_t n, uint64_t* local,
+                   uint64_t* exchange, hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
                     uint64_t* totals, hipStream_t s);
 int LaunchExpand(const uint64_t* rbits, const uint64_t* tile_start, const uint64_t* totals, const uint64_t* take,

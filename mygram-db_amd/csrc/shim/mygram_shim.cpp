@@ -19,6 +19,8 @@
 #include <thread>
 #include <unordered_map>
 
+#include <pthread.h>
+
 namespace mygramdb {
 
 using mygram::utils::Error;
@@ -576,8 +578,65 @@ std::vector<DocId> ResultSorter::SortByScore(const index::Index& index, const st
 namespace search_pipeline {
 
 namespace {
+// The gram ids of one term: a query term is a handful of n-grams, so they live inside the object (no heap traffic on the
+// planner's hot path — it plans a million terms a second); a long term spills to the heap.
+class IdVec {
+ public:
+  IdVec() = default;
+  IdVec(const IdVec& o) { assign(o.data(), o.size()); }
+  IdVec(IdVec&& o) noexcept { steal(o); }
+  IdVec& operator=(const IdVec& o) {
+    if (this != &o) assign(o.data(), o.size());
+    return *this;
+  }
+  IdVec& operator=(IdVec&& o) noexcept {
+    if (this != &o) steal(o);
+    return *this;
+  }
+  void push_back(uint32_t v) {
+    if (!heap_.empty()) {
+      heap_.push_back(v);
+    } else if (n_ < kInline) {
+      inl_[n_] = v;
+    } else {
+      heap_.assign(inl_, inl_ + n_);
+      heap_.push_back(v);
+    }
+    ++n_;
+  }
+  void assign(const uint32_t* p, size_t n) {
+    clear();
+    for (size_t i = 0; i < n; ++i) push_back(p[i]);
+  }
+  void assign(size_t n, uint32_t v) {
+    clear();
+    for (size_t i = 0; i < n; ++i) push_back(v);
+  }
+  void clear() {
+    heap_.clear();
+    n_ = 0;
+  }
+  [[nodiscard]] const uint32_t* data() const { return heap_.empty() ? inl_ : heap_.data(); }
+  [[nodiscard]] size_t size() const { return n_; }
+  [[nodiscard]] bool empty() const { return n_ == 0; }
+  [[nodiscard]] const uint32_t* begin() const { return data(); }
+  [[nodiscard]] const uint32_t* end() const { return data() + n_; }
+
+ private:
+  static constexpr size_t kInline = 8;
+  void steal(IdVec& o) {
+    heap_ = std::move(o.heap_);
+    std::copy(o.inl_, o.inl_ + kInline, inl_);
+    n_ = o.n_;
+    o.clear();
+  }
+  uint32_t inl_[kInline] = {0};
+  size_t n_ = 0;
+  std::vector<uint32_t> heap_;
+};
+
 struct TermInfo {  // search_pipeline.h:44-55
-  std::vector<uint32_t> gram_ids;
+  IdVec gram_ids;
   size_t n_grams = 0;
   uint64_t estimated_size = 0;  // UINT64_MAX = no n-grams
   uint64_t df = 0;
@@ -594,7 +653,8 @@ struct PlannedQuery {
   ErrorCode error = ErrorCode::kSuccess;
   std::string error_message;
   std::vector<mgx_term> terms, not_terms;
-  std::vector<std::vector<uint32_t>> ids;
+  std::vector<IdVec> ids;       // (reserved before the first mgx_term points into it: elements must not move)
+  std::vector<TermInfo> tis;    // scratch of PlanQuery, kept for its storage
   std::vector<mgx_filter> filters;
   std::vector<mgx_expr_token> expr;
   std::deque<std::string> texts;  // normalized text-level terms (addresses stay valid as the deque grows)
@@ -608,6 +668,7 @@ struct PlannedQuery {
     terms.clear();
     not_terms.clear();
     ids.clear();
+    tis.clear();
     filters.clear();
     expr.clear();
     texts.clear();
@@ -740,7 +801,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       return Fail(p, ErrorCode::kInvalidArgument, "malformed expression tree");
     p->ids.reserve(leaves.size() + q.not_terms.size());
     for (auto& ti : tis) {
-      if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids = {0};  // placeholder of an EMPTY leaf
+      if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids.assign(1, 0u);  // placeholder of an EMPTY leaf
       p->ids.push_back(ti.gram_ids);
       p->terms.push_back(mgx_term{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0});
     }
@@ -776,7 +837,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       }
       const size_t drop = static_cast<size_t>(q.fuzzy_max_distance) * n_eff;  // :1700-1703
       const size_t theta = grams.size() > drop ? grams.size() - drop : 1;
-      std::vector<uint32_t> known;
+      IdVec known;
       for (const auto& g : grams) {
         uint32_t id = 0;
         uint64_t ps = 0;
@@ -794,7 +855,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
     finish(MGX_SORT_DOCID);
     return;
   }
-  std::vector<TermInfo> tis;
+  std::vector<TermInfo>& tis = p->tis;
   tis.reserve(q.terms.size());
   for (const auto& t : q.terms) tis.push_back(MakeInfo(index, im, t));
   // search_pipeline.cpp:2012-2014 (std::sort on <=16 elements is an insertion sort: equal keys keep their order)
@@ -1055,10 +1116,20 @@ BatchExecutor::BatchExecutor(const index::Index& index, Options options) : impl_
   impl_->total_docs = index.Bm25DocCount();
   impl_->avgdl = index.Bm25AvgDocLength();
   impl_->slots.resize(static_cast<size_t>(std::max(1, options.depth)));
-  for (int t = 0; t < std::max(1, options.planner_threads); ++t) impl_->workers.emplace_back([this] { impl_->Work(); });
+  // (threads are named so that a profile — or bench.py's per-thread CPU accounting over /proc/self/task — can tell the
+  // roles apart)
+  for (int t = 0; t < std::max(1, options.planner_threads); ++t)
+    impl_->workers.emplace_back([this] {
+      pthread_setname_np(pthread_self(), "mgx-plan");
+      impl_->Work();
+    });
   static const int kDispatchers = std::getenv("MGX_DISPATCHERS") ? atoi(std::getenv("MGX_DISPATCHERS")) : 3;
   const int n_dispatchers = std::max(1, std::min(kDispatchers, std::max(1, options.depth)));
-  for (int t = 0; t < n_dispatchers; ++t) impl_->dispatchers.emplace_back([this] { impl_->Dispatch(); });
+  for (int t = 0; t < n_dispatchers; ++t)
+    impl_->dispatchers.emplace_back([this] {
+      pthread_setname_np(pthread_self(), "mgx-dispatch");
+      impl_->Dispatch();
+    });
 }
 
 BatchExecutor::~BatchExecutor() {
@@ -1130,6 +1201,25 @@ Expected<std::vector<BatchResult>, Error> BatchExecutor::Wait(uint64_t ticket, T
   const Error e = WaitInto(ticket, &out, timing);
   if (e.code() != ErrorCode::kSuccess) return MakeUnexpected(e);
   return out;
+}
+
+Error BatchExecutor::Warm(const std::vector<BatchQuery>& sample, int rounds) {
+  const size_t depth = impl_->slots.size();
+  std::vector<uint64_t> tickets;
+  std::vector<BatchResult> sink;
+  for (int r = 0; r < std::max(1, rounds); ++r) {
+    tickets.clear();
+    for (size_t k = 0; k < depth; ++k) {  // all slots in flight at once: each one is touched in every round
+      auto t = Submit(sample);
+      if (!t) return t.error();
+      tickets.push_back(*t);
+    }
+    for (uint64_t t : tickets) {
+      const Error e = WaitInto(t, &sink);
+      if (e.code() != ErrorCode::kSuccess) return e;
+    }
+  }
+  return Error{ErrorCode::kSuccess, ""};
 }
 
 Error BatchExecutor::WaitInto(uint64_t ticket, std::vector<BatchResult>* results, Timing* timing) {

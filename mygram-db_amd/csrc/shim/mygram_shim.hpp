@@ -319,6 +319,12 @@ class BatchExecutor {
   // next batch in without allocating; clear() or overwrite them)
   mygram::utils::Expected<uint64_t, mygram::utils::Error> Submit(std::vector<BatchQuery>&& queries);
   mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> Wait(uint64_t ticket, Timing* timing = nullptr);
+  // Setup, outside any timed loop: runs `sample` through EVERY slot `rounds` times and throws the results away, so that
+  // each slot's device arenas, pinned blocks, stream and events, the dispatcher threads' compile helpers and the index's
+  // per-parameter tables (block-max bytes, length norms) exist before the first real batch — a serving process pays
+  // for them at start-up, not on its first requests. Nothing of a batch's RESULT is kept: real batches are planned,
+  // compiled and run from scratch. Call before the first Submit (no batch may be in flight).
+  mygram::utils::Error Warm(const std::vector<BatchQuery>& sample, int rounds = 2);
   // Wait into a vector the caller keeps from batch to batch (its elements' vectors are re-used: no allocation in steady
   // state); the returned Error's code is kSuccess on success.
   mygram::utils::Error WaitInto(uint64_t ticket, std::vector<BatchResult>* results, Timing* timing = nullptr);

@@ -134,29 +134,50 @@ int mgxs_executor_create(mgxs_table* table, int depth, int planner_threads, mgxs
 
 void mgxs_executor_destroy(mgxs_executor* ex) { delete ex; }
 
+namespace {
+void FillQueries(std::vector<BatchQuery>* out, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                 uint32_t limit, uint32_t offset, int sort_by_score, int descending) {
+  out->resize(n_queries);
+  size_t at = 0;
+  for (uint32_t i = 0; i < n_queries; ++i) {
+    BatchQuery& q = (*out)[i];  // (possibly an earlier batch's object: every field is set again)
+    q.terms.resize(n_terms[i]);
+    for (uint32_t t = 0; t < n_terms[i]; ++t) q.terms[t].assign(terms[at++]);
+    q.ast.reset();
+    q.not_terms.clear();
+    q.filters.clear();
+    q.fuzzy_max_distance = 0;
+    q.verify_text = false;
+    q.bm25 = mygramdb::index::BM25Params{};
+    q.sort_by_score = sort_by_score != 0;
+    q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
+    q.limit = limit;
+    q.offset = offset;
+  }
+}
+}  // namespace
+
+int mgxs_executor_warm(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                       uint32_t limit, uint32_t offset, int sort_by_score, int descending, int rounds) {
+  if (!ex || (n_queries && (!n_terms || !terms))) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_executor_warm: null argument");
+  try {
+    std::vector<BatchQuery> sample;
+    FillQueries(&sample, n_queries, n_terms, terms, limit, offset, sort_by_score, descending);
+    const auto e = ex->ex->Warm(sample, rounds);
+    if (e.code() != mygram::utils::ErrorCode::kSuccess) return Fail(static_cast<int>(e.code()), e.message());
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
                 uint32_t limit, uint32_t offset, int sort_by_score, int descending, uint64_t* ticket) {
   if (ticket) *ticket = 0;
   if (!ex || !ticket || (n_queries && (!n_terms || !terms)))
     return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_submit: null argument");
   try {
-    ex->queries.resize(n_queries);
-    size_t at = 0;
-    for (uint32_t i = 0; i < n_queries; ++i) {
-      BatchQuery& q = ex->queries[i];  // (possibly an earlier batch's object: every field is set again)
-      q.terms.resize(n_terms[i]);
-      for (uint32_t t = 0; t < n_terms[i]; ++t) q.terms[t].assign(terms[at++]);
-      q.ast.reset();
-      q.not_terms.clear();
-      q.filters.clear();
-      q.fuzzy_max_distance = 0;
-      q.verify_text = false;
-      q.bm25 = mygramdb::index::BM25Params{};
-      q.sort_by_score = sort_by_score != 0;
-      q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
-      q.limit = limit;
-      q.offset = offset;
-    }
+    FillQueries(&ex->queries, n_queries, n_terms, terms, limit, offset, sort_by_score, descending);
     ex->limit = limit;
     auto r = ex->ex->Submit(std::move(ex->queries));  // (hands an earlier batch's objects back: built into again above)
     if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());

@@ -256,6 +256,10 @@ class DeviceIndex:
         check(load().mgx_index_memory_bytes(self._h, C.byref(n)))
         return int(n.value)
 
+    def set_batch_order(self, fifo=True):
+        """mgx_index_set_batch_order: batches in flight run first-in-first-out (default) or time-slice the device."""
+        check(load().mgx_index_set_batch_order(self._h, 0 if fifo else 1))
+
     def attach_text(self, corpus):
         """Normalized doc text into HBM (text-level BM25 terms: tf/df by text scan)."""
         check(load().mgx_index_attach_text(self._h, corpus.text_bytes.ctypes.data, corpus.text_off.ctypes.data))
