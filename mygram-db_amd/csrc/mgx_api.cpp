@@ -1358,6 +1358,10 @@ struct mgx_batch {
     uint64_t seed_table_docs = 0;  // table-wide doc count of those queries (BM25 N): the exchange pays on large shards only
     DevBuf d_has_seed;         // [n] u8: the query's first candidate list is a seed item's
     DevBuf d_fast_queries, d_items_fast[mgx::kFastMaxScore];
+    // selective flat queries (a sparse posting list drives: cand_kernel), score and docid-page groups
+    mgx::DevBatch dev_cand{};
+    DevBuf d_items_cand, d_cand_skip;  // d_cand_skip [n] u8: the query is candidate-driven (docid-page group)
+    uint32_t cand_leaves = 0, cand_instr = 0, cand_cap = 0;
     // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
     mgx::DevBatch dev_page_wave{}, dev_page_block{};
     DevBuf d_pq_wave, d_pq_block;
@@ -1680,6 +1684,63 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
     g.wplan = WavePlan{wl, 0, wi, 0, 0, has_list ? 1u : 0u, 0};
   }
+  // ---- selective queries: candidate-driven (cand_kernel). The smallest positive operand drives when it is a sorted
+  // posting array (a gram too sparse for a bitmap row) that the program loads before its first COUNT — terms arrive
+  // smallest-first (search_pipeline.cpp:2012-2014), so that is a gram of the first term and every funnel counter is a
+  // count of candidates. Everything else of the query is probed per candidate.
+  std::vector<uint32_t> cand_driver;
+  g.cand_leaves = g.cand_instr = g.cand_cap = 0;
+  if (score_mode || page_mode) {
+    const bool allow_cand = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr &&
+                                   !(std::getenv("MGX_CAND") && atoi(std::getenv("MGX_CAND")) == 0);
+    static const uint64_t kMaxPerTile = std::getenv("MGX_CAND_MAX_PER_TILE") ? static_cast<uint64_t>(atoll(std::getenv("MGX_CAND_MAX_PER_TILE"))) : 64ull;
+    const mgx_index* idx = b->idx;
+    for (uint32_t i = 0; allow_cand && i < n; ++i) {
+      const QuerySpec& s = specs[g.qids[i]];
+      if (on_wave[i] == 3 || !s.flat || s.prog.empty()) continue;
+      if (score_mode && (!s.fast_score_ok || s.score.empty())) continue;
+      bool ok = true, counted = false;
+      uint32_t driver = kNoLeaf;
+      uint64_t best = ~0ull;
+      for (size_t pc = 0; ok && pc < s.prog.size(); ++pc) {
+        const uint32_t op = s.prog[pc] >> 24, arg = s.prog[pc] & 0xFFFFFFu;
+        if (op == kOpCount) {
+          counted = true;
+          continue;
+        }
+        if ((op == kOpLoad) != (pc == 0) || (op != kOpLoad && op != kOpAnd && op != kOpAndNot)) { ok = false; break; }
+        const DevLeaf& lf = s.leaves[arg];
+        if (lf.kind != kLeafList && lf.kind != kLeafGramBitmap && lf.kind != kLeafFilterBitmap) { ok = false; break; }
+        // any positive gram loaded before the first COUNT makes every counter a count of candidates; the smallest of them
+        // drives (with terms in the reference's order that is the smallest gram of the whole query)
+        if (op == kOpAndNot || lf.kind == kLeafFilterBitmap || counted) continue;
+        const uint64_t sz = idx->h_offsets[lf.a + 1] - idx->h_offsets[lf.a];
+        if (sz < best) {
+          best = sz;
+          driver = arg;
+        }
+      }
+      if (!ok || driver == kNoLeaf || s.leaves[driver].kind != kLeafList) continue;
+      if (best > kMaxPerTile * b->idx->dev.n_tiles) continue;
+      for (uint32_t ins : s.prog)  // NOT of the driver's own gram: the tile program handles it (the result is empty)
+        if ((ins >> 24) == kOpAndNot && (ins & 0xFFFFFFu) == driver) ok = false;
+      if (score_mode)
+        for (const DevScoreTerm& st : s.score)
+          ok = ok && st.leaf != kNoLeaf && (s.leaves[st.leaf].kind == kLeafList || s.leaves[st.leaf].kind == kLeafGramBitmap);
+      if (!ok) continue;
+      if (cand_driver.empty()) cand_driver.assign(n, kNoLeaf);
+      cand_driver[i] = driver;
+      on_wave[i] = 4;
+      g.cand_leaves = std::max(g.cand_leaves, dq[i].n_leaves);
+      g.cand_instr = std::max(g.cand_instr, dq[i].n_instr);
+      g.cand_cap = std::max(g.cand_cap, dq[i].cap);
+    }
+    if (CandLdsBytes(g.cand_leaves, g.cand_instr, score_mode ? g.cand_cap : 0) > 150 * 1024) {
+      for (auto& w : on_wave)
+        if (w == 4) w = 0;  // (a page of a thousand entries with many operands: the general kernel takes these)
+      cand_driver.clear();
+    }
+  }
   if (g.plan.bytes > 160 * 1024)
     return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
   sec.Mark(1);
@@ -1754,6 +1815,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       // serves from becoming the tail of the step
       if (score_mode && !on_wave[i]) tiles = 8;
       list_begin[i] = n_lists;
+      if (on_wave[i] == 4) {  // candidate-driven: one workgroup holds the whole query (tile_begin = the driver's leaf)
+        items.push_back(DevItem{i, cand_driver[i], 0, n_lists++});
+        continue;
+      }
       uint32_t t0 = 0;
       // Fast path: a short "seed" item first (two tiles per wave), launched ahead of everything else (below): it scores
       // its tiles unpruned and publishes the query's first k-th best score, so the long items start pruning at once.
@@ -1834,7 +1899,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
   }
   const uint32_t n_lists_all = n_lists;
-  std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore];
+  std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore], items_cand;
   std::vector<uint8_t> has_seed(n, 0);
   uint32_t seed_k = 0;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0: the fast path's seed items (a query's first list), then the rest
@@ -1844,6 +1909,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
                         list_begin[it.query + 1] - list_begin[it.query] > 1 && it.n_tiles <= 16;
       if (seed != (pass == 0)) continue;
       if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
+      else if (w == 4) items_cand.push_back(it);
       else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
       if (seed && fastq[it.query].blockmax != 0) has_seed[it.query] = 1;  // (a query that prunes: its seed's keys are worth sharing)
     }
@@ -1870,6 +1936,12 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   if (!fastq.empty()) MGX_HIP(Upload(g.d_fast_queries, fastq.data(), fastq.size()));
   for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));
   MGX_HIP(Upload(g.d_items_wave_lists, items_wave_lists.data(), items_wave_lists.size()));
+  MGX_HIP(Upload(g.d_items_cand, items_cand.data(), items_cand.size()));
+  if (page_mode && !items_cand.empty()) {
+    std::vector<uint8_t> skip(n, 0);
+    for (uint32_t i = 0; i < n; ++i) skip[i] = on_wave[i] == 4 ? 1 : 0;
+    MGX_HIP(Upload(g.d_cand_skip, skip.data(), skip.size()));
+  }
   g.n_items = static_cast<uint32_t>(items_block.size());
   g.n_items_wave = static_cast<uint32_t>(items_wave.size());
   MGX_HIP(Upload(g.d_items, items_block.data(), items_block.size()));
@@ -1879,11 +1951,11 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   if (std::getenv("MGX_VERBOSE"))
     fprintf(stderr,
             "[mgx] %s group: %u queries; fast path %zu items (lds %u B, ring %u), wave kernel %u items (lds %u B), "
-            "block kernel %u items (lds %u B)\n",
-            score_mode ? "score" : "bitmap", n,
+            "block kernel %u items (lds %u B), candidate-driven %zu queries\n",
+            score_mode ? "score" : page_mode ? "docid-page" : df_mode ? "df" : "bitmap", n,
             items_fast[0].size() + items_fast[1].size() + items_fast[2].size() + items_fast[3].size() + items_fast[4].size(),
             g.fplan.bytes, g.fplan.ring, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()), g.wplan.bytes, g.n_items,
-            g.plan.bytes);
+            g.plan.bytes, items_cand.size());
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
   d.n_items = g.n_items;
@@ -1958,6 +2030,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     g.dev_fast[t].items = g.d_items_fast[t].as<DevItem>();
     g.dev_fast[t].n_items = static_cast<uint32_t>(items_fast[t].size());
   }
+  g.dev_cand = d;
+  g.dev_cand.items = g.d_items_cand.as<DevItem>();
+  g.dev_cand.n_items = static_cast<uint32_t>(items_cand.size());
   g.dev_wave = d;
   g.dev_wave.items = g.d_items_wave.as<DevItem>();
   g.dev_wave.n_items = g.n_items_wave;
@@ -1966,7 +2041,8 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   g.dev_wave_lists.n_items = static_cast<uint32_t>(items_wave_lists.size());
   if (page_mode) {
     std::vector<DevItem> pw, pb;
-    for (uint32_t i = 0; i < n; ++i) (on_wave[i] ? pw : pb).push_back(DevItem{i, 0, 0, 0});
+    for (uint32_t i = 0; i < n; ++i)
+      if (on_wave[i] != 4) (on_wave[i] ? pw : pb).push_back(DevItem{i, 0, 0, 0});  // (cand_kernel writes its own pages)
     MGX_HIP(Upload(g.d_pq_wave, pw.data(), pw.size()));
     MGX_HIP(Upload(g.d_pq_block, pb.data(), pb.size()));
     g.dev_page_wave = d;
@@ -2342,7 +2418,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     uint32_t n_fast = 0;
     for (int t = 0; t < kFastMaxScore; ++t) n_fast += g.dev_fast[t].n_items;
     const bool main_work = n_fast != 0 || g.n_items_wave != 0;
-    const bool side_work = g.n_items != 0 || g.dev_wave_lists.n_items != 0;
+    const bool side_work = g.n_items != 0 || g.dev_wave_lists.n_items != 0 || g.dev_cand.n_items != 0;
     hipStream_t side = s;
     if (main_work && side_work) {
       // fork: the (small) shares of the general kernel and of the list-operand plan run on the side stream while the
@@ -2355,6 +2431,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
       MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->res->fork_ev, 0));
       side = idx->side_stream;
     }
+    MGX_LAUNCH(LaunchCand(kModeScore, idx->dev, g.dev_cand, g.cand_leaves, g.cand_instr, g.cand_cap, side));
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
     MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side));
     // (both conditions are the same on every rank: the collective is entered by all or by none)
@@ -2424,6 +2501,19 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
+    // candidate-driven queries (selective: a sparse list drives) beside the tile passes, on the side stream: they write
+    // their totals and pages themselves
+    const bool cand_side = g.dev_cand.n_items != 0 && (g.dev_wave.n_items != 0 || g.n_items != 0) && b->res_owned;
+    if (cand_side) {
+      if (!b->res->fork_ev) {
+        MGX_HIP(hipEventCreateWithFlags(&b->res->fork_ev, hipEventDisableTiming));
+        MGX_HIP(hipEventCreateWithFlags(&b->res->join_ev, hipEventDisableTiming));
+      }
+      MGX_HIP(hipEventRecord(b->res->fork_ev, s));
+      MGX_HIP(hipStreamWaitEvent(idx->side_stream, b->res->fork_ev, 0));
+      MGX_LAUNCH(LaunchCand(kModeDocPage, idx->dev, g.dev_cand, g.cand_leaves, g.cand_instr, 0, idx->side_stream));
+      MGX_HIP(hipEventRecord(b->res->join_ev, idx->side_stream));
+    }
     MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, false, s));
     MGX_LAUNCH(LaunchTileEval(kModeDocCount, idx->dev, g.dev, g.plan, s));
     if (b->timing && !timed) {
@@ -2431,9 +2521,11 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
       timed = true;
     }
     MGX_LAUNCH(LaunchScanTiles(g.dev.tile_cnt, n, idx->dev.n_tiles, b->d_ptile_start.as<uint64_t>(),
-                               const_cast<uint64_t*>(g.dev.totals), s));
+                               const_cast<uint64_t*>(g.dev.totals), s, g.d_cand_skip.as<uint8_t>()));
+    if (!cand_side) MGX_LAUNCH(LaunchCand(kModeDocPage, idx->dev, g.dev_cand, g.cand_leaves, g.cand_instr, 0, s));
     MGX_LAUNCH(LaunchWavePage(idx->dev, g.dev_page_wave, g.wplan, s));
     MGX_LAUNCH(LaunchTileEval(kModeDocPage, idx->dev, g.dev_page_block, g.plan, s));
+    if (cand_side) MGX_HIP(hipStreamWaitEvent(s, b->res->join_ev, 0));
   }
   if (b->timing) {
     if (timed) {

@@ -2246,6 +2246,306 @@ __global__ __launch_bounds__(kBlock) void wave_page_kernel(DevIndex ix, DevBatch
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// cand_kernel: candidate-driven evaluation of SELECTIVE flat queries (a sparse sorted posting list drives)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// The reference stops scanning as soon as a conjunction is small: Execute probes the remaining terms instead of
+// intersecting them once <= 1000 candidates are left (search_pipeline.cpp:828-829 -> Index::FilterByNgrams ->
+// PostingList::RetainPresent, posting_list.cpp:432-474), SearchAnd sorts its lists smallest-first and exits when the
+// accumulator is empty (index.cpp:228-240,338-351), Intersect gallops (posting_list.cpp:634-715). The tile kernels of
+// this file evaluate every tile of every operand whatever the sizes: a query whose smallest list has a thousand postings
+// walked all 611 tiles of all its operands. Here the smallest positive operand — a sorted u32 posting array that is too
+// sparse to have a bitmap row — IS the candidate set:
+//   * one workgroup of sixteen waves per query, each wave takes a contiguous share of the driver list, 128 postings per
+//     step, two per lane (coalesced 256-byte loads; the driver's tf byte sits at the same index);
+//   * every other operand is PROBED per candidate, in program order: a bitmap-form operand (dense gram, filter) by one
+//     8-byte gather of the word that holds the doc's bit; another sorted list by a binary search inside the candidate's
+//     tile segment (skip row) — the galloping step of a merge whose other side is a few postings long; NOT terms and NE
+//     filters invert the test. A wave whose 64 candidates are all dead skips the rest of the program (the early exit);
+//   * funnel counters are popcounts of the alive mask where the tile program has its COUNT instructions — exact, because
+//     the host only sends a query here when its driver is loaded before the first COUNT (terms arrive smallest-first,
+//     search_pipeline.cpp:2012-2014, so the driver is a gram of the first term);
+//   * SORT _score: survivors are scored in place — tf from the driver's own tf column, from the doc-slot nibble row of a
+//     dense gram, or by the same segment search for another sparse gram; BM25 in the reference's fp64 operation order
+//     (bm25_scorer.cpp:73-88) — and offered to the per-wave top-k; docid-ordered pages: pass 1 counts, a workgroup
+//     barrier turns the waves' counts into rank offsets, pass 2 re-probes only the waves that hold ranks of the page and
+//     writes the doc ids at their rank positions.
+// Bytes touched per query: 5 B per driver posting + one 64-byte sector per (candidate still alive, operand) instead of
+// 2 KiB per (tile, operand).
+// 16 waves per query and two candidates per lane in flight: a probe is a dependent global load (a microsecond under
+// load), and with four waves and one candidate per lane a 48,000-posting driver was a chain of ~1,000 such loads per wave.
+constexpr int kCandBlock = 1024;
+constexpr int kCandWaves = kCandBlock / 64;
+constexpr int kCandU = 2;
+
+struct CandOffsets {
+  uint32_t leaf, prog, misc, tk_keys, tk_docs, total;
+};
+__host__ __device__ inline CandOffsets carve_cand(uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap) {
+  CandOffsets o;
+  uint32_t at = 0;
+  o.leaf = at;     at += align8(max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
+  o.prog = at;     at += align8(max_instr * 4);
+  o.misc = at;     at += kCandWaves * 8 * 4;
+  o.tk_keys = at;  at += kCandWaves * 2 * max_cap * 8;
+  o.tk_docs = at;  at += kCandWaves * 2 * max_cap * 4;
+  o.total = at;
+  return o;
+}
+uint32_t CandLdsBytes(uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap) {
+  return carve_cand(max_leaves ? max_leaves : 1, max_instr ? max_instr : 1, max_cap).total;
+}
+
+// Is the doc at `slot` (tile `tile`, doc id `d`) a member of operand `lf`?
+__device__ __forceinline__ bool cand_member(const DevIndex& ix, const DevLeaf lf, uint32_t d, uint32_t slot, uint32_t tile) {
+  if (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap) {
+    const uint32_t w = (slot & (kTileDocs - 1)) >> 6;
+    const uint64_t* wp = lf.kind == kLeafGramBitmap
+                             ? ix.gram_bitmaps + tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + w
+                             : ix.filter_bitmaps + tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + w;
+    return ((*wp >> (slot & 63)) & 1ull) != 0;
+  }
+  if (lf.kind == kLeafList) {
+    const uint64_t l0 = ix.offsets[lf.a];
+    uint64_t lo = l0, hi = ix.offsets[lf.a + 1];
+    if (lf.row != kNoRow) {
+      const uint32_t* r = ix.tile_off + static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1);
+      hi = l0 + r[tile + 1];
+      lo = l0 + r[tile];
+    }
+    const uint64_t p = lower_bound_u32(ix.docids, lo, hi, d);
+    return p < hi && ix.docids[p] == d;
+  }
+  if (lf.kind == kLeafRange) return slot >= lf.a && slot < lf.b;
+  return false;
+}
+
+// The flat program on kCandU candidates per lane (alive[u]: the lane holds a posting of the driver). On return alive[u]
+// marks the survivors; the funnel counts of the wave are added to cnt[0..3].
+__device__ __forceinline__ void cand_run_program(const DevIndex& ix, const DevLeaf* leaf, const uint32_t* prog,
+                                                 uint32_t n_instr, uint32_t driver_leaf, bool (&alive)[kCandU],
+                                                 const uint32_t (&d)[kCandU], uint32_t (&cnt)[4]) {
+  for (uint32_t pc = 0; pc < n_instr; ++pc) {
+    const uint32_t ins = prog[pc];
+    const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+    uint64_t any = 0;
+    uint32_t c = 0;
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {
+      const uint64_t m = __ballot(alive[u]);
+      any |= m;
+      c += static_cast<uint32_t>(__popcll(m));
+    }
+    if (op == kOpCount) {
+      cnt[0] += (arg & 1u) ? c : 0;
+      cnt[1] += (arg & 2u) ? c : 0;
+      cnt[2] += (arg & 4u) ? c : 0;
+      cnt[3] += (arg & 8u) ? c : 0;
+      continue;
+    }
+    if (arg == driver_leaf) continue;  // (LOAD / AND of the candidate set itself)
+    if (any == 0) break;               // nothing left: the rest of the program counts zeros
+    const DevLeaf lf = leaf[arg];
+    bool in[kCandU];
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {  // (the probes of the lane's candidates are independent loads: in flight together)
+      const uint32_t slot = d[u] - ix.first_doc_id;
+      in[u] = alive[u] && cand_member(ix, lf, d[u], slot, slot >> kTileShift);
+    }
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) alive[u] = op == kOpAndNot ? (alive[u] && !in[u]) : in[u];
+  }
+}
+
+template <int MODE>  // kModeScore | kModeDocPage
+__global__ __launch_bounds__(kCandBlock) void cand_kernel(DevIndex ix, DevBatch bt, uint32_t max_leaves, uint32_t max_instr,
+                                                          uint32_t max_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const CandOffsets co = carve_cand(max_leaves, max_instr, max_cap);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + co.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + co.prog);
+  uint32_t* const wcnt = reinterpret_cast<uint32_t*>(smem + co.misc);  // [kCandWaves][8]
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  constexpr uint32_t kStep = 64 * kCandU;
+
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query, driver_leaf = it.tile_begin;
+  const DevQuery q = bt.queries[qi];
+  for (uint32_t i = tid; i < q.n_leaves; i += kCandBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kCandBlock) prog[i] = bt.prog[q.prog_begin + i];
+  __syncthreads();
+  const uint32_t dgram = leaf[driver_leaf].a;
+  const uint64_t l0 = ix.offsets[dgram], l1 = ix.offsets[dgram + 1];
+  // this wave's contiguous share of the driver list, in whole steps
+  const uint64_t steps = (l1 - l0 + kStep - 1) / kStep, per = (steps + kCandWaves - 1) / kCandWaves;
+  const uint64_t wa = min(l1, l0 + wave * per * kStep), wb = min(l1, wa + per * kStep);
+
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  uint32_t cnt_res = 0;
+  const bool desc = q.descending != 0;
+
+  WaveTopK tk;
+  if (MODE == kModeScore) {
+    tk.cap = q.cap;
+    tk.needed = q.needed;
+    tk.lds_sort = false;
+    tk.keys = reinterpret_cast<uint64_t*>(smem + co.tk_keys) + static_cast<size_t>(wave) * 2 * q.cap;
+    tk.docs = reinterpret_cast<uint32_t*>(smem + co.tk_docs) + static_cast<size_t>(wave) * 2 * q.cap;
+    tk.have = 0;
+    tk.pend = 0;
+    tk.bound_key = 0;
+    tk.bound_doc = 0;
+    tk.gbound_ptr = nullptr;  // (one workgroup holds the whole query: nothing to share)
+    tk.gbound = 0;
+    for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
+      tk.keys[i] = 0;
+      tk.docs[i] = 0;
+    }
+    wave_lds_sync();
+  }
+
+  for (uint64_t p0 = wa; p0 < wb; p0 += kStep) {
+    bool alive[kCandU];
+    uint32_t d[kCandU];
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {
+      const uint64_t p = p0 + u * 64 + lane;
+      alive[u] = p < wb;
+      d[u] = alive[u] ? ix.docids[p] : ix.first_doc_id;
+    }
+    cand_run_program(ix, leaf, prog, q.n_instr, driver_leaf, alive, d, cnt);
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {
+      const uint64_t amask = __ballot(alive[u]);
+      cnt_res += static_cast<uint32_t>(__popcll(amask));
+      if (MODE == kModeScore && amask != 0) {
+        // BM25Scorer::ScoreDocuments for the survivors, term by term in the query's order (bm25_scorer.cpp:73-88)
+        const uint64_t p = p0 + u * 64 + lane;
+        const uint32_t slot = d[u] - ix.first_doc_id;
+        double score = 0.0;
+        uint32_t dl = 0;
+        if (alive[u]) {
+          dl = ix.dl8[slot];
+          if (dl == 255u) dl = ix.doc_len[slot];
+        }
+        const double length_norm = q.one_minus_b + q.b * static_cast<double>(dl) / q.avgdl_clamped;
+        for (uint32_t i = 0; i < q.n_score; ++i) {
+          const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+          const DevLeaf lf = leaf[st.leaf];
+          uint32_t tfv = 0;
+          if (alive[u]) {
+            if (st.leaf == driver_leaf) {
+              tfv = posting_tf(ix, p);
+            } else if (lf.kind == kLeafGramBitmap) {
+              const uint32_t nb = ix.tfnib[static_cast<uint64_t>(lf.b) * ix.nib_row_stride + (slot >> 1)];
+              tfv = (nb >> ((slot & 1u) * 4u)) & 15u;
+              if (tfv == 15u) tfv = exact_tf(ix, lf.a, lf.row, slot);
+            } else if (lf.kind == kLeafList) {
+              tfv = exact_tf(ix, lf.a, lf.row, slot);
+            }
+          }
+          if (tfv != 0) {
+            const double tf = static_cast<double>(tfv);
+            const double numerator = tf * q.k1_plus_1;
+            const double denominator = tf + q.k1 * length_norm;
+            score += st.idf * numerator / denominator;
+          }
+        }
+        wave_topk_offer(tk, alive[u], score_key(score, desc), desc ? d[u] : ~d[u]);
+      }
+    }
+  }
+
+  // ---- counters: one workgroup holds the whole query ------------------------------------------------------------------
+  if (lane == 0) {
+    wcnt[wave * 8 + 0] = cnt[0];
+    wcnt[wave * 8 + 1] = cnt[1];
+    wcnt[wave * 8 + 2] = cnt[2];
+    wcnt[wave * 8 + 3] = cnt[3];
+    wcnt[wave * 8 + 4] = cnt_res;
+  }
+  if (MODE == kModeScore) {
+    wave_topk_truncate(tk);
+    if (lane == 0) wcnt[wave * 8 + 5] = tk.have;
+  }
+  __syncthreads();
+  if (tid < 5) {
+    unsigned long long v = 0;
+    for (int w = 0; w < kCandWaves; ++w) v += wcnt[w * 8 + tid];
+    bt.counters[static_cast<uint64_t>(qi) * 8 + tid] = v;
+  }
+
+  if (MODE == kModeScore) {
+    // the waves' lists -> this query's one candidate list, best first (rank by counting the better entries elsewhere)
+    const uint64_t* all_keys = reinterpret_cast<const uint64_t*>(smem + co.tk_keys);
+    const uint32_t* all_docs = reinterpret_cast<const uint32_t*>(smem + co.tk_docs);
+    const uint32_t cap = q.cap;
+    uint32_t total = 0;
+    for (int w = 0; w < kCandWaves; ++w) total += min(wcnt[w * 8 + 5], q.needed);
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
+    for (uint32_t e = tid; e < kCandWaves * cap; e += kCandBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= min(wcnt[w * 8 + 5], q.needed)) continue;
+      const uint64_t k = all_keys[static_cast<size_t>(w) * 2 * cap + i];
+      const uint32_t dd0 = all_docs[static_cast<size_t>(w) * 2 * cap + i];
+      uint32_t rank = i;
+      for (uint32_t w2 = 0; w2 < static_cast<uint32_t>(kCandWaves) && rank < q.needed; ++w2) {
+        if (w2 == w) continue;
+        const uint64_t* kk = all_keys + static_cast<size_t>(w2) * 2 * cap;
+        const uint32_t* dd = all_docs + static_cast<size_t>(w2) * 2 * cap;
+        uint32_t lo = 0, hi = min(wcnt[w2 * 8 + 5], q.needed);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, dd0)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < q.needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = dd0;
+      }
+    }
+    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
+    return;
+  }
+
+  // ---- docid-ordered page: ranks of the survivors, then the page -----------------------------------------------------
+  uint64_t total = 0, my_start = 0;
+  for (int w = 0; w < kCandWaves; ++w) {
+    if (static_cast<uint32_t>(w) == wave) my_start = total;
+    total += wcnt[w * 8 + 4];
+  }
+  if (tid == 0) const_cast<uint64_t*>(bt.totals)[q.out_slot] = total;
+  const uint64_t take = total < q.limit ? total : q.limit;
+  if (take == 0) return;
+  const uint64_t lo = desc ? total - take : 0, hi = desc ? total : take;
+  if (my_start >= hi || my_start + cnt_res <= lo) return;  // wave-uniform: none of this wave's ranks is on the page
+  uint32_t* const out = bt.page_docs + static_cast<uint64_t>(q.out_slot) * bt.page_stride;
+  uint64_t rank0 = my_start;
+  uint32_t dummy[4] = {0, 0, 0, 0};
+  for (uint64_t p0 = wa; p0 < wb && rank0 < hi; p0 += kStep) {
+    bool alive[kCandU];
+    uint32_t d[kCandU];
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {
+      const uint64_t p = p0 + u * 64 + lane;
+      alive[u] = p < wb;
+      d[u] = alive[u] ? ix.docids[p] : ix.first_doc_id;
+    }
+    cand_run_program(ix, leaf, prog, q.n_instr, driver_leaf, alive, d, dummy);
+#pragma unroll
+    for (int u = 0; u < kCandU; ++u) {
+      const uint64_t amask = __ballot(alive[u]);
+      if (alive[u]) {
+        const uint64_t rank = rank0 + static_cast<uint64_t>(__popcll(amask & ((1ull << lane) - 1ull)));
+        if (rank >= lo && rank < hi) out[desc ? total - 1 - rank : rank] = d[u];
+      }
+      rank0 += static_cast<uint64_t>(__popcll(amask));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // merge of sorted candidate lists (per-workgroup lists of one shard, or per-shard lists of one query)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -2474,10 +2774,12 @@ __global__ void sum_totals_kernel(const uint64_t* __restrict__ totals, uint32_t 
 // Exclusive scan of tile_cnt per bitmap-mode query (one workgroup each): tile_start[slot][t], total[slot].
 __global__ __launch_bounds__(kBlock) void scan_tiles_kernel(const uint32_t* __restrict__ tile_cnt, uint32_t n_tiles,
                                                             uint64_t* __restrict__ tile_start,
-                                                            uint64_t* __restrict__ totals) {
+                                                            uint64_t* __restrict__ totals,
+                                                            const uint8_t* __restrict__ skip) {
   __shared__ uint64_t s_carry;
   __shared__ uint32_t s_w[4];
   const uint32_t slot = blockIdx.x;
+  if (skip != nullptr && skip[slot] != 0) return;  // a query without tile counts (cand_kernel writes its total itself)
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
   for (uint32_t base = 0; base < n_tiles; base += kBlock) {
@@ -2904,6 +3206,24 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
   return 0;
 }
 
+int LaunchCand(int mode, const DevIndex& ix, const DevBatch& bt, uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap,
+               hipStream_t s) {
+  if (bt.n_items == 0) return 0;
+  if (max_leaves == 0) max_leaves = 1;
+  if (max_instr == 0) max_instr = 1;
+  const uint32_t lds = carve_cand(max_leaves, max_instr, mode == kModeScore ? max_cap : 0).total;
+  auto* kernel = mode == kModeScore ? &cand_kernel<kModeScore> : &cand_kernel<kModeDocPage>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(kernel, dim3(bt.n_items), dim3(kCandBlock), lds, s, ix, bt, max_leaves, max_instr,
+                     mode == kModeScore ? max_cap : 0u);
+  MGX_KCHECK();
+  return 0;
+}
+
 template <int T>
 static int LaunchBitmapScoreT(const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s) {
   if (plan.bytes > 64 * 1024) {
@@ -3105,9 +3425,9 @@ int LaunchSumTotals(const uint64_t* totals, uint32_t n_shards, uint32_t n_querie
 }
 
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
-                    uint64_t* totals, hipStream_t s) {
+                    uint64_t* totals, hipStream_t s, const uint8_t* skip) {
   if (n_slots == 0) return 0;
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_slots), dim3(kBlock), 0, s, tile_cnt, n_tiles, tile_start, totals);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_slots), dim3(kBlock), 0, s, tile_cnt, n_tiles, tile_start, totals, skip);
   MGX_KCHECK();
   return 0;
 }

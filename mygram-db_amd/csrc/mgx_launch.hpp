@@ -21,6 +21,10 @@ int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
 int LaunchBitmapScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s);
 int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, bool text_df, hipStream_t s);
+// candidate-driven evaluation of selective flat queries (items: query, tile_begin = the driver's leaf index, list)
+int LaunchCand(int mode, const DevIndex& ix, const DevBatch& bt, uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap,
+               hipStream_t s);
+uint32_t CandLdsBytes(uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
 
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,
@@ -42,7 +46,7 @@ int LaunchBuildContribTables(const TableJob* jobs, uint32_t n_jobs, uint32_t tab
 int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, uint32_t n, uint64_t* local,
                    uint64_t* exchange, hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,
-                    uint64_t* totals, hipStream_t s);
+                    uint64_t* totals, hipStream_t s, const uint8_t* skip = nullptr);
 int LaunchExpand(const uint64_t* rbits, const uint64_t* tile_start, const uint64_t* totals, const uint64_t* take,
                  const uint64_t* out_off, const uint32_t* reverse, uint32_t n_slots, uint32_t n_tiles,
                  uint32_t first_doc_id, uint32_t* out, hipStream_t s);
