@@ -1362,6 +1362,10 @@ struct mgx_batch {
     mgx::DevBatch dev_cand{};
     DevBuf d_items_cand, d_cand_skip;  // d_cand_skip [n] u8: the query is candidate-driven (docid-page group)
     uint32_t cand_leaves = 0, cand_instr = 0, cand_cap = 0;
+    // SORT _score over long sorted posting arrays (merge_score_kernel: the driver's tile segments against staged bitmaps)
+    mgx::DevBatch dev_merge{};
+    DevBuf d_items_merge;
+    uint32_t merge_leaves = 0, merge_instr = 0, merge_ops = 0, merge_cap = 0;
     // docid-page group: the page pass runs one workgroup per query; flat programs on the wave kernel
     mgx::DevBatch dev_page_wave{}, dev_page_block{};
     DevBuf d_pq_wave, d_pq_block;
@@ -1690,6 +1694,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   // count of candidates. Everything else of the query is probed per candidate.
   std::vector<uint32_t> cand_driver;
   g.cand_leaves = g.cand_instr = g.cand_cap = 0;
+  g.merge_leaves = g.merge_instr = g.merge_ops = g.merge_cap = 0;
   if (score_mode || page_mode) {
     const bool allow_cand = std::getenv("MGX_FORCE_BLOCK_KERNEL") == nullptr &&
                                    !(std::getenv("MGX_CAND") && atoi(std::getenv("MGX_CAND")) == 0);
@@ -1721,13 +1726,27 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         }
       }
       if (!ok || driver == kNoLeaf || s.leaves[driver].kind != kLeafList) continue;
-      if (best > kMaxPerTile * b->idx->dev.n_tiles) continue;
       for (uint32_t ins : s.prog)  // NOT of the driver's own gram: the tile program handles it (the result is empty)
         if ((ins >> 24) == kOpAndNot && (ins & 0xFFFFFFu) == driver) ok = false;
       if (score_mode)
         for (const DevScoreTerm& st : s.score)
           ok = ok && st.leaf != kNoLeaf && (s.leaves[st.leaf].kind == kLeafList || s.leaves[st.leaf].kind == kLeafGramBitmap);
       if (!ok) continue;
+      if (best > kMaxPerTile * b->idx->dev.n_tiles) {
+        // a LONG driver: too many candidates to probe one by one — the tile-synchronous merge (SORT _score only; docid
+        // pages of such queries stay on the counting kernels, which have no per-match work)
+        const bool allow_merge = !(std::getenv("MGX_MERGE") && atoi(std::getenv("MGX_MERGE")) == 0);
+        uint32_t staged = 0;
+        for (size_t li = 0; li < s.leaves.size(); ++li) staged += li != driver ? 1u : 0u;
+        if (!score_mode || !allow_merge || staged > kMergeMaxOps || dq[i].cap > 256) continue;
+        dq[i].pat_off = driver;  // (unused by score-mode queries otherwise: where the kernel finds its driver)
+        on_wave[i] = 5;
+        g.merge_leaves = std::max(g.merge_leaves, dq[i].n_leaves);
+        g.merge_instr = std::max(g.merge_instr, dq[i].n_instr);
+        g.merge_ops = std::max(g.merge_ops, staged);
+        g.merge_cap = std::max(g.merge_cap, dq[i].cap);
+        continue;
+      }
       if (cand_driver.empty()) cand_driver.assign(n, kNoLeaf);
       cand_driver[i] = driver;
       on_wave[i] = 4;
@@ -1740,6 +1759,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         if (w == 4) w = 0;  // (a page of a thousand entries with many operands: the general kernel takes these)
       cand_driver.clear();
     }
+    if (MergeLdsBytes(g.merge_leaves, g.merge_instr, g.merge_ops, g.merge_cap) > 150 * 1024)
+      for (auto& w : on_wave)
+        if (w == 5) w = 0;
   }
   if (g.plan.bytes > 160 * 1024)
     return Fail(MGX_ERR_NOT_IMPLEMENTED, "query shape exceeds the 160 KiB LDS of a CU");
@@ -1870,6 +1892,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     static const double kSqueezeEnv = std::getenv("MGX_HEAVY_SQUEEZE") ? atof(std::getenv("MGX_HEAVY_SQUEEZE")) : -1.0;
     const double kHeavySqueeze = kSqueezeEnv >= 0.0 ? kSqueezeEnv : 0.6 + 0.4 * std::min(1.0, n_tiles / 600.0);
     auto band_of = [&](const DevItem& it) {
+      if (on_wave[it.query] == 4) return 0u;  // (a candidate-driven item covers the whole query; tile_begin holds its driver)
       const uint32_t band = it.tile_begin / kSortTiles;
       if (score_mode && on_wave[it.query] == 3 && specs[g.qids[it.query]].est_density >= kHeavyDensity)
         return static_cast<uint32_t>(band * kHeavySqueeze);
@@ -1899,7 +1922,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     }
   }
   const uint32_t n_lists_all = n_lists;
-  std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore], items_cand;
+  std::vector<DevItem> items_wave, items_block, items_wave_lists, items_fast[kFastMaxScore], items_cand, items_merge;
   std::vector<uint8_t> has_seed(n, 0);
   uint32_t seed_k = 0;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0: the fast path's seed items (a query's first list), then the rest
@@ -1910,6 +1933,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       if (seed != (pass == 0)) continue;
       if (w == 3) items_fast[fastq[it.query].n_score - 1].push_back(it);
       else if (w == 4) items_cand.push_back(it);
+      else if (w == 5) items_merge.push_back(it);
       else (w == 2 && score_mode ? items_wave_lists : w ? items_wave : items_block).push_back(it);
       if (seed && fastq[it.query].blockmax != 0) has_seed[it.query] = 1;  // (a query that prunes: its seed's keys are worth sharing)
     }
@@ -1937,6 +1961,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   for (int t = 0; t < kFastMaxScore; ++t) MGX_HIP(Upload(g.d_items_fast[t], items_fast[t].data(), items_fast[t].size()));
   MGX_HIP(Upload(g.d_items_wave_lists, items_wave_lists.data(), items_wave_lists.size()));
   MGX_HIP(Upload(g.d_items_cand, items_cand.data(), items_cand.size()));
+  MGX_HIP(Upload(g.d_items_merge, items_merge.data(), items_merge.size()));
   if (page_mode && !items_cand.empty()) {
     std::vector<uint8_t> skip(n, 0);
     for (uint32_t i = 0; i < n; ++i) skip[i] = on_wave[i] == 4 ? 1 : 0;
@@ -1951,11 +1976,11 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
   if (std::getenv("MGX_VERBOSE"))
     fprintf(stderr,
             "[mgx] %s group: %u queries; fast path %zu items (lds %u B, ring %u), wave kernel %u items (lds %u B), "
-            "block kernel %u items (lds %u B), candidate-driven %zu queries\n",
+            "block kernel %u items (lds %u B), candidate-driven %zu queries, list merge %zu items\n",
             score_mode ? "score" : page_mode ? "docid-page" : df_mode ? "df" : "bitmap", n,
             items_fast[0].size() + items_fast[1].size() + items_fast[2].size() + items_fast[3].size() + items_fast[4].size(),
             g.fplan.bytes, g.fplan.ring, g.n_items_wave + static_cast<uint32_t>(items_wave_lists.size()), g.wplan.bytes, g.n_items,
-            g.plan.bytes, items_cand.size());
+            g.plan.bytes, items_cand.size(), items_merge.size());
   DevBatch& d = g.dev;
   d.items = g.d_items.as<DevItem>();
   d.n_items = g.n_items;
@@ -2030,6 +2055,9 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     g.dev_fast[t].items = g.d_items_fast[t].as<DevItem>();
     g.dev_fast[t].n_items = static_cast<uint32_t>(items_fast[t].size());
   }
+  g.dev_merge = d;
+  g.dev_merge.items = g.d_items_merge.as<DevItem>();
+  g.dev_merge.n_items = static_cast<uint32_t>(items_merge.size());
   g.dev_cand = d;
   g.dev_cand.items = g.d_items_cand.as<DevItem>();
   g.dev_cand.n_items = static_cast<uint32_t>(items_cand.size());
@@ -2417,7 +2445,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     }
     uint32_t n_fast = 0;
     for (int t = 0; t < kFastMaxScore; ++t) n_fast += g.dev_fast[t].n_items;
-    const bool main_work = n_fast != 0 || g.n_items_wave != 0;
+    const bool main_work = n_fast != 0 || g.n_items_wave != 0 || g.dev_merge.n_items != 0;
     const bool side_work = g.n_items != 0 || g.dev_wave_lists.n_items != 0 || g.dev_cand.n_items != 0;
     hipStream_t side = s;
     if (main_work && side_work) {
@@ -2459,6 +2487,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
         MGX_LAUNCH(LaunchBitmapScore(static_cast<uint32_t>(t + 1), idx->dev, g.dev_fast[t], g.fplan, s));
     }
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave, g.wplan, s));
+    MGX_LAUNCH(LaunchMergeScore(idx->dev, g.dev_merge, g.merge_leaves, g.merge_instr, g.merge_ops, g.merge_cap, s));
     if (side != s) {
       MGX_HIP(hipEventRecord(b->res->join_ev, side));
       MGX_HIP(hipStreamWaitEvent(s, b->res->join_ev, 0));

@@ -24,6 +24,7 @@ constexpr uint32_t kMaxLeaves = 192;              // distinct operands of one qu
 constexpr uint32_t kMaxLdsLeaves = 64;            // of them resident in LDS at once: sorted-list and scored operands
 constexpr uint32_t kMaxScoreTerms = 64;           // scored terms (= the 64 AND terms of query_parser.h:270)
 constexpr uint32_t kMaxNeeded = 1024;             // offset+limit handled by the fused top-k
+constexpr uint32_t kMergeMaxOps = 6;           // operands besides the driver that merge_score_kernel stages per tile
 constexpr uint32_t kMatchBuf = 2048;              // matches enumerated per scoring round
 
 // ---- operand kinds --------------------------------------------------------------------------------------------

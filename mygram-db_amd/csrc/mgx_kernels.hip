@@ -2546,6 +2546,336 @@ __global__ __launch_bounds__(kCandBlock) void cand_kernel(DevIndex ix, DevBatch 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// merge_score_kernel: SORT _score over LONG sorted posting arrays (a list-form operand too long to probe per candidate)
+// ---------------------------------------------------------------------------------------------------------------
+//
+// The reference intersects sorted arrays by merging / galloping (PostingList::Intersect, posting_list.cpp:634-715) and
+// then scores every result by scanning its text. Round 2 ran these queries on wave_score_kernel's list path: every
+// operand scattered into an LDS bitmap, the matches enumerated out of the AND of the bitmaps — and the tf of a match
+// under a list-form term found by a BINARY SEARCH of the posting array per (match, term): ~12 dependent global loads,
+// 182M matches x 3 terms per benchmark batch on an index without bitmaps (24.7 ms, 16 % of the HBM roofline on the
+// algorithmic bytes, 1.73x re-read traffic). This kernel is the tile-synchronous merge that carries posting RANKS:
+//   * a wave owns whole 16384-doc tiles; the smallest positive list of the query DRIVES: its tile segment (skip row) is
+//     read 64 postings at a time, one per lane — doc id and, at the same index, tf byte: coalesced, read once;
+//   * every other operand of the tile is staged in this wave's LDS as a 2 KiB bitmap: a sorted list by scattering its
+//     segment (coalesced 16-byte loads, ids of one word merged per lane before the ds_or), a bitmap-form gram or filter
+//     by copying its row; for a scored list the per-word prefix popcounts go beside it (one DPP scan per tile);
+//   * a candidate is tested against the staged bitmaps in program order (LDS bit tests, NOT terms and NE filters
+//     inverted; funnel counters are popcounts of the alive mask at the program's COUNT positions — the host sends a
+//     query here only when its driver is loaded before the first COUNT);
+//   * a survivor's tf under a list-form term is tf[segment base + prefix[word] + popcount(word below its bit)]: two LDS
+//     reads and ONE byte gather into the tile's own tf segment, no search; under a bitmap-form term the doc-slot nibble;
+//     BM25 in the reference's fp64 operation order; per-wave top-k with the query-wide bound.
+// Every posting of every operand is read exactly once per tile visit; nothing is searched.
+constexpr int kMergeBlock = 512;
+constexpr int kMergeWaves = kMergeBlock / 64;
+constexpr int kMergeU = 4;               // driver postings per lane and step
+constexpr uint32_t kMergeQueue = 64 + 64 * kMergeU;  // survivors waiting for a full scoring round
+
+struct MergeOffsets {
+  uint32_t leaf, prog, slot_of, wave0, w_bm, w_pref, w_seg, w_queue, w_keys, w_docs, wave_bytes, total;
+};
+__host__ __device__ inline MergeOffsets carve_merge(uint32_t max_leaves, uint32_t max_instr, uint32_t max_ops, uint32_t max_cap) {
+  MergeOffsets o;
+  uint32_t at = 0;
+  o.leaf = at;     at += align8(max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
+  o.prog = at;     at += align8(max_instr * 4);
+  o.slot_of = at;  at += align8(max_leaves);
+  at = (at + 15u) & ~15u;
+  o.wave0 = at;
+  uint32_t w = 0;
+  o.w_bm = w;      w += max_ops * kWordsPerTile * 8;
+  o.w_pref = w;    w += max_ops * kWordsPerTile * 2;
+  o.w_seg = w;     w += align8(max_ops * 8);
+  o.w_queue = w;   w += kMergeQueue * 4;
+  o.w_keys = w;    w += 2 * max_cap * 8;
+  o.w_docs = w;    w += 2 * max_cap * 4;
+  o.wave_bytes = (w + 15u) & ~15u;
+  o.total = at + kMergeWaves * o.wave_bytes + 64;
+  return o;
+}
+uint32_t MergeLdsBytes(uint32_t max_leaves, uint32_t max_instr, uint32_t max_ops, uint32_t max_cap) {
+  return carve_merge(max_leaves ? max_leaves : 1, max_instr ? max_instr : 1, max_ops ? max_ops : 1, max_cap).total;
+}
+
+__global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, DevBatch bt, uint32_t max_leaves,
+                                                                  uint32_t max_instr, uint32_t max_ops, uint32_t max_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const MergeOffsets mo = carve_merge(max_leaves, max_instr, max_ops, max_cap);
+  DevLeaf* const leaf = reinterpret_cast<DevLeaf*>(smem + mo.leaf);
+  uint32_t* const prog = reinterpret_cast<uint32_t*>(smem + mo.prog);
+  uint8_t* const slot_of = smem + mo.slot_of;  // leaf -> staged operand slot (0xFF: the driver / unused)
+  const uint32_t tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+  unsigned char* const wbase = smem + mo.wave0 + static_cast<size_t>(wave) * mo.wave_bytes;
+  uint64_t* const bm = reinterpret_cast<uint64_t*>(wbase + mo.w_bm);      // [ops][256]
+  uint16_t* const pref = reinterpret_cast<uint16_t*>(wbase + mo.w_pref);  // [ops][256]
+  uint64_t* const seg = reinterpret_cast<uint64_t*>(wbase + mo.w_seg);    // [ops] posting index of the tile's first posting
+  uint32_t* const wq = reinterpret_cast<uint32_t*>(wbase + mo.w_queue);   // [kMergeQueue] survivors waiting to be scored
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + mo.wave0 + kMergeWaves * mo.wave_bytes);
+
+  const DevItem it = bt.items[blockIdx.x];
+  const uint32_t qi = it.query;
+  const DevQuery q = bt.queries[qi];
+  for (uint32_t i = tid; i < q.n_leaves; i += kMergeBlock) leaf[i] = bt.leaves[q.leaf_begin + i];
+  for (uint32_t i = tid; i < q.n_instr; i += kMergeBlock) prog[i] = bt.prog[q.prog_begin + i];
+  __syncthreads();
+  // the driver: the host put its leaf index into DevQuery::pat_off (unused by score-mode queries)
+  const uint32_t driver_leaf = q.pat_off;
+  if (tid == 0) {
+    uint32_t n = 0;  // (at most kMergeMaxOps: the host checked)
+    for (uint32_t i = 0; i < q.n_leaves; ++i) slot_of[i] = 0xFF;
+    for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+      const uint32_t op = prog[pc] >> 24, arg = prog[pc] & 0xFFFFFFu;
+      if (op == kOpCount || arg == driver_leaf || slot_of[arg] != 0xFF) continue;
+      slot_of[arg] = static_cast<uint8_t>(n++);
+    }
+  }
+  __syncthreads();
+  // which staged operands need ranks (a scored list-form term)
+  uint32_t need_rank = 0;
+  for (uint32_t i = 0; i < q.n_score; ++i) {
+    const uint32_t lfi = bt.score_terms[q.score_begin + i].leaf;
+    if (lfi != driver_leaf && leaf[lfi].kind == kLeafList) need_rank |= 1u << slot_of[lfi];
+  }
+
+  WaveTopK tk;
+  tk.cap = q.cap;
+  tk.needed = q.needed;
+  tk.lds_sort = false;
+  tk.keys = reinterpret_cast<uint64_t*>(wbase + mo.w_keys);
+  tk.docs = reinterpret_cast<uint32_t*>(wbase + mo.w_docs);
+  tk.have = 0;
+  tk.pend = 0;
+  tk.bound_key = 0;
+  tk.bound_doc = 0;
+  tk.gbound_ptr = bt.bounds ? bt.bounds + qi : nullptr;
+  tk.gbound = 0;
+  for (uint32_t i = lane; i < 2 * q.cap; i += 64) {
+    tk.keys[i] = 0;
+    tk.docs[i] = 0;
+  }
+  wave_lds_sync();
+
+  const DevLeaf dlf = leaf[driver_leaf];
+  const uint64_t dl0 = ix.offsets[dlf.a], dl1 = ix.offsets[dlf.a + 1];
+  const uint32_t* const drow = dlf.row != kNoRow ? ix.tile_off + static_cast<uint64_t>(dlf.row) * (ix.n_tiles + 1) : nullptr;
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  uint32_t cnt_res = 0;
+  const bool desc = q.descending != 0;
+  const uint32_t tile_end = min(it.tile_begin + it.n_tiles, ix.n_tiles);
+
+  for (uint32_t tile = it.tile_begin + wave; tile < tile_end; tile += kMergeWaves) {
+    const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
+    uint64_t da, db;
+    if (drow) {
+      da = dl0 + drow[tile];
+      db = dl0 + drow[tile + 1];
+    } else {
+      da = lower_bound_u32(ix.docids, dl0, dl1, tile_first);
+      db = lower_bound_u32(ix.docids, da, dl1, tile_first + kTileDocs);
+    }
+    if (da == db) continue;  // wave-uniform: no candidate in this tile
+    wave_topk_refresh_gbound(tk);
+    // ---- stage the other operands of the tile ---------------------------------------------------------------------------
+    for (uint32_t li = 0; li < q.n_leaves; ++li) {
+      const uint32_t j = slot_of[li];
+      if (j == 0xFF) continue;
+      const DevLeaf lf = leaf[li];
+      uint64_t* const b = bm + static_cast<size_t>(j) * kWordsPerTile;
+      if (lf.kind == kLeafList) {
+        const uint64_t l0 = ix.offsets[lf.a], l1 = ix.offsets[lf.a + 1];
+        uint64_t a, e;
+        if (lf.row != kNoRow) {
+          const uint32_t* r = ix.tile_off + static_cast<uint64_t>(lf.row) * (ix.n_tiles + 1);
+          a = l0 + r[tile];
+          e = l0 + r[tile + 1];
+        } else {
+          a = lower_bound_u32(ix.docids, l0, l1, tile_first);
+          e = lower_bound_u32(ix.docids, a, l1, tile_first + kTileDocs);
+        }
+        if (lane == 0) seg[j] = a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[lane * 4 + k] = 0;
+        wave_lds_sync();
+        wave_scatter_segment(ix.docids, a, e, static_cast<uint32_t>(tile_first), reinterpret_cast<uint32_t*>(b));
+        wave_lds_sync();
+        if ((need_rank >> j) & 1u) {  // per-word prefix popcounts: rank of a member = prefix[word] + bits below it
+          uint32_t c[4], mine = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            c[k] = static_cast<uint32_t>(__popcll(b[lane * 4 + k]));
+            mine += c[k];
+          }
+          uint32_t run = wave_incl_scan(mine) - mine;
+          uint16_t* const pr = pref + static_cast<size_t>(j) * kWordsPerTile;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            pr[lane * 4 + k] = static_cast<uint16_t>(run);
+            run += c[k];
+          }
+        }
+      } else {  // bitmap-form gram or filter: the tile's 2 KiB row
+        const uint64_t* rowp = lf.kind == kLeafGramBitmap
+                                   ? ix.gram_bitmaps + tile * ix.gb_tile_stride + lf.b * ix.gb_row_stride + lane * 4
+                                   : ix.filter_bitmaps + tile * ix.fb_tile_stride + lf.b * ix.fb_row_stride + lane * 4;
+        const uint4 v0 = *reinterpret_cast<const uint4*>(rowp);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(rowp + 2);
+        *reinterpret_cast<uint4*>(b + lane * 4) = v0;
+        *reinterpret_cast<uint4*>(b + lane * 4 + 2) = v1;
+      }
+    }
+    wave_lds_sync();
+    // ---- the driver's candidates, kMergeU per lane and step; survivors wait in the queue until 64 can be scored at once --
+    uint32_t n_wait = 0;  // wave-uniform: queued survivors (slot in tile << 16 | driver posting offset in the tile segment)
+    for (uint64_t p0 = da; p0 < db || n_wait != 0; p0 += 64 * kMergeU) {
+      if (p0 < db) {
+        bool alive[kMergeU];
+        uint32_t sl[kMergeU];
+#pragma unroll
+        for (int u = 0; u < kMergeU; ++u) {  // (the loads of a step are issued together)
+          const uint64_t p = p0 + u * 64 + lane;
+          alive[u] = p < db;
+          sl[u] = (alive[u] ? ix.docids[p] : static_cast<uint32_t>(tile_first)) - static_cast<uint32_t>(tile_first);
+        }
+        for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+          const uint32_t ins = prog[pc];
+          const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+          uint64_t any = 0;
+          uint32_t c = 0;
+#pragma unroll
+          for (int u = 0; u < kMergeU; ++u) {
+            const uint64_t am = __ballot(alive[u]);
+            any |= am;
+            c += static_cast<uint32_t>(__popcll(am));
+          }
+          if (op == kOpCount) {
+            cnt[0] += (arg & 1u) ? c : 0;
+            cnt[1] += (arg & 2u) ? c : 0;
+            cnt[2] += (arg & 4u) ? c : 0;
+            cnt[3] += (arg & 8u) ? c : 0;
+            continue;
+          }
+          if (arg == driver_leaf) continue;
+          if (any == 0) break;
+          const uint64_t* const ob = bm + static_cast<size_t>(slot_of[arg]) * kWordsPerTile;
+#pragma unroll
+          for (int u = 0; u < kMergeU; ++u) {
+            const bool in = (ob[sl[u] >> 6] >> (sl[u] & 63)) & 1ull;
+            alive[u] = op == kOpAndNot ? (alive[u] && !in) : (alive[u] && in);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kMergeU; ++u) {
+          const uint64_t am = __ballot(alive[u]);
+          if (alive[u])
+            wq[n_wait + static_cast<uint32_t>(__popcll(am & ((1ull << lane) - 1ull)))] =
+                (sl[u] << 16) | static_cast<uint32_t>(p0 + u * 64 + lane - da);
+          n_wait += static_cast<uint32_t>(__popcll(am));
+        }
+        cnt_res += 0;  // (counted below, from the queue)
+        wave_lds_sync();
+      }
+      // ---- BM25 of the queued survivors, 64 at a time (the last, partial round when the segment is exhausted) ----------
+      while (n_wait >= 64 || (p0 + 64 * kMergeU >= db && n_wait != 0)) {
+        const uint32_t take = n_wait < 64 ? n_wait : 64;
+        const bool alive = lane < take;
+        const uint32_t ent = alive ? wq[n_wait - take + lane] : 0u;  // (taken from the tail: no shifting of the rest)
+        n_wait -= take;
+        cnt_res += take;
+        const uint32_t sl = ent >> 16;
+        const uint64_t p = da + (ent & 0xFFFFu);
+        const uint32_t w = sl >> 6;
+        const uint64_t bit = 1ull << (sl & 63);
+        const uint32_t slot = tile * kTileDocs + sl;
+        const uint32_t d = static_cast<uint32_t>(tile_first) + sl;
+        double score = 0.0;
+        uint32_t dl = 0;
+        if (alive) {
+          dl = ix.dl8[slot];
+          if (dl == 255u) dl = ix.doc_len[slot];
+        }
+        const double length_norm = q.one_minus_b + q.b * static_cast<double>(dl) / q.avgdl_clamped;
+        for (uint32_t i = 0; i < q.n_score; ++i) {
+          const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+          const DevLeaf lf = leaf[st.leaf];
+          uint32_t tfv = 0;
+          if (alive) {
+            if (st.leaf == driver_leaf) {
+              tfv = posting_tf(ix, p);
+            } else if (lf.kind == kLeafList) {
+              const uint32_t j = slot_of[st.leaf];
+              const uint64_t word = bm[static_cast<size_t>(j) * kWordsPerTile + w];
+              if (word & bit) {
+                const uint32_t rank = pref[static_cast<size_t>(j) * kWordsPerTile + w] +
+                                      static_cast<uint32_t>(__popcll(word & (bit - 1ull)));
+                tfv = posting_tf(ix, seg[j] + rank);
+              }
+            } else if (lf.kind == kLeafGramBitmap) {
+              const uint32_t nb = ix.tfnib[static_cast<uint64_t>(lf.b) * ix.nib_row_stride + (slot >> 1)];
+              tfv = (nb >> ((slot & 1u) * 4u)) & 15u;
+              if (tfv == 15u) tfv = exact_tf(ix, lf.a, lf.row, slot);
+            }
+          }
+          if (tfv != 0) {
+            const double tf = static_cast<double>(tfv);
+            const double numerator = tf * q.k1_plus_1;
+            const double denominator = tf + q.k1 * length_norm;
+            score += st.idf * numerator / denominator;
+          }
+        }
+        wave_topk_offer(tk, alive, score_key(score, desc), desc ? d : ~d);
+      }
+    }
+    wave_lds_sync();
+  }
+
+  {
+    uint32_t v[5] = {cnt[0], cnt[1], cnt[2], cnt[3], cnt_res};
+    if (lane == 0) {
+#pragma unroll
+      for (int sidx = 0; sidx < 5; ++sidx)
+        if (v[sidx]) atomicAdd(&bt.counters[static_cast<uint64_t>(qi) * 8 + sidx], (unsigned long long)v[sidx]);
+    }
+  }
+
+  // ---- the waves' lists -> this item's candidate list, best first ------------------------------------------------------
+  wave_topk_truncate(tk);
+  if (lane == 0) misc[wave] = tk.have;
+  __syncthreads();
+  {
+    const uint32_t cap = q.cap;
+    uint32_t total = 0;
+    for (int w = 0; w < kMergeWaves; ++w) total += min(misc[w], q.needed);
+    const uint64_t obase = static_cast<uint64_t>(it.list) * bt.cand_stride;
+    for (uint32_t e = tid; e < kMergeWaves * cap; e += kMergeBlock) {
+      const uint32_t w = e / cap, i = e % cap;
+      if (i >= min(misc[w], q.needed)) continue;
+      const unsigned char* wb = smem + mo.wave0 + static_cast<size_t>(w) * mo.wave_bytes;
+      const uint64_t k = reinterpret_cast<const uint64_t*>(wb + mo.w_keys)[i];
+      const uint32_t dd0 = reinterpret_cast<const uint32_t*>(wb + mo.w_docs)[i];
+      uint32_t rank = i;
+      for (uint32_t w2 = 0; w2 < static_cast<uint32_t>(kMergeWaves) && rank < q.needed; ++w2) {
+        if (w2 == w) continue;
+        const unsigned char* wb2 = smem + mo.wave0 + static_cast<size_t>(w2) * mo.wave_bytes;
+        const uint64_t* kk = reinterpret_cast<const uint64_t*>(wb2 + mo.w_keys);
+        const uint32_t* dd = reinterpret_cast<const uint32_t*>(wb2 + mo.w_docs);
+        uint32_t lo = 0, hi = min(misc[w2], q.needed);
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (better(kk[mid], dd[mid], k, dd0)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < q.needed) {
+        bt.cand_keys[obase + rank] = k;
+        bt.cand_docs[obase + rank] = dd0;
+      }
+    }
+    if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // merge of sorted candidate lists (per-workgroup lists of one shard, or per-shard lists of one query)
 // ---------------------------------------------------------------------------------------------------------------
 
@@ -3220,6 +3550,24 @@ int LaunchCand(int mode, const DevIndex& ix, const DevBatch& bt, uint32_t max_le
   }
   hipLaunchKernelGGL(kernel, dim3(bt.n_items), dim3(kCandBlock), lds, s, ix, bt, max_leaves, max_instr,
                      mode == kModeScore ? max_cap : 0u);
+  MGX_KCHECK();
+  return 0;
+}
+
+int LaunchMergeScore(const DevIndex& ix, const DevBatch& bt, uint32_t max_leaves, uint32_t max_instr, uint32_t max_ops,
+                     uint32_t max_cap, hipStream_t s) {
+  if (bt.n_items == 0) return 0;
+  if (max_leaves == 0) max_leaves = 1;
+  if (max_instr == 0) max_instr = 1;
+  if (max_ops == 0) max_ops = 1;
+  const uint32_t lds = carve_merge(max_leaves, max_instr, max_ops, max_cap).total;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_score_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(merge_score_kernel, dim3(bt.n_items), dim3(kMergeBlock), lds, s, ix, bt, max_leaves, max_instr, max_ops,
+                     max_cap);
   MGX_KCHECK();
   return 0;
 }

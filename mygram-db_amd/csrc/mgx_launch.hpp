@@ -25,6 +25,10 @@ int LaunchWaveCount(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan
 int LaunchCand(int mode, const DevIndex& ix, const DevBatch& bt, uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap,
                hipStream_t s);
 uint32_t CandLdsBytes(uint32_t max_leaves, uint32_t max_instr, uint32_t max_cap);
+// tile-synchronous merge over long sorted posting arrays with rank-carried tf (SORT _score; DevQuery::pat_off = driver leaf)
+int LaunchMergeScore(const DevIndex& ix, const DevBatch& bt, uint32_t max_leaves, uint32_t max_instr, uint32_t max_ops,
+                     uint32_t max_cap, hipStream_t s);
+uint32_t MergeLdsBytes(uint32_t max_leaves, uint32_t max_instr, uint32_t max_ops, uint32_t max_cap);
 int LaunchReadProbe(const void* src, uint64_t bytes, uint32_t* sink, hipStream_t s);
 
 int LaunchMergeTopK(const DevQuery* queries, const uint32_t* query_ids, uint32_t n_slots, uint32_t n_lists,

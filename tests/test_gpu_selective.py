@@ -112,3 +112,41 @@ def test_candidate_driven_equals_tile_scan(pair):
         assert np.array_equal(x.scores, y.scores), q.terms
         for k in ("total_candidates", "after_intersection", "after_not", "after_filters"):
             assert getattr(x, k) == getattr(y, k), (q.terms, k)
+
+
+@pytest.mark.parametrize("dense_threshold", [2.0, 0.18])
+def test_long_posting_arrays_merge_with_carried_ranks(dense_threshold):
+    """An index WITHOUT bitmaps (dense_threshold 2: every list a sorted u32 array) and one at the reference's
+    roaring_threshold 0.18 (lists below 18 % density stay arrays, posting_list.cpp:800-834): SORT _score over LONG lists
+    runs on mgx::merge_score_kernel — the smallest list drives, the others are staged per tile, a match's tf under a
+    list-form term is read at its RANK in the tile segment. Oracle parity (ranks and fp64 scores bit for bit, funnel
+    counters) and equality with the round-2 list path (MGX_MERGE=0)."""
+    p = Pair(corpus=mg.Corpus.synthetic(200_000, seed=21), dense_threshold=dense_threshold)
+    rng = np.random.default_rng(22)
+    c, sizes, grams = _grams_by_size(p)
+    cat = rng.integers(0, 3, size=c.n_docs)
+    fids = [p.add_filter((np.nonzero(cat == v)[0] + 1).astype(np.uint32)) for v in range(3)]
+    dense = grams[:120]
+    w = sizes[dense].astype(np.float64)
+    w /= w.sum()
+    qs = []
+    for i in range(300):
+        k = int(rng.integers(1, 5))
+        pick = rng.choice(len(dense), size=k, replace=False, p=w)
+        terms = [c.gram(dense[j]).decode() for j in pick]
+        kw = {"sort_score": True, "limit": int(rng.choice([1, 10, 100])), "descending": i % 4 != 0}
+        if i % 6 == 0:
+            kw["offset"] = int(rng.integers(0, 30))
+        if i % 5 == 0:
+            kw["filters"] = [(fids[int(rng.integers(0, 3))], i % 10 == 0)]
+        not_terms = [c.gram(grams[int(rng.integers(0, 200))]).decode()] if i % 7 == 0 else []
+        qs.append(Query(terms, not_terms, **kw))
+    got = p.check(qs)
+    assert sum(g.total > 0 for g in got) > 100
+    os.environ["MGX_MERGE"] = "0"
+    try:
+        old = p.dev.search_batch(qs)
+    finally:
+        del os.environ["MGX_MERGE"]
+    for x, y, q in zip(got, old, qs):
+        assert x.total == y.total and x.docs.tolist() == y.docs.tolist() and np.array_equal(x.scores, y.scores), q.terms
