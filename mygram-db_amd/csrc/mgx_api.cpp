@@ -1706,7 +1706,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
       if (score_mode && (!s.fast_score_ok || s.score.empty())) continue;
       bool ok = true, counted = false;
       uint32_t driver = kNoLeaf;
-      uint64_t best = ~0ull;
+      uint64_t best = ~0ull, longest_list = 0;
       for (size_t pc = 0; ok && pc < s.prog.size(); ++pc) {
         const uint32_t op = s.prog[pc] >> 24, arg = s.prog[pc] & 0xFFFFFFu;
         if (op == kOpCount) {
@@ -1716,6 +1716,7 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         if ((op == kOpLoad) != (pc == 0) || (op != kOpLoad && op != kOpAnd && op != kOpAndNot)) { ok = false; break; }
         const DevLeaf& lf = s.leaves[arg];
         if (lf.kind != kLeafList && lf.kind != kLeafGramBitmap && lf.kind != kLeafFilterBitmap) { ok = false; break; }
+        if (lf.kind == kLeafList) longest_list = std::max<uint64_t>(longest_list, idx->h_offsets[lf.a + 1] - idx->h_offsets[lf.a]);
         // any positive gram loaded before the first COUNT makes every counter a count of candidates; the smallest of them
         // drives (with terms in the reference's order that is the smallest gram of the whole query)
         if (op == kOpAndNot || lf.kind == kLeafFilterBitmap || counted) continue;
@@ -1732,7 +1733,10 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
         for (const DevScoreTerm& st : s.score)
           ok = ok && st.leaf != kNoLeaf && (s.leaves[st.leaf].kind == kLeafList || s.leaves[st.leaf].kind == kLeafGramBitmap);
       if (!ok) continue;
-      if (best > kMaxPerTile * b->idx->dev.n_tiles) {
+      // probing a LONG sorted list costs a binary search of its tile segment per candidate (14 dependent loads on a segment
+      // of 16384): such operands are staged per tile instead (the merge kernel), whatever the driver's size
+      const bool long_probe = longest_list > 8 * kMaxPerTile * b->idx->dev.n_tiles;
+      if (best > kMaxPerTile * b->idx->dev.n_tiles || long_probe) {
         // a LONG driver: too many candidates to probe one by one — the tile-synchronous merge (SORT _score only; docid
         // pages of such queries stay on the counting kernels, which have no per-match work)
         const bool allow_merge = !(std::getenv("MGX_MERGE") && atoi(std::getenv("MGX_MERGE")) == 0);
