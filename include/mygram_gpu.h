@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 2U
+#define MGX_ABI_VERSION 3U
 
 /* Values of mygram::utils::ErrorCode used on this path (src/utils/error.h:37-48,100). */
 #define MGX_OK 0
@@ -254,6 +254,15 @@ typedef struct mgx_query {
    * (RequiresExactTextForHybridFragments :138-150). Every positive term must then carry its normalized `text`;
    * needs mgx_index_attach_text. after_filters still counts the docs before this filter, `total` those after it. */
   uint32_t exact_text;
+  /* MGX_SORT_SCORE: which terms BM25 sums, as indices into `terms`, in summation order (bm25_scorer.cpp:77-86); a term
+   * may be listed more than once (ScoreDocuments adds a repeated term's contribution each time). NULL => every positive
+   * term in order (the plain conjunctive query). An expression query lists the TERM leaves that are not under a NOT, in
+   * tree order (CollectAstScoringTerms, search_pipeline.cpp:232-254; search_handler.cpp:428-456 scores exactly those:
+   * reference vector tests/server/search_pipeline_test.cpp:1350-1392); a FUZZY query its terms in the order given. A
+   * listed term may match none of a result's text (an OR branch, a fuzzy neighbour): its tf is then 0 and it adds
+   * nothing, as in the reference. */
+  const uint32_t* score_terms;
+  uint32_t n_score_terms;
 } mgx_query;
 
 typedef struct mgx_batch mgx_batch;

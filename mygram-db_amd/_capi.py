@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MGX_LIBRARY: tools only (e.g. the -DMGX_ABLATION build of `make ablation`); the product is libmygram_gpu.so
 LIB_PATH = os.environ.get("MGX_LIBRARY") or os.path.join(_HERE, "libmygram_gpu.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 GRAM_ABSENT = 0xFFFFFFFF
 SORT_DOCID, SORT_SCORE = 0, 1
 
@@ -73,7 +73,8 @@ class Query(C.Structure):
                 ("sort", C.c_uint32), ("limit", C.c_uint32), ("offset", C.c_uint32), ("reverse", C.c_uint32),
                 ("k1", C.c_double), ("b", C.c_double), ("total_docs", C.c_uint64), ("avg_doc_length", C.c_double),
                 ("expr", C.c_void_p), ("n_expr", C.c_uint32), ("universe_first", C.c_uint32),
-                ("universe_count", C.c_uint64), ("exact_text", C.c_uint32)]
+                ("universe_count", C.c_uint64), ("exact_text", C.c_uint32), ("score_terms", C.c_void_p),
+                ("n_score_terms", C.c_uint32)]
 
 
 class ExprToken(C.Structure):

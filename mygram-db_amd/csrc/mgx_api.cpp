@@ -1253,12 +1253,18 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   out->avgdl = in.avg_doc_length;
   if (in.sort == MGX_SORT_SCORE) {
     if (!idx->can_score) return Fail(MGX_ERR_NOT_IMPLEMENTED, "index was created without tf/doc_len columns");
+    // the scored terms: the caller's list (expression / FUZZY queries: search_handler.cpp:428-456 scores the positive
+    // terms of the tree or query, whatever branch produced the result set), or every positive term in order
+    const uint32_t n_scored = in.score_terms ? in.n_score_terms : in.n_terms;
+    auto scored_index = [&](uint32_t k) { return in.score_terms ? in.score_terms[k] : k; };
+    for (uint32_t k = 0; k < n_scored; ++k)
+      if (scored_index(k) >= in.n_terms) return Fail(MGX_ERR_OUT_OF_RANGE, "score_terms refers to a term that is not given");
     const uint64_t needed = static_cast<uint64_t>(in.offset) + in.limit;
     if (in.limit == 0 || needed > kMaxNeeded) {
       // deep page (the reference is benchmarked with OFFSET 10000): the full-sort fallback. The matches are
       // materialised like a docid-ordered result, then scored and sorted whole at fetch time.
-      for (uint32_t i = 0; i < in.n_terms; ++i) {
-        const mgx_term& t = in.terms[i];
+      for (uint32_t k = 0; k < n_scored; ++k) {
+        const mgx_term& t = in.terms[scored_index(k)];
         if (t.text != nullptr || t.n_grams != 1)
           return Fail(MGX_ERR_NOT_IMPLEMENTED,
                       "SORT _score beyond offset+limit 1024 with a text-level term: score with "
@@ -1272,19 +1278,20 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
         return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 192 distinct operands in one query");
       return MGX_OK;
     }
-    if (in.n_terms > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 64 scored terms");
+    if (n_scored > kMaxScoreTerms) return Fail(MGX_ERR_NOT_IMPLEMENTED, "more than 64 scored terms");
     out->mode = kModeScore;
     out->total_docs = in.total_docs;
-    for (uint32_t i = 0; i < in.n_terms; ++i) {
-      const mgx_term& t = in.terms[i];
+    if (in.score_terms) out->wave_ok = out->fast_score_ok = false;  // (a listed term need not be an AND operand of the result: the general kernel tests membership)
+    for (uint32_t i = 0; i < n_scored; ++i) {
+      const mgx_term& t = in.terms[scored_index(i)];
       if (t.text != nullptr) {
         // tf from the doc text, df from a scan of the term's candidates (N1: terms that are not one n-gram)
         if (!idx->dev.text)
           return Fail(MGX_ERR_INVALID_ARGUMENT, "text-level scored term without mgx_index_attach_text");
         if (t.text_len == 0 || t.text_len > 4096)
           return Fail(MGX_ERR_OUT_OF_RANGE, "text-level scored term: length must be 1..4096 bytes");
-        if (t.threshold != 0 && t.threshold < t.n_grams)
-          return Fail(MGX_ERR_NOT_IMPLEMENTED, "text-level scored term with a fuzzy threshold");
+        // (a FUZZY term is scored as the exact term: tf = its occurrences in the text, df = the candidates of the AND of
+        // ALL its n-grams whose text contains it — PopulateTermDocumentFrequency does not know about the threshold)
         QuerySpec::TextTerm tt;
         tt.pattern.assign(reinterpret_cast<const char*>(t.text), t.text_len);
         tt.grams.assign(t.gram_ids, t.gram_ids + t.n_grams);

@@ -657,6 +657,8 @@ struct PlannedQuery {
   std::vector<TermInfo> tis;    // scratch of PlanQuery, kept for its storage
   std::vector<mgx_filter> filters;
   std::vector<mgx_expr_token> expr;
+  std::vector<uint32_t> score_list;  // mgx_query::score_terms of expression / FUZZY queries
+  bool has_score_list = false;
   std::deque<std::string> texts;  // normalized text-level terms (addresses stay valid as the deque grows)
   // Back to the freshly constructed state WITHOUT giving memory back: an executor slot re-plans a thousand of these
   // per batch, and constructing one allocates (the deque's map and first node alone are two mallocs).
@@ -671,6 +673,8 @@ struct PlannedQuery {
     tis.clear();
     filters.clear();
     expr.clear();
+    score_list.clear();
+    has_score_list = false;
     texts.clear();
   }
 };
@@ -747,6 +751,11 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
     m.b = q.bm25.b;
     m.total_docs = total_docs;
     m.avg_doc_length = avgdl;
+    if (p->has_score_list) {  // (non-NULL even when empty: "no term is scored" is not "every term is")
+      static const uint32_t kNone = 0;
+      m.score_terms = p->score_list.empty() ? &kNone : p->score_list.data();
+      m.n_score_terms = static_cast<uint32_t>(p->score_list.size());
+    }
     p->on_device = true;
   };
   auto add_not_terms = [&]() -> bool {  // ApplyNotFilter :871-932
@@ -768,12 +777,15 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
   };
   if (q.ast) {
     // ---- boolean expression: distinct TERM leaves in first-use order, tree in postfix -----------------------------
-    if (!q.terms.empty() || q.sort_by_score)
-      return Fail(p, ErrorCode::kNotImplemented, "an expression query takes its terms from the tree and is not scored");
+    if (!q.terms.empty())
+      return Fail(p, ErrorCode::kNotImplemented, "an expression query takes its terms from the tree");
     std::vector<std::string> leaves;
     std::vector<TermInfo> tis;
     bool bad = false;
-    std::function<void(const query::QueryNode&)> walk = [&](const query::QueryNode& nd) {
+    // SORT _score: the TERM leaves that are not under a NOT, in tree order, repeats kept (CollectAstScoringTerms,
+    // search_pipeline.cpp:232-254; search_handler.cpp:428-456 scores exactly those, whatever branch matched)
+    p->has_score_list = q.sort_by_score;
+    std::function<void(const query::QueryNode&, bool)> walk = [&](const query::QueryNode& nd, bool under_not) {
       if (nd.type == query::NodeType::TERM) {
         size_t k = 0;
         while (k < leaves.size() && leaves[k] != nd.term) ++k;
@@ -784,31 +796,45 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
         // a term with an unknown gram (or none at all) is an empty doc set inside the tree
         const bool empty = tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX;
         p->expr.push_back(empty ? mgx_expr_token{MGX_EXPR_EMPTY, 0} : mgx_expr_token{MGX_EXPR_TERM, static_cast<uint32_t>(k)});
+        // (a leaf with an unknown gram occurs in no text: tf = df = 0, it adds nothing to any score)
+        if (q.sort_by_score && !under_not && !empty) p->score_list.push_back(static_cast<uint32_t>(k));
         return;
       }
       if (nd.children.empty() || (nd.type == query::NodeType::NOT && nd.children.size() != 1)) {
         bad = true;
         return;
       }
-      for (const auto& c : nd.children) walk(*c);
+      for (const auto& c : nd.children) walk(*c, under_not || nd.type == query::NodeType::NOT);
       const uint32_t op = nd.type == query::NodeType::AND ? MGX_EXPR_AND
                           : nd.type == query::NodeType::OR ? MGX_EXPR_OR
                                                            : MGX_EXPR_NOT;
       p->expr.push_back(mgx_expr_token{op, static_cast<uint32_t>(nd.children.size())});
     };
-    walk(*q.ast);
+    walk(*q.ast, false);
     if (bad || leaves.empty() || leaves.size() > MGX_MAX_TERMS)
       return Fail(p, ErrorCode::kInvalidArgument, "malformed expression tree");
     p->ids.reserve(leaves.size() + q.not_terms.size());
     for (auto& ti : tis) {
-      if (ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX) ti.gram_ids.assign(1, 0u);  // placeholder of an EMPTY leaf
+      const bool empty_leaf = ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX;
+      if (empty_leaf) ti.gram_ids.assign(1, 0u);  // placeholder of an EMPTY leaf
       p->ids.push_back(ti.gram_ids);
-      p->terms.push_back(mgx_term{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0});
+      mgx_term mt{p->ids.back().data(), static_cast<uint32_t>(p->ids.back().size()), 0, 0.0, nullptr, 0};
+      if (q.sort_by_score && !empty_leaf) {
+        if (ti.is_gram) {
+          mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ti.df);
+        } else {  // tf / df from the text on the device
+          p->texts.push_back(ti.normalized);
+          mt.text = reinterpret_cast<const uint8_t*>(p->texts.back().data());
+          mt.text_len = static_cast<uint32_t>(p->texts.back().size());
+        }
+      }
+      p->terms.push_back(mt);
     }
     if (!add_not_terms()) return;
     for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
     if (im->has_gaps) p->filters.push_back(mgx_filter{im->exists_bitmap, 0u});  // NOT universe = added ids
-    finish(MGX_SORT_DOCID);
+    finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
+    p->q.offset = q.sort_by_score ? q.offset : 0;
     p->q.expr = p->expr.data();
     p->q.n_expr = static_cast<uint32_t>(p->expr.size());
     return;
@@ -818,9 +844,10 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
   if (q.fuzzy_max_distance > 0) {
     // ---- ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): no size sort; theta per term; unknown grams are skipped by
     // Index::SearchByThreshold (index.cpp:512-523) unless theta asks for every gram (then it is SearchAnd) ------------
-    if (q.sort_by_score || q.verify_text)
-      return Fail(p, ErrorCode::kNotImplemented, "FUZZY with SORT _score / verify_text is a host path (edit distance over texts)");
+    if (q.verify_text)
+      return Fail(p, ErrorCode::kNotImplemented, "FUZZY with verify_text is a host path (edit distance over texts)");
     p->ids.reserve(q.terms.size() + q.not_terms.size());
+    p->has_score_list = q.sort_by_score;
     for (const auto& raw : q.terms) {
       const std::string normalized = index.NormalizeText(raw);
       auto grams = GenerateQueryNgrams(normalized, index.GetNgramSize(), im->query_kanji, index.GetCrossBoundaryNgrams());
@@ -848,11 +875,28 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       p->ids.push_back(std::move(known));
       const auto& ids = p->ids.back();
       const uint32_t thr = (empty || theta >= ids.size()) ? 0u : static_cast<uint32_t>(theta);
-      p->terms.push_back(mgx_term{ids.data(), static_cast<uint32_t>(ids.size()), thr, 0.0, nullptr, 0});
+      mgx_term mt{ids.data(), static_cast<uint32_t>(ids.size()), thr, 0.0, nullptr, 0};
+      // SORT _score: the EXACT term is scored (GenerateTermInfos' infos, search_pipeline.cpp:1895-1899 ->
+      // search_handler.cpp:428-456). A term with an unknown n-gram occurs in no text (tf = df = 0): left out.
+      if (q.sort_by_score && !empty && ids.size() == grams.size()) {
+        p->score_list.push_back(static_cast<uint32_t>(p->terms.size()));
+        if (grams.size() == 1 && grams[0] == normalized) {
+          uint32_t gid = 0;
+          uint64_t ps = 0;
+          im->Resolve(grams[0], &gid, &ps);
+          mt.idf = index::BM25Scorer::ComputeIDF(total_docs, ps);
+        } else {
+          p->texts.push_back(normalized);
+          mt.text = reinterpret_cast<const uint8_t*>(p->texts.back().data());
+          mt.text_len = static_cast<uint32_t>(p->texts.back().size());
+        }
+      }
+      p->terms.push_back(mt);
     }
     if (!add_not_terms()) return;
     for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
-    finish(MGX_SORT_DOCID);
+    finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
+    p->q.offset = q.sort_by_score ? q.offset : 0;
     return;
   }
   std::vector<TermInfo>& tis = p->tis;

@@ -253,14 +253,15 @@ struct BatchQuery {
   std::vector<std::string> terms;      // search_text + and_terms (raw; normalised here)
   // ExecuteWithBooleanAst (src/server/search_pipeline.cpp:1408-1578): when set, the positive part of the query is this
   // tree (TERM = the term's doc set, NOT = every document of the index minus the child) and `terms` must be empty;
-  // NOT terms and filters still apply to its result. SORT _score is not combined with an expression here.
+  // NOT terms and filters still apply to its result. With SORT _score the scored terms are the tree's TERM leaves that are
+  // not under a NOT (CollectAstScoringTerms, search_pipeline.cpp:232-254), as SearchHandler scores them (:428-456).
   std::shared_ptr<const query::QueryNode> ast;
   std::vector<std::string> not_terms;
   std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
   uint32_t fuzzy_max_distance = 0;     // FUZZY d (query_parser_clauses.cpp:454: 1 or 2); 0 = not a fuzzy query.
                                        // ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): per term "at least theta of
-                                       // its n-grams", AND across terms in the order given. Not combined with
-                                       // SORT _score or verify_text here (edit-distance verification reads the texts)
+                                       // its n-grams", AND across terms in the order given; SORT _score scores the
+                                       // exact terms. Not combined with verify_text here (edit-distance verification)
   bool sort_by_score = false;          // SORT _score
   bool verify_text = false;            // the caller's ShouldApplyVerifyText(memory.verify_text, terms) decision
                                        // (search_pipeline.cpp:42-66); mixed-script fragments force it (:858-866)

@@ -715,12 +715,26 @@ class Index:
                     shells.append(shell)
                     continue
                 cterms = (_capi.Term * len(tis))()
+                scored = []
                 for j, t in enumerate(tis):
                     ids_list = [_capi.GRAM_ABSENT] if (t.fuzzy_empty or not t.fuzzy_ids) else t.fuzzy_ids
                     ids = np.asarray(ids_list, dtype=np.uint32)
                     keep.append(ids)
                     thr = 0 if (t.fuzzy_empty or t.threshold >= len(ids)) else t.threshold
-                    cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, 0.0, None, 0)
+                    idf, text_ptr, text_len = 0.0, None, 0
+                    # SORT _score: the EXACT term is scored (search_handler.cpp:428-456 over GenerateTermInfos' infos,
+                    # search_pipeline.cpp:1895-1899). A term with an unknown n-gram occurs in no text: tf = df = 0, it
+                    # adds nothing and is left out of the scored list.
+                    if q.sort_score and len(t.fuzzy_ids) == len(t.grams) and not t.fuzzy_empty:
+                        scored.append(j)
+                        if t.df is None:  # text-level term
+                            self.ensure_text()
+                            tb = np.frombuffer(t.normalized.encode("utf-8"), dtype=np.uint8).copy()
+                            keep.append(tb)
+                            text_ptr, text_len = tb.ctypes.data, len(tb)
+                        else:
+                            idf = compute_idf(self.total_docs, t.df)
+                    cterms[j] = _capi.Term(ids.ctypes.data, len(ids), thr, idf, text_ptr, text_len)
                 nts = []
                 for nt in q.not_terms:
                     ti = self.term_info(nt)
@@ -738,11 +752,15 @@ class Index:
                 for j, (bid, negate) in enumerate(q.filters):
                     cf[j] = _capi.Filter(bid, int(negate))
                 keep.extend([cterms, cnots, cf])
-                if q.sort_score:
-                    raise _capi.MgxError(4, "FUZZY with SORT _score is not on the device path")
                 cq = _capi.Query(C.cast(cterms, C.c_void_p), len(tis), C.cast(cnots, C.c_void_p), len(nts),
-                                 C.cast(cf, C.c_void_p), len(q.filters), _capi.SORT_DOCID, q.limit, q.offset,
+                                 C.cast(cf, C.c_void_p), len(q.filters),
+                                 _capi.SORT_SCORE if q.sort_score else _capi.SORT_DOCID, q.limit, q.offset,
                                  int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
+                if q.sort_score:
+                    sc = np.asarray(scored, dtype=np.uint32)
+                    keep.append(sc)
+                    cq.score_terms = sc.ctypes.data if len(sc) else C.cast(cterms, C.c_void_p).value  # (non-NULL: "none")
+                    cq.n_score_terms = len(sc)
                 cqueries.append(cq)
                 shells.append(None)
                 continue
@@ -774,6 +792,20 @@ class Index:
                 emit(q.expr)
                 expr_tokens = (_capi.ExprToken * len(toks))(*[_capi.ExprToken(o, a) for o, a in toks])
                 keep.append(expr_tokens)
+                # SORT _score over an expression: the TERM leaves that are not under a NOT, in tree order, repeats kept
+                # (CollectAstScoringTerms, search_pipeline.cpp:232-254); a leaf with an unknown gram occurs in no text
+                # (tf = df = 0) and is left out
+                expr_scored = []
+
+                def collect(e, under_not):
+                    if isinstance(e, str):
+                        i = q.terms.index(e)
+                        if not under_not and tis[i].estimated_size not in (0, None):
+                            expr_scored.append(i)
+                        return
+                    for c in e[1:]:
+                        collect(c, under_not or e[0] == "not")
+                collect(q.expr, False)
                 # placeholder grams for EMPTY leaves so that every mgx_term stays well-formed
                 for t in tis:
                     if t.estimated_size in (0, None):
@@ -841,6 +873,11 @@ class Index:
                              _capi.SORT_SCORE if q.sort_score else _capi.SORT_DOCID, q.limit, q.offset,
                              int(q.descending), q.k1, q.b, self.total_docs, self.avg_doc_length)
             cq.exact_text = int(exact)
+            if expr_tokens is not None and q.sort_score:
+                sc = np.asarray(expr_scored, dtype=np.uint32)
+                keep.append(sc)
+                cq.score_terms = sc.ctypes.data if len(sc) else C.cast(cterms, C.c_void_p).value  # (non-NULL: "none")
+                cq.n_score_terms = len(sc)
             if expr_tokens is not None:
                 cq.expr = C.cast(expr_tokens, C.c_void_p)
                 cq.n_expr = len(expr_tokens)

@@ -306,6 +306,97 @@ int main() {
       std::printf("ExecuteBatch(ast) error: %s\n", r.error().message().c_str());
     }
   }
+  {  // SORT _score over the boolean and FUZZY branches: the batch path must return what the reference's composition
+     // returns — the branch's result set, BM25Scorer::ScoreDocuments over the POSITIVE terms (search_handler.cpp:428-456;
+     // NOT-excluded terms are not scored: tests/server/search_pipeline_test.cpp:1350-1392), ResultSorter::SortByScore
+    using namespace mygramdb::search_pipeline;
+    using mygramdb::query::NodeType;
+    using mygramdb::query::QueryNode;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning basics");
+    index.AddDocument(2, "deep learning techniques");
+    index.AddDocument(3, "old article about cats");
+    index.AddDocument(4, "learning learning learning");
+    index.AddDocument(5, "cats and machine cats");
+    index.AddDocument(6, "basics of basics");
+    auto term = [](const char* t) { return std::make_unique<QueryNode>(std::string(t)); };
+    auto node = [](NodeType t, std::vector<std::unique_ptr<QueryNode>> kids) {
+      auto n = std::make_unique<QueryNode>(t);
+      n->children = std::move(kids);
+      return n;
+    };
+    auto kids = [](std::unique_ptr<QueryNode> a, std::unique_ptr<QueryNode> b = nullptr) {
+      std::vector<std::unique_ptr<QueryNode>> v;
+      v.push_back(std::move(a));
+      if (b) v.push_back(std::move(b));
+      return v;
+    };
+    // single-gram leaves: their df is the posting count, so the composition needs nothing but the shim's own operators
+    struct Case {
+      std::shared_ptr<const QueryNode> ast;
+      std::vector<std::string> scored;  // CollectAstScoringTerms
+    };
+    std::vector<Case> cases;
+    cases.push_back({node(NodeType::OR, kids(term("ba"), term("ca"))), {"ba", "ca"}});
+    cases.push_back({node(NodeType::AND, kids(node(NodeType::OR, kids(term("ba"), term("ca"))), term("ma"))), {"ba", "ca", "ma"}});
+    cases.push_back({node(NodeType::AND, kids(term("le"), node(NodeType::NOT, kids(term("de"))))), {"le"}});
+    const uint64_t n_docs = index.Bm25DocCount();
+    const double avgdl = index.Bm25AvgDocLength();
+    for (const Case& c : cases) {
+      BatchQuery plain, scored;
+      plain.ast = scored.ast = c.ast;
+      plain.order = SortOrder::ASC;
+      plain.limit = 0;
+      scored.sort_by_score = true;
+      scored.limit = 4;
+      auto a = ExecuteBatch(index, {plain});
+      auto b = ExecuteBatch(index, {scored});
+      EXPECT(a.has_value() && b.has_value());
+      if (!a || !b) {
+        std::printf("scored expression: %s\n", (!a ? a.error() : b.error()).message().c_str());
+        continue;
+      }
+      std::vector<uint64_t> dfs;
+      for (const auto& t : c.scored) dfs.push_back(index.PostingSize(t));
+      auto sc = BM25Scorer::ScoreDocuments((*a)[0].results, c.scored, dfs, index, n_docs, avgdl, BM25Params{});
+      EXPECT(sc.has_value());
+      if (!sc) continue;
+      std::vector<double> scores;
+      for (const auto& sd : *sc) scores.push_back(sd.score);
+      const V want = ResultSorter::SortByScore(index, (*a)[0].results, scores, SortOrder::DESC, 4, 0);
+      EXPECT((*b)[0].results == want);
+      EXPECT((*b)[0].total == (*a)[0].results.size());
+      for (size_t i = 0; i < want.size() && i < (*b)[0].scores.size(); ++i) {
+        double ws = 0;
+        for (size_t k = 0; k < (*a)[0].results.size(); ++k)
+          if ((*a)[0].results[k] == want[i]) ws = scores[k];
+        EXPECT((*b)[0].scores[i] == ws);
+      }
+    }
+    // FUZZY 1 SORT _score: "learnig" matches docs 1, 2 (and 4: le ea ar rn ni of its six bigrams); the EXACT term occurs
+    // in no text, so every score is 0 and the docid decides (DESC: larger first)
+    BatchQuery fz;
+    fz.terms = {"learnig"};
+    fz.fuzzy_max_distance = 1;
+    fz.sort_by_score = true;
+    fz.limit = 10;
+    auto f = ExecuteBatch(index, {fz});
+    EXPECT(f.has_value());
+    if (f) {
+      EXPECT((*f)[0].results == (V{4, 2, 1}));
+      EXPECT((*f)[0].scores.size() == 3 && (*f)[0].scores[0] == 0.0);
+    } else {
+      std::printf("scored FUZZY: %s\n", f.error().message().c_str());
+    }
+    // ... and with the exact spelling the term is scored: the doc that repeats it ranks first
+    fz.terms = {"learning"};
+    auto f2 = ExecuteBatch(index, {fz});
+    EXPECT(f2.has_value());
+    if (f2) {
+      EXPECT(!(*f2)[0].results.empty() && (*f2)[0].results[0] == 4);
+      EXPECT((*f2)[0].scores.size() == (*f2)[0].results.size() && (*f2)[0].scores[0] > (*f2)[0].scores.back());
+    }
+  }
   {  // tests/server/search_pipeline_test.cpp:1492-1512 MixedScriptBoundaryFragmentRequiresExactTextMatch, and the
      // caller-driven verify_text filter
     using namespace mygramdb::search_pipeline;
