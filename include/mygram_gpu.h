@@ -156,6 +156,40 @@ int mgx_index_memory_bytes(const mgx_index* idx, uint64_t* out);
 /* Registers one FilterIndex (column,value) doc set (src/storage/filter_index.h:39-124) as a device bitmap usable
  * as a filter operand; docids ascending, inside the owned range. */
 int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id);
+/* Typed filter columns (DocumentStore filter values, src/storage/document_store.h:73-87): what FILTER conditions other
+ * than a caller-resolved bitmap, and FACET, are evaluated on. Values by local doc slot, widened to 8 bytes:
+ * MGX_FC_SIGNED (bool, int8..int64, TimeValue seconds) as int64, MGX_FC_UNSIGNED (uint8..uint64; strings as their rank in
+ * the caller's bytewise-sorted dictionary) as uint64, MGX_FC_DOUBLE as IEEE bits. is_null (may be NULL: none) marks NULLs.
+ * value_ids (may be NULL: FACET unavailable on this column): the dense id < n_values of every doc's value, 0xFFFFFFFF
+ * for NULL — FilterIndex keeps one bitmap per distinct value (filter_index.h:39-124); the ids are their device form. */
+#define MGX_FC_SIGNED 0u
+#define MGX_FC_UNSIGNED 1u
+#define MGX_FC_DOUBLE 2u
+typedef struct mgx_filter_column_desc {
+  uint32_t struct_size; /* sizeof(mgx_filter_column_desc) */
+  uint32_t version;     /* MGX_ABI_VERSION */
+  uint32_t value_class; /* MGX_FC_* */
+  uint32_t n_values;    /* distinct non-NULL values (value_ids) */
+  const void* values;   /* n_docs x 8 bytes */
+  const uint8_t* is_null;
+  const uint32_t* value_ids;
+} mgx_filter_column_desc;
+int mgx_index_add_filter_column(mgx_index* idx, const mgx_filter_column_desc* desc, uint32_t* out_column_id);
+/* One FilterCondition (src/query/query_parser.h:123-127) on a typed column -> a filter bitmap usable like the ones of
+ * mgx_index_add_filter_bitmap: the docs whose stored value compares true against the literal (given in the column's
+ * class: literal_bits = the int64 / uint64 / double bit pattern). op: MGX_CMP_*. eq_epsilon > 0: = and != on doubles
+ * test |stored - literal| against it (CompareDoubleValues, src/utils/comparison_utils.h:56-70: the per-document path of
+ * ApplyFilters, search_pipeline.cpp:1098-1194); 0: exact (the FilterIndex bitmap path compares serialized keys,
+ * :1021-1094). null_matches: NULL docs are members (the per-document path lets NULL pass != only, :1151-1157).
+ * never_matches: the literal has no interpretation in the column's type — no non-NULL doc matches (:1167,1172,1177,1182). */
+#define MGX_CMP_EQ 0u
+#define MGX_CMP_NE 1u
+#define MGX_CMP_LT 2u
+#define MGX_CMP_LE 3u
+#define MGX_CMP_GT 4u
+#define MGX_CMP_GE 5u
+int mgx_index_filter_compare(mgx_index* idx, uint32_t column_id, uint32_t op, uint64_t literal_bits, double eq_epsilon,
+                             int null_matches, int never_matches, uint32_t* out_bitmap_id);
 /* How batches that are in flight at the same time (one stream per batch object) share the device.
  * MGX_ORDER_FIFO (default): the main kernels of a batch start when those of the batch enqueued before it on this index
  * have finished — first in, first out, so a batch's latency is its own kernel time plus what was queued ahead of it;
@@ -386,6 +420,13 @@ int mgx_threshold(mgx_index* idx, const uint32_t* gram_ids, uint32_t n, uint32_t
 /* Index::FilterByNgrams: keeps caller order and duplicates. */
 int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids, uint32_t n,
                uint32_t** out_docs, uint64_t* out_n);
+/* FACET (ExecuteFacetPipeline, src/server/search_pipeline.cpp:2061-2153): counts_out[v] = how many docs of the query's
+ * result set hold value id v of the column (FilterIndex::GetColumnValueCountsFiltered, filter_index.cpp:284-312 — a
+ * histogram of the column's value ids over the result bitmap); *matched = the size of the result set. `query` is the
+ * search part (terms / expression, NOT terms, filters; sort, limit and offset are ignored: the whole result set counts);
+ * the caller orders the values by count and pages them. counts_out has room for the column's n_values. */
+int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id, uint64_t* counts_out, uint64_t* matched);
+
 /* BM25Scorer::ScoreDocuments for single-gram terms: one score per candidate, in candidate order. A candidate
  * outside the index or with empty text scores 0.0 (bm25_scorer.cpp:73-89). */
 int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids,

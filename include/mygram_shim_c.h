@@ -72,6 +72,29 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
 int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_docs, uint32_t* docs, double* scores,
               double* timing_ms);
 
+/* Index::AddFilterColumn: one filter column of the table (DocumentStore filter values, src/storage/document_store.h:73-87),
+ * one value per doc slot. value_type = the FilterValue alternative every non-NULL value holds: 1 bool, 2 int8, 3 uint8,
+ * 4 int16, 5 uint16, 6 int32, 7 uint32, 8 int64, 9 uint64, 10 TimeValue (seconds), 11 string, 12 double. `values`: n x 8
+ * bytes (int64 for the signed types and bool, uint64 for the unsigned ones, double for 12; ignored for strings, which
+ * come NUL-terminated in `strings`); is_null (may be NULL) marks NULLs. */
+int mgxs_table_add_filter_column(mgxs_table* table, const char* name, int value_type, uint64_t n, const void* values,
+                                 const char* const* strings, const uint8_t* is_null);
+/* One query with parsed FILTER conditions (query::FilterCondition: column, op 0 EQ 1 NE 2 GT 3 GTE 4 LT 5 LTE as
+ * query::FilterOp, literal) through search_pipeline::ExecuteBatch; the conditions are resolved like
+ * ApplyFiltersWithBitmap (src/server/search_pipeline.cpp:1196-1237). docs / scores have room for `limit` entries. */
+int mgxs_search(mgxs_table* table, uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
+                uint32_t n_cond, const char* const* cond_columns, const uint32_t* cond_ops, const char* const* cond_values,
+                int sort_by_score, int descending, uint32_t limit, uint32_t offset, uint64_t* total, uint32_t* n_docs,
+                uint32_t* docs, double* scores /* may be NULL */);
+/* search_pipeline::ExecuteFacet (ExecuteFacetPipeline, src/server/search_pipeline.cpp:2061-2153): value counts of `column`
+ * over the query's result set (no terms: every document), count descending, paged by offset then limit. counts has room
+ * for `limit` entries, display_off for limit + 1; value k's printable form (DeserializeToDisplayString) is
+ * display[display_off[k] .. display_off[k+1]). */
+int mgxs_facet(mgxs_table* table, uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
+               uint32_t n_cond, const char* const* cond_columns, const uint32_t* cond_ops, const char* const* cond_values,
+               const char* column, uint32_t limit, uint32_t offset, uint64_t* matched, uint64_t* total_values,
+               uint32_t* n_out, uint64_t* counts, char* display, size_t display_cap, uint32_t* display_off);
+
 /* search_pipeline::MicroBatcher: the thread-safe front end. mgxs_batcher_search may be called from any number of threads at
  * once and blocks until the query's batch has run; queries are gathered into batches of at most `max_batch`, a batch
  * closing when full or when its first query has waited `max_delay_us`. docs / scores have room for

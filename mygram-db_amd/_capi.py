@@ -22,7 +22,8 @@ EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
     "mgx_columns_build", "mgx_columns_from_mgix", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
-    "mgx_index_add_filter_bitmap", "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
+    "mgx_index_add_filter_bitmap", "mgx_index_add_filter_column", "mgx_index_filter_compare", "mgx_facet_counts",
+    "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
     "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy",
     "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_execute_sharded", "mgx_batch_execute_gather", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
@@ -75,6 +76,11 @@ class Query(C.Structure):
                 ("expr", C.c_void_p), ("n_expr", C.c_uint32), ("universe_first", C.c_uint32),
                 ("universe_count", C.c_uint64), ("exact_text", C.c_uint32), ("score_terms", C.c_void_p),
                 ("n_score_terms", C.c_uint32)]
+
+
+class FilterColumnDesc(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("version", C.c_uint32), ("value_class", C.c_uint32), ("n_values", C.c_uint32),
+                ("values", C.c_void_p), ("is_null", C.c_void_p), ("value_ids", C.c_void_p)]
 
 
 class ExprToken(C.Structure):
@@ -136,6 +142,9 @@ def load():
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
     L.mgx_index_attach_text.argtypes = [vp, vp, vp]
     L.mgx_index_set_batch_order.argtypes = [vp, C.c_uint32]
+    L.mgx_index_add_filter_column.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.mgx_index_filter_compare.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, i32, i32, C.POINTER(C.c_uint32)]
+    L.mgx_facet_counts.argtypes = [vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint64)]
     L.mgx_batch_count_df.argtypes = [vp, vp]
     L.mgx_batch_df_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
     L.mgx_batch_export_topk.argtypes = [vp, vp, vp, C.POINTER(u32), vp]

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
-           "mgxs_submit", "mgxs_wait",
+           "mgxs_submit", "mgxs_wait", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -46,6 +46,10 @@ def load():
     L.mgxs_submit.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, C.POINTER(u64)]
     L.mgxs_executor_warm.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, i32]
     L.mgxs_wait.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    L.mgxs_table_add_filter_column.argtypes = [vp, C.c_char_p, i32, u64, vp, vp, vp]
+    L.mgxs_search.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, i32, i32, u32, u32, C.POINTER(u64), C.POINTER(u32), vp, vp]
+    L.mgxs_facet.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, C.c_char_p, u32, u32, C.POINTER(u64), C.POINTER(u64),
+                             C.POINTER(u32), vp, vp, C.c_size_t, vp]
     L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
     L.mgxs_batcher_destroy.argtypes = [vp]
     L.mgxs_batcher_destroy.restype = None
@@ -126,6 +130,69 @@ class Table:
         if getattr(self, "_h", None):
             load().mgxs_table_destroy(self._h)
             self._h = None
+
+    # ---- FILTER conditions and FACET through the C++ planner -----------------------------------------------------
+    VALUE_TYPES = {"bool": 1, "int8": 2, "uint8": 3, "int16": 4, "uint16": 5, "int32": 6, "uint32": 7, "int64": 8,
+                   "uint64": 9, "time": 10, "string": 11, "double": 12}
+    OPS = {"=": 0, "!=": 1, ">": 2, ">=": 3, "<": 4, "<=": 5}
+
+    def add_filter_column(self, name, value_type, values, is_null=None):
+        """Index::AddFilterColumn. values: one per doc slot (numbers, or str/bytes for "string"); is_null: bool mask."""
+        t = self.VALUE_TYPES[value_type]
+        n = len(values)
+        nul = np.ascontiguousarray(is_null, dtype=np.uint8) if is_null is not None else None
+        if t == 11:
+            raw = [(v.encode("utf-8") if isinstance(v, str) else bytes(v)) for v in values]
+            arr = (C.c_char_p * max(n, 1))(*raw)
+            _check(load().mgxs_table_add_filter_column(self._h, name.encode(), t, n, None, C.cast(arr, C.c_void_p),
+                                                       nul.ctypes.data if nul is not None else None))
+            return
+        dt = np.float64 if t == 12 else (np.uint64 if t in (3, 5, 7, 9) else np.int64)
+        a = np.ascontiguousarray(values, dtype=dt)
+        _check(load().mgxs_table_add_filter_column(self._h, name.encode(), t, n, a.ctypes.data, None,
+                                                   nul.ctypes.data if nul is not None else None))
+
+    @staticmethod
+    def _strs(items):
+        raw = [s.encode("utf-8") if isinstance(s, str) else bytes(s) for s in items]
+        return (C.c_char_p * max(len(raw), 1))(*raw), len(raw)
+
+    def _conds(self, conditions):
+        cols, _ = self._strs([c[0] for c in conditions])
+        vals, n = self._strs([c[2] for c in conditions])
+        ops = np.asarray([self.OPS[c[1]] for c in conditions] or [0], dtype=np.uint32)
+        return cols, ops, vals, n
+
+    def search(self, terms, not_terms=(), conditions=(), sort_by_score=False, descending=True, limit=100, offset=0):
+        """One query with FILTER conditions [(column, op, literal)] -> (total, docs, scores)."""
+        t, nt = self._strs(terms)
+        x, nx = self._strs(not_terms)
+        cols, ops, vals, nc = self._conds(list(conditions))
+        total, n = C.c_uint64(), C.c_uint32()
+        docs = np.zeros(max(limit, 1), np.uint32)
+        scores = np.zeros(max(limit, 1), np.float64)
+        _check(load().mgxs_search(self._h, nt, C.cast(t, C.c_void_p), nx, C.cast(x, C.c_void_p), nc,
+                                  C.cast(cols, C.c_void_p), ops.ctypes.data, C.cast(vals, C.c_void_p), int(sort_by_score),
+                                  int(descending), limit, offset, C.byref(total), C.byref(n), docs.ctypes.data,
+                                  scores.ctypes.data))
+        return int(total.value), docs[: n.value].copy(), scores[: n.value].copy()
+
+    def facet(self, column, terms=(), not_terms=(), conditions=(), limit=100, offset=0):
+        """ExecuteFacet -> (matched documents, total values, [(display value, count)] count-descending)."""
+        t, nt = self._strs(terms)
+        x, nx = self._strs(not_terms)
+        cols, ops, vals, nc = self._conds(list(conditions))
+        matched, total_values, n = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        counts = np.zeros(max(limit, 1), np.uint64)
+        cap = 1 << 20
+        buf = C.create_string_buffer(cap)
+        off = np.zeros(max(limit, 1) + 1, np.uint32)
+        _check(load().mgxs_facet(self._h, nt, C.cast(t, C.c_void_p), nx, C.cast(x, C.c_void_p), nc,
+                                 C.cast(cols, C.c_void_p), ops.ctypes.data, C.cast(vals, C.c_void_p), column.encode(), limit,
+                                 offset, C.byref(matched), C.byref(total_values), C.byref(n), counts.ctypes.data, buf, cap,
+                                 off.ctypes.data))
+        out = [(buf.raw[off[k]: off[k + 1]], int(counts[k])) for k in range(n.value)]
+        return int(matched.value), int(total_values.value), out
 
 
 class Executor:

@@ -289,6 +289,12 @@ struct mgx_index {
   std::vector<uint32_t> h_skip_row;  // per gram
   std::vector<uint32_t> h_bm_row;    // per gram
   uint32_t n_filter_rows = 0, filter_cap_rows = 0;
+  struct FilterColumn {  // mgx_index_add_filter_column
+    uint32_t value_class = 0, n_values = 0;
+    DevBuf d_values, d_null, d_value_ids;
+  };
+  std::vector<std::unique_ptr<FilterColumn>> filter_columns;
+  std::vector<DevBuf> retired_filter_pools;
   uint64_t n_grams = 0;
   bool can_score = false;
   uint64_t words_per_row = 0;  // n_tiles * 256
@@ -875,6 +881,88 @@ int mgx_index_attach_text(mgx_index* idx, const uint8_t* text_bytes, const uint6
   return MGX_OK;
 }
 
+// A fresh, zeroed row of the filter bitmap pool (the pool doubles when full). Called with idx->mu held; the row is
+// counted (n_filter_rows) by the caller once its bits are in place.
+static int NewFilterRow(mgx_index* idx, uint32_t* row_out) {
+  if (idx->n_filter_rows == idx->filter_cap_rows) {
+    const uint32_t ncap = idx->filter_cap_rows ? idx->filter_cap_rows * 2 : 8;
+    DevBuf nb;
+    MGX_HIP(nb.Alloc(static_cast<size_t>(ncap) * idx->filter_row_stride * sizeof(uint64_t)));
+    if (idx->n_filter_rows)
+      MGX_HIP(hipMemcpy(nb.p, idx->d_filter_bitmaps.p,
+                        static_cast<size_t>(idx->n_filter_rows) * idx->filter_row_stride * sizeof(uint64_t),
+                        hipMemcpyDeviceToDevice));
+    // (rows are added while batches run — a FILTER condition becomes a row the first time it is seen — and a kernel in
+    // flight still reads the old pool: it is retired, not freed; doubling keeps the waste below the pool's own size)
+    idx->retired_filter_pools.push_back(std::move(idx->d_filter_bitmaps));
+    idx->d_filter_bitmaps = std::move(nb);
+    idx->filter_cap_rows = ncap;
+    idx->dev.filter_bitmaps = idx->d_filter_bitmaps.as<uint64_t>();
+    MGX_HIP(mgx::SyncDevIndex(idx));
+  }
+  const uint32_t row = idx->n_filter_rows;
+  uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->filter_row_stride;
+  MGX_HIP(hipMemsetAsync(dst, 0, idx->filter_row_stride * sizeof(uint64_t), idx->stream));
+  *row_out = row;
+  return MGX_OK;
+}
+
+int mgx_index_add_filter_column(mgx_index* idx, const mgx_filter_column_desc* d, uint32_t* out_column_id) {
+  if (out_column_id) *out_column_id = 0;
+  if (!idx || !d || !out_column_id || !d->values)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_add_filter_column: null argument");
+  if (d->struct_size < sizeof(mgx_filter_column_desc) || d->version != MGX_ABI_VERSION)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_add_filter_column: bad struct_size/version");
+  if (d->value_class > MGX_FC_DOUBLE) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_add_filter_column: unknown value class");
+  const uint64_t n = idx->dev.n_docs;
+  if (d->value_ids)
+    for (uint64_t i = 0; i < n; ++i)
+      if (d->value_ids[i] != 0xFFFFFFFFu && d->value_ids[i] >= d->n_values)
+        return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_add_filter_column: a value id is not below n_values");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    auto col = std::make_unique<mgx_index::FilterColumn>();
+    col->value_class = d->value_class;
+    col->n_values = d->value_ids ? d->n_values : 0;
+    MGX_HIP(mgx::Upload(col->d_values, static_cast<const uint64_t*>(d->values), n));
+    if (d->is_null) MGX_HIP(mgx::Upload(col->d_null, d->is_null, n));
+    if (d->value_ids) MGX_HIP(mgx::Upload(col->d_value_ids, d->value_ids, n));
+    idx->filter_columns.push_back(std::move(col));
+    *out_column_id = static_cast<uint32_t>(idx->filter_columns.size() - 1);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_add_filter_column: ") + e.what());
+  }
+}
+
+int mgx_index_filter_compare(mgx_index* idx, uint32_t column_id, uint32_t op, uint64_t literal_bits, double eq_epsilon,
+                             int null_matches, int never_matches, uint32_t* out_bitmap_id) {
+  if (out_bitmap_id) *out_bitmap_id = 0;
+  if (!idx || !out_bitmap_id) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_compare: null argument");
+  if (op > MGX_CMP_GE) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_compare: unknown operator");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (column_id >= idx->filter_columns.size())
+      return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_filter_compare: unknown filter column");
+    MGX_HIP(hipSetDevice(idx->device));
+    const mgx_index::FilterColumn& col = *idx->filter_columns[column_id];
+    uint32_t row = 0;
+    int rc = NewFilterRow(idx, &row);
+    if (rc) return rc;
+    uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->filter_row_stride;
+    MGX_LAUNCH(mgx::LaunchFilterCompare(col.d_values.as<uint64_t>(), col.d_null.as<uint8_t>(), idx->dev.n_docs,
+                                        col.value_class, op, literal_bits, eq_epsilon, null_matches ? 1u : 0u,
+                                        never_matches ? 1u : 0u, dst, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    idx->n_filter_rows++;
+    *out_bitmap_id = row;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_filter_compare: ") + e.what());
+  }
+}
+
 int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t n, uint32_t* out_bitmap_id) {
   if (out_bitmap_id) *out_bitmap_id = 0;
   if (!idx || !out_bitmap_id || (n && !docids))
@@ -885,22 +973,11 @@ int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t
     if (docids[i] < idx->dev.first_doc_id || docids[i] - idx->dev.first_doc_id >= idx->dev.n_docs)
       return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_add_filter_bitmap: doc id outside the index range");
   }
-  if (idx->n_filter_rows == idx->filter_cap_rows) {
-    const uint32_t ncap = idx->filter_cap_rows ? idx->filter_cap_rows * 2 : 8;
-    DevBuf nb;
-    MGX_HIP(nb.Alloc(static_cast<size_t>(ncap) * idx->filter_row_stride * sizeof(uint64_t)));
-    if (idx->n_filter_rows)
-      MGX_HIP(hipMemcpy(nb.p, idx->d_filter_bitmaps.p,
-                        static_cast<size_t>(idx->n_filter_rows) * idx->filter_row_stride * sizeof(uint64_t),
-                        hipMemcpyDeviceToDevice));
-    idx->d_filter_bitmaps = std::move(nb);
-    idx->filter_cap_rows = ncap;
-    idx->dev.filter_bitmaps = idx->d_filter_bitmaps.as<uint64_t>();
-    MGX_HIP(mgx::SyncDevIndex(idx));
+  uint32_t row = 0;
+  {
+    const int rc = NewFilterRow(idx, &row);
+    if (rc) return rc;
   }
-  const uint32_t row = idx->n_filter_rows;
-  uint64_t* dst = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(row) * idx->filter_row_stride;
-  MGX_HIP(hipMemsetAsync(dst, 0, idx->filter_row_stride * sizeof(uint64_t), idx->stream));
   if (n) {
     DevBuf d_ids, d_lo, d_hi;
     MGX_HIP(mgx::Upload(d_ids, docids, n));
@@ -3257,6 +3334,61 @@ static int RunSingle(mgx_index* idx, mgx::QuerySpec&& spec, uint32_t** out_docs,
   *out_docs = o;
   *out_n = n;
   return MGX_OK;
+}
+
+int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id, uint64_t* counts_out, uint64_t* matched) {
+  if (matched) *matched = 0;
+  if (!idx || !query || !counts_out || !matched)
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_facet_counts: null argument");
+  try {
+    // the search part as a materialising query: the result bitmap of every tile, then a histogram of the column's value
+    // ids over it (what roaring_bitmap_and_cardinality per value bitmap adds up to, filter_index.cpp:300-306)
+    mgx_query q = *query;
+    q.sort = MGX_SORT_DOCID;
+    q.limit = 0;
+    q.offset = 0;
+    q.reverse = 0;
+    q.score_terms = nullptr;
+    q.n_score_terms = 0;
+    mgx::QuerySpec spec;
+    int rc = mgx::CompileQuery(idx, q, &spec);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (column_id >= idx->filter_columns.size())
+      return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_facet_counts: unknown filter column");
+    const mgx_index::FilterColumn& col = *idx->filter_columns[column_id];
+    if (!col.d_value_ids.p) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_facet_counts: the column was added without value ids");
+    std::vector<mgx::QuerySpec> specs;
+    specs.push_back(std::move(spec));
+    if (!idx->single_res) idx->single_res = std::make_unique<mgx::BatchResources>();
+    idx->single_res->Reset();
+    mgx_batch batch_obj;
+    mgx_batch* b = &batch_obj;
+    b->res = idx->single_res.get();
+    rc = mgx::PrepareInto(b, idx, std::move(specs));
+    if (rc) return rc;
+    rc = mgx::ExecuteImpl(b, idx->stream);
+    if (rc) return rc;
+    if (b->bitmap.qids.size() != 1) return mgx::Fail(MGX_ERR_INTERNAL, "mgx_facet_counts: the query did not compile to a result bitmap");
+    DevBuf d_counts;
+    {
+      mgx::ResourceScope none(nullptr);
+      MGX_HIP(d_counts.Alloc(std::max<size_t>(col.n_values, 1) * sizeof(unsigned long long)));
+    }
+    MGX_HIP(hipMemsetAsync(d_counts.p, 0, d_counts.bytes, idx->stream));
+    MGX_LAUNCH(mgx::LaunchFacetCount(b->d_rbits.as<uint64_t>(), idx->dev.n_tiles * mgx::kWordsPerTile,
+                                     col.d_value_ids.as<uint32_t>(), idx->dev.n_docs, col.n_values,
+                                     d_counts.as<unsigned long long>(), idx->stream));
+    uint64_t total = 0;
+    if (col.n_values)
+      MGX_HIP(hipMemcpyAsync(counts_out, d_counts.p, static_cast<size_t>(col.n_values) * 8, hipMemcpyDeviceToHost, idx->stream));
+    MGX_HIP(hipMemcpyAsync(&total, b->d_totals.p, 8, hipMemcpyDeviceToHost, idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    *matched = total;
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_facet_counts: ") + e.what());
+  }
 }
 
 static int CheckGrams(const mgx_index* idx, const uint32_t* g, uint32_t n, const char* what) {

@@ -16,6 +16,7 @@
 // All of them are HBM/LDS/issue-bound integer and fp64 work; none uses MFMA (nothing here is a dense contraction).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "mgx_internal.hpp"
@@ -3694,6 +3695,109 @@ __global__ __launch_bounds__(256) void build_contrib_tables_kernel(const TableJo
 int LaunchBuildContribTables(const TableJob* jobs, uint32_t n_jobs, uint32_t table_dl, double* pool, hipStream_t s) {
   if (n_jobs == 0 || table_dl == 0) return 0;
   hipLaunchKernelGGL(build_contrib_tables_kernel, dim3(n_jobs), dim3(256), 0, s, jobs, table_dl, pool);
+  MGX_KCHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// typed filter columns: FilterCondition -> doc bitmap, FACET value counts
+// ---------------------------------------------------------------------------------------------------------------
+// A filter column (DocumentStore filter values, src/storage/document_store.h:73-87) lives by doc slot, every value widened
+// to 8 bytes: signed integers / bool / TimeValue as int64, unsigned integers and string ranks as uint64, FLOAT/DOUBLE as
+// their bits; a byte per doc says NULL. One pass turns a condition (op, literal) into a filter bitmap row:
+//   * the per-document comparison of ApplyFilters (search_pipeline.cpp:1136-1187): CompareValues' six operators on the
+//     widened value, CompareDoubleValues' epsilon for = / != on doubles (eq_epsilon > 0), NULL a member iff null_matches
+//     (the fallback lets NULL pass != only, :1151-1157); never_matches: the literal did not parse for this column's type
+//     (":invalid number -> false" for every non-NULL doc);
+//   * the EQ bitmap of the FilterIndex path (BuildTypeUnionBitmap, :1021-1094): op EQ, eq_epsilon 0 (doubles by their
+//     bits, as the serialized keys compare), null_matches 0.
+// One thread per doc, one ballot per 64 docs: coalesced 8-byte loads, one 8-byte store per wave.
+__global__ __launch_bounds__(256) void filter_compare_kernel(const uint64_t* __restrict__ values,
+                                                             const uint8_t* __restrict__ is_null, uint32_t n_docs,
+                                                             uint32_t value_class, uint32_t op, uint64_t literal,
+                                                             double eq_epsilon, uint32_t null_matches,
+                                                             uint32_t never_matches, uint64_t* __restrict__ dst) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  bool m = false;
+  if (slot < n_docs) {
+    if (is_null != nullptr && is_null[slot] != 0) {
+      m = null_matches != 0;
+    } else if (never_matches == 0) {
+      const uint64_t v = values[slot];
+      bool lt, gt, le, ge, eq, ne;
+      if (value_class == 0) {  // signed
+        const long long a = static_cast<long long>(v), b = static_cast<long long>(literal);
+        lt = a < b; gt = a > b; le = a <= b; ge = a >= b; eq = a == b; ne = a != b;
+      } else if (value_class == 1) {  // unsigned / string rank
+        lt = v < literal; gt = v > literal; le = v <= literal; ge = v >= literal; eq = v == literal; ne = v != literal;
+      } else {  // double: CompareDoubleValues (comparison_utils.h:56-70), or the exact key comparison of the bitmap path
+        const double a = __longlong_as_double(static_cast<long long>(v)), b = __longlong_as_double(static_cast<long long>(literal));
+        lt = a < b; gt = a > b; le = a <= b; ge = a >= b;
+        if (eq_epsilon > 0.0) {
+          eq = fabs(a - b) < eq_epsilon;
+          ne = fabs(a - b) >= eq_epsilon;
+        } else {
+          eq = v == literal;
+          ne = !eq;
+        }
+      }
+      m = op == 0u ? eq : op == 1u ? ne : op == 2u ? lt : op == 3u ? le : op == 4u ? gt : ge;
+    }
+  }
+  const uint64_t mask = __ballot(m);
+  if ((threadIdx.x & 63) == 0 && slot < ((n_docs + 63u) & ~63u)) dst[slot >> 6] = mask;
+}
+
+int LaunchFilterCompare(const uint64_t* values, const uint8_t* is_null, uint32_t n_docs, uint32_t value_class, uint32_t op,
+                        uint64_t literal, double eq_epsilon, uint32_t null_matches, uint32_t never_matches, uint64_t* dst,
+                        hipStream_t s) {
+  if (n_docs == 0) return 0;
+  hipLaunchKernelGGL(filter_compare_kernel, dim3((n_docs + 255) / 256), dim3(256), 0, s, values, is_null, n_docs, value_class,
+                     op, literal, eq_epsilon, null_matches, never_matches, dst);
+  MGX_KCHECK();
+  return 0;
+}
+
+// FACET (FilterIndex::GetColumnValueCountsFiltered, src/storage/filter_index.cpp:284-312): how many docs of a result
+// bitmap hold each distinct value of a column. value_ids[slot] = dense id of the doc's value (0xFFFFFFFF: NULL — NULLs have
+// no bitmap in the reference's index and are not counted). One thread per 64-doc word of the result; a column of up to
+// kFacetLdsValues distinct values is counted in an LDS histogram per workgroup and flushed once, larger ones with global
+// atomics.
+constexpr uint32_t kFacetLdsValues = 8192;
+__global__ __launch_bounds__(256) void facet_count_kernel(const uint64_t* __restrict__ rbits, uint32_t n_words,
+                                                          const uint32_t* __restrict__ value_ids, uint32_t n_docs,
+                                                          uint32_t n_values, uint32_t use_lds,
+                                                          unsigned long long* __restrict__ counts) {
+  extern __shared__ uint32_t hist[];
+  if (use_lds) {
+    for (uint32_t i = threadIdx.x; i < n_values; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+  }
+  for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += gridDim.x * blockDim.x) {
+    uint64_t bits = rbits[w];
+    while (bits) {
+      const uint32_t slot = w * 64u + static_cast<uint32_t>(__builtin_ctzll(bits));
+      bits &= bits - 1;
+      if (slot >= n_docs) continue;
+      const uint32_t id = value_ids[slot];
+      if (id >= n_values) continue;
+      if (use_lds) atomicAdd(&hist[id], 1u); else atomicAdd(&counts[id], 1ull);
+    }
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_values; i += blockDim.x)
+      if (hist[i]) atomicAdd(&counts[i], static_cast<unsigned long long>(hist[i]));
+  }
+}
+
+int LaunchFacetCount(const uint64_t* rbits, uint32_t n_words, const uint32_t* value_ids, uint32_t n_docs, uint32_t n_values,
+                     unsigned long long* counts, hipStream_t s) {
+  if (n_words == 0 || n_values == 0) return 0;
+  const uint32_t use_lds = n_values <= kFacetLdsValues ? 1u : 0u;
+  const uint32_t blocks = std::min<uint32_t>((n_words + 255) / 256, 2048);
+  hipLaunchKernelGGL(facet_count_kernel, dim3(blocks), dim3(256), use_lds ? n_values * 4 : 0, s, rbits, n_words, value_ids,
+                     n_docs, n_values, use_lds, counts);
   MGX_KCHECK();
   return 0;
 }

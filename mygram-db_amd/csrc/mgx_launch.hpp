@@ -47,6 +47,11 @@ int LaunchPackSeedKeys(const uint32_t* list_begin, const uint8_t* has_seed, cons
 int LaunchApplySeedBounds(const uint64_t* all, uint32_t world, uint32_t n, uint32_t k, const DevQuery* queries,
                           unsigned long long* bounds, hipStream_t s);
 int LaunchBuildContribTables(const TableJob* jobs, uint32_t n_jobs, uint32_t table_dl, double* pool, hipStream_t s);
+int LaunchFilterCompare(const uint64_t* values, const uint8_t* is_null, uint32_t n_docs, uint32_t value_class, uint32_t op,
+                        uint64_t literal, double eq_epsilon, uint32_t null_matches, uint32_t never_matches, uint64_t* dst,
+                        hipStream_t s);
+int LaunchFacetCount(const uint64_t* rbits, uint32_t n_words, const uint32_t* value_ids, uint32_t n_docs, uint32_t n_values,
+                     unsigned long long* counts, hipStream_t s);
 int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, uint32_t n, uint64_t* local,
                    uint64_t* exchange, hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,

@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -121,6 +123,58 @@ std::vector<storage::DocId> Take(uint32_t* p, uint64_t n) {
 }  // namespace
 
 // =================================================================================================================
+// storage::FilterValue keys
+// =================================================================================================================
+
+namespace storage {
+
+std::string SerializeFilterValue(const FilterValue& value) {  // src/storage/filter_index.cpp:177-258 (little-endian host)
+  return std::visit(
+      [](const auto& val) -> std::string {
+        using T = std::decay_t<decltype(val)>;
+        auto raw = [](char tag, const void* p, size_t n) {
+          std::string r(1 + n, '\0');
+          r[0] = tag;
+          std::memcpy(&r[1], p, n);
+          return r;
+        };
+        if constexpr (std::is_same_v<T, std::monostate>) return std::string(1, '\x00');
+        else if constexpr (std::is_same_v<T, bool>) return std::string{'\x01', val ? '\x01' : '\x00'};
+        else if constexpr (std::is_same_v<T, std::string>) return std::string(1, '\x0B') + val;
+        else if constexpr (std::is_same_v<T, double>) return raw('\x0C', &val, sizeof(double));
+        else if constexpr (std::is_same_v<T, TimeValue>) return raw('\x0A', &val.seconds, sizeof(int64_t));
+        else if constexpr (std::is_same_v<T, int8_t>) return raw('\x02', &val, 1);
+        else if constexpr (std::is_same_v<T, uint8_t>) return raw('\x03', &val, 1);
+        else if constexpr (std::is_same_v<T, int16_t>) return raw('\x04', &val, 2);
+        else if constexpr (std::is_same_v<T, uint16_t>) return raw('\x05', &val, 2);
+        else if constexpr (std::is_same_v<T, int32_t>) return raw('\x06', &val, 4);
+        else if constexpr (std::is_same_v<T, uint32_t>) return raw('\x07', &val, 4);
+        else if constexpr (std::is_same_v<T, int64_t>) return raw('\x08', &val, 8);
+        else return raw('\x09', &val, 8);  // uint64_t
+      },
+      value);
+}
+
+std::string FilterValueToDisplayString(const FilterValue& value) {  // DeserializeToDisplayString, filter_index.cpp:314-407
+  return std::visit(
+      [](const auto& val) -> std::string {
+        using T = std::decay_t<decltype(val)>;
+        if constexpr (std::is_same_v<T, std::monostate>) return "NULL";
+        else if constexpr (std::is_same_v<T, bool>) return val ? "true" : "false";
+        else if constexpr (std::is_same_v<T, std::string>) return val;
+        else if constexpr (std::is_same_v<T, TimeValue>) return std::to_string(val.seconds);
+        else if constexpr (std::is_same_v<T, double>) {
+          char buf[32];
+          auto [ptr, ec] = std::to_chars(buf, buf + sizeof(buf), val);
+          return ec != std::errc() ? std::string() : std::string(buf, ptr);
+        } else return std::to_string(val);
+      },
+      value);
+}
+
+}  // namespace storage
+
+// =================================================================================================================
 // index::Index
 // =================================================================================================================
 
@@ -188,6 +242,38 @@ struct Index::Impl {
     return false;
   }
   std::unordered_map<std::string, uint64_t> absent_grams;  // grams of the table this shard has no posting for -> size
+
+  // ---- filter columns (DocumentStore filter values + FilterIndex, on the device by doc slot) -------------------------
+  struct FilterColumn {
+    std::string name;
+    size_t type = 0;      // index of the FilterValue alternative every non-NULL value holds (0: the column is all NULL)
+    uint32_t device_id = 0;
+    std::vector<storage::FilterValue> dict;  // distinct non-NULL values, ascending (strings bytewise): value id = position
+  };
+  mutable std::mutex filter_mu;  // columns, the condition cache
+  mutable std::vector<FilterColumn> filter_columns;
+  mutable std::unordered_map<std::string, std::pair<uint32_t, bool>> condition_cache;  // key -> (bitmap id, negate)
+  mutable std::map<DocId, storage::FilterMap> pending_filters;  // AddDocument(..., filters) before the first search
+  mutable uint32_t empty_bitmap = 0;
+  mutable bool have_empty_bitmap = false;
+
+  // FilterIndex::ResolveColumnName (filter_index.cpp:122-147): exact name first, else the one unambiguous ASCII
+  // case-insensitive match
+  const FilterColumn* ResolveColumn(std::string_view name) const {
+    const FilterColumn* hit = nullptr;
+    for (const auto& c : filter_columns)
+      if (c.name == name) return &c;
+    for (const auto& c : filter_columns) {
+      if (c.name.size() != name.size()) continue;
+      bool same = true;
+      for (size_t i = 0; same && i < name.size(); ++i)
+        same = std::tolower(static_cast<unsigned char>(c.name[i])) == std::tolower(static_cast<unsigned char>(name[i]));
+      if (!same) continue;
+      if (hit) return nullptr;
+      hit = &c;
+    }
+    return hit;
+  }
 };
 
 Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, bool cross_boundary_ngrams,
@@ -226,6 +312,84 @@ bool Index::AddDocument(DocId doc_id, std::string_view text) {
   }
   impl_->pending[doc_id] = std::string(text);
   return !GenerateHybridNgrams(text, ngram_size_, kanji_ngram_size_, cross_boundary_).empty();  // index.cpp:39-74
+}
+
+bool Index::AddDocument(DocId doc_id, std::string_view text, const storage::FilterMap& filters) {
+  const bool has_grams = AddDocument(doc_id, text);
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  if (!impl_->finalized) impl_->pending_filters[doc_id] = filters;
+  return has_grams;
+}
+
+namespace {
+// widened device value of a non-NULL FilterValue (strings: their dictionary rank, filled in by the caller)
+uint64_t WidenFilterValue(const storage::FilterValue& v) {
+  return std::visit(
+      [](const auto& val) -> uint64_t {
+        using T = std::decay_t<decltype(val)>;
+        if constexpr (std::is_same_v<T, std::monostate> || std::is_same_v<T, std::string>) return 0;
+        else if constexpr (std::is_same_v<T, storage::TimeValue>) return static_cast<uint64_t>(val.seconds);
+        else if constexpr (std::is_same_v<T, double>) {
+          uint64_t u;
+          std::memcpy(&u, &val, 8);
+          return u;
+        } else if constexpr (std::is_signed_v<T> || std::is_same_v<T, bool>) return static_cast<uint64_t>(static_cast<int64_t>(val));
+        else return static_cast<uint64_t>(val);
+      },
+      v);
+}
+uint32_t FilterClassOf(size_t type) {  // MGX_FC_* of a FilterValue alternative
+  switch (type) {
+    case 12: return MGX_FC_DOUBLE;
+    case 3: case 5: case 7: case 9: case 11: return MGX_FC_UNSIGNED;
+    default: return MGX_FC_SIGNED;  // bool, int8/16/32/64, TimeValue
+  }
+}
+}  // namespace
+
+std::string Index::AddFilterColumn(const std::string& name, const std::vector<storage::FilterValue>& values) const {
+  Finalize();
+  Impl* im = impl_.get();
+  if (!im->dev) return im->last_error.empty() ? "AddFilterColumn: no device index" : im->last_error;
+  if (values.size() != im->view.n_docs) return "AddFilterColumn: one value per doc slot of the index";
+  Impl::FilterColumn col;
+  col.name = name;
+  for (const auto& v : values) {
+    if (v.index() == 0) continue;
+    if (col.type == 0) col.type = v.index();
+    if (v.index() != col.type) return "AddFilterColumn: the values of one column must hold one type";
+  }
+  std::vector<storage::FilterValue> nn;
+  for (const auto& v : values)
+    if (v.index() != 0) nn.push_back(v);
+  std::sort(nn.begin(), nn.end());
+  nn.erase(std::unique(nn.begin(), nn.end()), nn.end());
+  col.dict = std::move(nn);
+  const size_t n = values.size();
+  std::vector<uint64_t> wide(n, 0);
+  std::vector<uint8_t> nul(n, 0);
+  std::vector<uint32_t> ids(n, 0xFFFFFFFFu);
+  for (size_t i = 0; i < n; ++i) {
+    if (values[i].index() == 0) {
+      nul[i] = 1;
+      continue;
+    }
+    const auto it = std::lower_bound(col.dict.begin(), col.dict.end(), values[i]);
+    ids[i] = static_cast<uint32_t>(it - col.dict.begin());
+    wide[i] = col.type == 11 ? ids[i] : WidenFilterValue(values[i]);  // strings compare by their bytewise rank
+  }
+  mgx_filter_column_desc d{sizeof(mgx_filter_column_desc), MGX_ABI_VERSION, FilterClassOf(col.type),
+                           static_cast<uint32_t>(col.dict.size()), wide.data(), nul.data(), ids.data()};
+  if (mgx_index_add_filter_column(im->dev, &d, &col.device_id) != MGX_OK) return mgx_last_error();
+  std::lock_guard<std::mutex> lock(im->filter_mu);
+  for (auto& c : im->filter_columns)
+    if (c.name == name) {
+      c = std::move(col);  // (replaced: cached conditions of the old column are dropped)
+      im->condition_cache.clear();
+      return "";
+    }
+  im->filter_columns.push_back(std::move(col));
+  return "";
 }
 
 void Index::AddDocumentBatch(const std::vector<DocumentItem>& documents) {
@@ -280,7 +444,34 @@ std::string Index::Finalize() const {
   if (impl_->has_gaps &&
       mgx_index_add_filter_bitmap(impl_->dev, existing.data(), existing.size(), &impl_->exists_bitmap) != MGX_OK)
     impl_->last_error = mgx_last_error();
+  pending_columns_ready_ = !impl_->pending_filters.empty();
   return impl_->last_error;
+}
+
+// The filter values recorded by AddDocument(doc, text, filters) become device columns (outside impl_->mu: AddFilterColumn
+// calls Finalize itself).
+void Index::FlushPendingFilterColumns() const {
+  std::map<DocId, storage::FilterMap> pending;
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    if (!pending_columns_ready_) return;
+    pending_columns_ready_ = false;
+    pending.swap(impl_->pending_filters);
+  }
+  std::vector<std::string> names;
+  for (const auto& kv : pending)
+    for (const auto& f : kv.second)
+      if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);
+  const DocId first = impl_->view.first_doc_id;
+  for (const auto& name : names) {
+    std::vector<storage::FilterValue> values(impl_->view.n_docs);
+    for (const auto& kv : pending) {
+      const auto it = kv.second.find(name);
+      if (it != kv.second.end() && kv.first >= first && kv.first - first < values.size()) values[kv.first - first] = it->second;
+    }
+    const std::string err = AddFilterColumn(name, values);
+    if (!err.empty()) impl_->last_error = err;
+  }
 }
 
 const std::string& Index::LastError() const { return impl_->last_error; }
@@ -734,8 +925,187 @@ void Fail(PlannedQuery* p, ErrorCode code, const char* msg) {
   p->error_message = msg;
 }
 
+// ---- FILTER conditions -> device bitmaps -------------------------------------------------------------------------------
+template <typename T>
+bool ParseWhole(const std::string& s, T* out) {  // std::from_chars over the whole string (search_pipeline.cpp:962-991)
+  const char* end = s.data() + s.size();
+  T v{};
+  auto [ptr, ec] = std::from_chars(s.data(), end, v);
+  if (ec != std::errc() || ptr != end) return false;
+  *out = v;
+  return true;
+}
+
+struct ResolvedFilter {
+  bool skip = false;     // the condition holds for every document
+  uint32_t bitmap = 0;
+  bool negate = false;
+};
+
+// One FilterCondition against the table's columns. bitmap_mode: every condition of the query is EQ / NE (the FilterIndex
+// path, ApplyFiltersWithBitmap search_pipeline.cpp:1196-1237); otherwise the per-document semantics of ApplyFilters
+// (:1098-1194) for every condition of the query. Returns an error message or "".
+std::string ResolveCondition(const index::Index& index, const query::FilterCondition& cond, bool bitmap_mode,
+                             ResolvedFilter* out) {
+  index.FlushPendingFilterColumns();
+  index::Index::Impl* im = index.impl();
+  std::lock_guard<std::mutex> lock(im->filter_mu);
+  const index::Index::Impl::FilterColumn* col = im->ResolveColumn(cond.column);
+  std::string key;
+  key.push_back(bitmap_mode ? 'b' : 'f');
+  key.push_back(static_cast<char>('0' + static_cast<int>(cond.op)));
+  key += col ? col->name : std::string("\x01") + cond.column;
+  key.push_back('\0');
+  key += cond.value;
+  const auto hit = im->condition_cache.find(key);
+  if (hit != im->condition_cache.end()) {
+    out->bitmap = hit->second.first;
+    out->negate = hit->second.second;
+    out->skip = hit->second.first == 0xFFFFFFFFu;
+    return "";
+  }
+  auto remember = [&](uint32_t bitmap, bool negate, bool skip) {
+    out->bitmap = bitmap;
+    out->negate = negate;
+    out->skip = skip;
+    im->condition_cache.emplace(key, std::make_pair(skip ? 0xFFFFFFFFu : bitmap, negate));
+  };
+  auto empty_bitmap = [&](uint32_t* id) -> std::string {
+    if (!im->have_empty_bitmap) {
+      if (mgx_index_add_filter_bitmap(im->dev, nullptr, 0, &im->empty_bitmap) != MGX_OK) return mgx_last_error();
+      im->have_empty_bitmap = true;
+    }
+    *id = im->empty_bitmap;
+    return "";
+  };
+  const bool is_ne = cond.op == query::FilterOp::NE;
+  // a column no document has: every stored value is NULL — nothing equals or orders against it, != holds everywhere
+  // (bitmap path: OrEqBitmapInto finds no column, :107-109; per-document path: NULL passes != only, :1151-1157)
+  if (col == nullptr || col->type == 0) {
+    if (is_ne) {
+      remember(0, false, true);
+      return "";
+    }
+    uint32_t id = 0;
+    const std::string err = empty_bitmap(&id);
+    if (!err.empty()) return err;
+    remember(id, false, false);
+    return "";
+  }
+  const size_t type = col->type;
+  const std::string& v = cond.value;
+  uint64_t lit = 0;
+  bool valid = false;
+  uint32_t op = 0;
+  double eps = 0.0;
+  if (type == 11) {  // string column: ranks in the column's bytewise-sorted dictionary
+    const storage::FilterValue needle{v};
+    const auto lb = std::lower_bound(col->dict.begin(), col->dict.end(), needle);
+    const auto ub = std::upper_bound(col->dict.begin(), col->dict.end(), needle);
+    const uint64_t lbi = static_cast<uint64_t>(lb - col->dict.begin()), ubi = static_cast<uint64_t>(ub - col->dict.begin());
+    valid = true;
+    switch (cond.op) {
+      case query::FilterOp::EQ:
+      case query::FilterOp::NE:
+        op = MGX_CMP_EQ;  // (NE: the EQ set, negated below / by the null rule)
+        lit = lb != ub ? lbi : ~0ull;  // a literal no document holds equals no rank
+        break;
+      case query::FilterOp::LT: op = MGX_CMP_LT; lit = lbi; break;   // stored <  v  <=> rank <  lower_bound
+      case query::FilterOp::LTE: op = MGX_CMP_LT; lit = ubi; break;  // stored <= v  <=> rank <  upper_bound
+      case query::FilterOp::GT: op = MGX_CMP_GE; lit = ubi; break;   // stored >  v  <=> rank >= upper_bound
+      default: op = MGX_CMP_GE; lit = lbi; break;                     // stored >= v  <=> rank >= lower_bound
+    }
+  } else {
+    switch (cond.op) {
+      case query::FilterOp::EQ: case query::FilterOp::NE: op = MGX_CMP_EQ; break;
+      case query::FilterOp::LT: op = MGX_CMP_LT; break;
+      case query::FilterOp::LTE: op = MGX_CMP_LE; break;
+      case query::FilterOp::GT: op = MGX_CMP_GT; break;
+      default: op = MGX_CMP_GE; break;
+    }
+    if (type == 1) {  // bool
+      if (bitmap_mode) {  // BuildTypeUnionBitmap :1043-1048
+        valid = v == "1" || v == "true" || v == "0" || v == "false";
+        lit = (v == "1" || v == "true") ? 1 : 0;
+      } else {  // ParseFilterValue :957: anything but "1" / "true" reads as false
+        valid = true;
+        lit = (v == "1" || v == "true") ? 1 : 0;
+      }
+    } else if (type == 12) {  // double
+      double d = 0.0;
+      valid = ParseWhole(v, &d);
+      std::memcpy(&lit, &d, 8);
+      if (!bitmap_mode) eps = 1e-9;  // mygram::constants::kFilterValueEpsilon (src/utils/constants.h:104)
+    } else if (type == 3 || type == 5 || type == 7 || type == 9) {  // unsigned
+      uint64_t u = 0;
+      valid = ParseWhole(v, &u);
+      lit = u;
+      if (bitmap_mode && valid) {  // the literal must be representable in the column's type (:1078-1089)
+        const uint64_t mx = type == 3 ? 0xFFull : type == 5 ? 0xFFFFull : type == 7 ? 0xFFFFFFFFull : ~0ull;
+        valid = u <= mx;
+      }
+    } else {  // signed integers, TimeValue
+      int64_t i = 0;
+      valid = ParseWhole(v, &i);
+      lit = static_cast<uint64_t>(i);
+      if (bitmap_mode && valid) {  // :1057-1067
+        const int64_t lo = type == 2 ? INT8_MIN : type == 4 ? INT16_MIN : type == 6 ? INT32_MIN : INT64_MIN;
+        const int64_t hi = type == 2 ? INT8_MAX : type == 4 ? INT16_MAX : type == 6 ? INT32_MAX : INT64_MAX;
+        valid = i >= lo && i <= hi;
+      }
+    }
+  }
+  uint32_t id = 0;
+  if (bitmap_mode) {
+    // EQ: AND the union of the literal's interpretations; NE: ANDNOT it (NULL documents are in no value bitmap: they
+    // pass NE, fail EQ). No interpretation in this column's type: the union is empty.
+    if (!valid) {
+      if (is_ne) {
+        remember(0, false, true);
+        return "";
+      }
+      const std::string err = empty_bitmap(&id);
+      if (!err.empty()) return err;
+      remember(id, false, false);
+      return "";
+    }
+    if (mgx_index_filter_compare(im->dev, col->device_id, MGX_CMP_EQ, lit, 0.0, 0, 0, &id) != MGX_OK) return mgx_last_error();
+    remember(id, is_ne, false);
+    return "";
+  }
+  // per-document semantics: the set of documents that PASS the condition, ANDed
+  const uint32_t dev_op = is_ne ? static_cast<uint32_t>(MGX_CMP_NE) : op;
+  if (mgx_index_filter_compare(im->dev, col->device_id, dev_op, lit, eps, is_ne ? 1 : 0, valid ? 0 : 1, &id) != MGX_OK)
+    return mgx_last_error();
+  remember(id, false, false);
+  return "";
+}
+
 void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_docs, double avgdl, PlannedQuery* p) {
   const index::Index::Impl* im = index.impl();
+  // FILTER clauses: caller-resolved bitmaps, then the parsed conditions (resolved here, cached by the Index)
+  auto add_filters = [&]() -> bool {
+    for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    bool bitmap_mode = true;  // AllFiltersHaveBitmapSupport, search_pipeline.cpp:996-1003
+    for (const auto& c : q.filter_conditions)
+      bitmap_mode = bitmap_mode && (c.op == query::FilterOp::EQ || c.op == query::FilterOp::NE);
+    for (const auto& c : q.filter_conditions) {
+      ResolvedFilter rf;
+      const std::string err = ResolveCondition(index, c, bitmap_mode, &rf);
+      if (!err.empty()) {
+        p->error = ErrorCode::kInternalError;
+        p->error_message = err;
+        return false;
+      }
+      if (!rf.skip) p->filters.push_back(mgx_filter{rf.bitmap, rf.negate ? 1u : 0u});
+    }
+    if (p->filters.size() > MGX_MAX_TERMS) {
+      p->error = ErrorCode::kInvalidArgument;
+      p->error_message = "more than 64 filters in one query";
+      return false;
+    }
+    return true;
+  };
   auto finish = [&](uint32_t sort) {
     mgx_query& m = p->q;
     m.terms = p->terms.data();
@@ -831,7 +1201,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       p->terms.push_back(mt);
     }
     if (!add_not_terms()) return;
-    for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    if (!add_filters()) return;
     if (im->has_gaps) p->filters.push_back(mgx_filter{im->exists_bitmap, 0u});  // NOT universe = added ids
     finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
     p->q.offset = q.sort_by_score ? q.offset : 0;
@@ -894,7 +1264,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       p->terms.push_back(mt);
     }
     if (!add_not_terms()) return;
-    for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+    if (!add_filters()) return;
     finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
     p->q.offset = q.sort_by_score ? q.offset : 0;
     return;
@@ -932,7 +1302,7 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
     p->terms.push_back(mt);
   }
   if (!add_not_terms()) return;
-  for (const auto& f : q.filters) p->filters.push_back(mgx_filter{f.first, f.second ? 1u : 0u});
+  if (!add_filters()) return;
   finish(q.sort_by_score ? MGX_SORT_SCORE : MGX_SORT_DOCID);
   p->q.offset = q.offset;
   p->q.exact_text = exact ? 1u : 0u;
@@ -995,6 +1365,55 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   rc = mgx_batch_fetch(batch, &v);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   Collect(plans, v, &out);
+  return out;
+}
+
+Expected<FacetOutput, Error> ExecuteFacet(const index::Index& index, const BatchQuery& query, const std::string& column) {
+  index.Finalize();
+  index.FlushPendingFilterColumns();
+  index::Index::Impl* im = index.impl();
+  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  uint32_t device_column = 0;
+  std::vector<storage::FilterValue> dict;
+  {
+    std::lock_guard<std::mutex> lock(im->filter_mu);
+    const index::Index::Impl::FilterColumn* col = im->ResolveColumn(column);
+    if (col == nullptr)  // search_pipeline.cpp:2089-2092
+      return MakeUnexpected(MakeError(ErrorCode::kIndexNotFound, "Facet column \"" + column + "\" not found"));
+    device_column = col->device_id;
+    dict = col->dict;
+  }
+  // the search part: the query's own, or — FACET without search terms — every document (GetAllDocIds, :2118) narrowed by
+  // its NOT terms and filters: the expression NOT(<empty>) is the universe
+  BatchQuery q = query;
+  q.sort_by_score = false;
+  q.limit = 0;
+  q.offset = 0;
+  if (q.terms.empty() && !q.ast) {
+    auto all = std::make_shared<query::QueryNode>(query::NodeType::NOT);
+    all->children.push_back(std::make_unique<query::QueryNode>(std::string()));
+    q.ast = std::move(all);
+  }
+  PlannedQuery plan;
+  PlanQuery(index, q, index.Bm25DocCount(), index.Bm25AvgDocLength(), &plan);
+  if (plan.error != ErrorCode::kSuccess) return MakeUnexpected(MakeError(plan.error, plan.error_message));
+  FacetOutput out;
+  std::vector<uint64_t> counts(std::max<size_t>(dict.size(), 1), 0);
+  if (plan.on_device) {
+    if (mgx_facet_counts(im->dev, &plan.q, device_column, counts.data(), &out.matched_documents) != MGX_OK)
+      return MakeUnexpected(MakeError(ErrorCode::kInternalError, mgx_last_error()));
+  }
+  std::vector<size_t> order;
+  for (size_t v = 0; v < dict.size(); ++v)
+    if (counts[v] > 0) order.push_back(v);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return counts[a] > counts[b]; });  // :307
+  out.total_values = order.size();
+  const size_t first = std::min<size_t>(query.offset, order.size());                         // :2141-2148
+  const size_t last = std::min<size_t>(order.size(), first + static_cast<size_t>(query.limit));
+  for (size_t k = first; k < last; ++k) {
+    out.value_counts.emplace_back(storage::SerializeFilterValue(dict[order[k]]), counts[order[k]]);
+    out.display.push_back(storage::FilterValueToDisplayString(dict[order[k]]));
+  }
   return out;
 }
 

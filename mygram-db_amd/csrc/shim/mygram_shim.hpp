@@ -103,6 +103,20 @@ void ResetTextNormalizationFailureCountForTesting();
 
 namespace mygramdb::storage {
 using DocId = uint32_t;  // src/types/doc_id.h:31
+
+// src/storage/document_store.h:44-87: the value a document holds in one filter column.
+struct TimeValue {
+  int64_t seconds;
+  bool operator==(const TimeValue& o) const { return seconds == o.seconds; }
+  bool operator<(const TimeValue& o) const { return seconds < o.seconds; }
+};
+using FilterValue = std::variant<std::monostate, bool, int8_t, uint8_t, int16_t, uint16_t, int32_t, uint32_t, int64_t,
+                                 uint64_t, TimeValue, std::string, double>;
+using FilterMap = std::unordered_map<std::string, FilterValue>;
+// FilterIndex::SerializeFilterValue (src/storage/filter_index.cpp:177-258): type tag + little-endian value bytes — the key
+// FACET reports a value under; DeserializeToDisplayString (:314-372) is its printable form.
+std::string SerializeFilterValue(const FilterValue& value);
+std::string FilterValueToDisplayString(const FilterValue& value);
 }
 
 namespace mygramdb::index {
@@ -166,6 +180,13 @@ class Index {
   // FilterIndex (column,value) doc set -> device bitmap id usable in search_pipeline::BatchQuery::filters.
   [[nodiscard]] mygram::utils::Expected<uint32_t, mygram::utils::Error> AddFilterBitmap(
       const std::vector<DocId>& docs) const;
+  // One filter column of the table (what DocumentStore::AddDocument's FilterMap holds per document,
+  // src/storage/document_store.h:73-87): values[i] belongs to doc first_doc_id + i (std::monostate = NULL); every
+  // non-NULL value must hold the same alternative (one MySQL column type). The column goes to the device by doc slot;
+  // BatchQuery::filter_conditions and ExecuteFacet resolve against it. Returns "" or an error message.
+  std::string AddFilterColumn(const std::string& name, const std::vector<storage::FilterValue>& values) const;
+  // AddDocument with the document's filter values (recorded until the first search, like the text)
+  bool AddDocument(DocId doc_id, std::string_view text, const storage::FilterMap& filters);
 
   // An Index over column arrays and a device index that already exist (built through the C ABI by the caller, e.g. a
   // loader that read them from a dump): nothing is copied, the handles stay the caller's and must outlive the Index.
@@ -195,6 +216,10 @@ class Index {
   std::string normalize_width_ = "keep";
   bool normalize_lower_ = true;
   std::unique_ptr<Impl> impl_;
+  mutable bool pending_columns_ready_ = false;  // (under Impl::mu)
+
+ public:
+  void FlushPendingFilterColumns() const;  // internal: AddDocument's filter values -> device columns, after Finalize
 };
 
 struct BM25Params {  // src/index/bm25_scorer.h:20-23
@@ -223,6 +248,12 @@ namespace mygramdb::query {
 
 using DocId = storage::DocId;
 enum class SortOrder : uint8_t { ASC, DESC };  // src/query/query_parser.h
+enum class FilterOp : uint8_t { EQ, NE, GT, GTE, LT, LTE };  // src/query/query_parser.h:93-100
+struct FilterCondition {                                       // src/query/query_parser.h:123-127
+  std::string column;
+  FilterOp op = FilterOp::EQ;
+  std::string value;
+};
 
 // query::QueryNode (src/query/query_ast.h:52-83): the boolean expression tree QueryASTParser produces.
 enum class NodeType : uint8_t { AND, OR, NOT, TERM };
@@ -258,6 +289,12 @@ struct BatchQuery {
   std::shared_ptr<const query::QueryNode> ast;
   std::vector<std::string> not_terms;
   std::vector<std::pair<uint32_t, bool>> filters;  // (bitmap id from Index::AddFilterBitmap, negate = FilterOp::NE)
+  // query::Query::filters as parsed (FILTER col op value): resolved against the columns of Index::AddFilterColumn the way
+  // ApplyFiltersWithBitmap does (search_pipeline.cpp:1196-1237) — all EQ / NE: the literal under every type
+  // interpretation the column can hold (BuildTypeUnionBitmap :1021-1094), exact; any other operator in the list: every
+  // condition by the per-document comparison of ApplyFilters (:1098-1194: NULL passes != only, doubles compare = / !=
+  // with an epsilon). A condition becomes a device bitmap the first time it is seen and is cached by the Index.
+  std::vector<query::FilterCondition> filter_conditions;
   uint32_t fuzzy_max_distance = 0;     // FUZZY d (query_parser_clauses.cpp:454: 1 or 2); 0 = not a fuzzy query.
                                        // ExecuteWithFuzzy (search_pipeline.cpp:1659-1744): per term "at least theta of
                                        // its n-grams", AND across terms in the order given; SORT _score scores the
@@ -284,6 +321,20 @@ struct BatchResult {
 // Execute, BM25 + SortByScore) and run as ONE device batch.
 mygram::utils::Expected<std::vector<BatchResult>, mygram::utils::Error> ExecuteBatch(
     const index::Index& index, const std::vector<BatchQuery>& queries);
+
+// FACET (ExecuteFacetPipeline, src/server/search_pipeline.cpp:2061-2153): how many documents of the query's result set
+// hold each value of `column`. query.terms / ast / not_terms / filters / filter_conditions select the documents (none of
+// them: every document); limit / offset page the VALUES (offset first, :2141-2148); sort fields are ignored.
+struct FacetOutput {
+  uint64_t matched_documents = 0;
+  uint64_t total_values = 0;  // values with a non-zero count, before paging
+  // (SerializeFilterValue key, count), count descending; the order among equal counts is unspecified in the reference
+  // (hash-map iteration + std::sort) — here ties keep the column's value order
+  std::vector<std::pair<std::string, uint64_t>> value_counts;
+  std::vector<std::string> display;  // DeserializeToDisplayString of each key, parallel to value_counts
+};
+mygram::utils::Expected<FacetOutput, mygram::utils::Error> ExecuteFacet(const index::Index& index, const BatchQuery& query,
+                                                                        const std::string& column);
 
 // A serving loop over ExecuteBatch's work. Submit queues a FRESH batch and returns at once; a pool of `planner_threads`
 // workers plans it in chunks of queries (GenerateTermInfos, the size sort and idf per term — the way the reference

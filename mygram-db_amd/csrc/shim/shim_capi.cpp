@@ -218,6 +218,112 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
   }
 }
 
+namespace {
+using mygramdb::query::FilterCondition;
+using mygramdb::query::FilterOp;
+using mygramdb::storage::FilterValue;
+
+BatchQuery MakeQuery(uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
+                     uint32_t n_cond, const char* const* cond_columns, const uint32_t* cond_ops,
+                     const char* const* cond_values, int sort_by_score, int descending, uint32_t limit, uint32_t offset) {
+  BatchQuery q;
+  for (uint32_t t = 0; t < n_terms; ++t) q.terms.emplace_back(terms[t]);
+  for (uint32_t t = 0; t < n_not; ++t) q.not_terms.emplace_back(not_terms[t]);
+  for (uint32_t c = 0; c < n_cond; ++c)
+    q.filter_conditions.push_back(FilterCondition{cond_columns[c], static_cast<FilterOp>(cond_ops[c]), cond_values[c]});
+  q.sort_by_score = sort_by_score != 0;
+  q.order = descending ? mygramdb::query::SortOrder::DESC : mygramdb::query::SortOrder::ASC;
+  q.limit = limit;
+  q.offset = offset;
+  return q;
+}
+}  // namespace
+
+int mgxs_table_add_filter_column(mgxs_table* table, const char* name, int value_type, uint64_t n, const void* values,
+                                 const char* const* strings, const uint8_t* is_null) {
+  if (!table || !name || (n && !values && !strings)) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_add_filter_column: null argument");
+  if (value_type < 1 || value_type > 12) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_add_filter_column: value_type is 1..12");
+  try {
+    std::vector<FilterValue> v(n);
+    const int64_t* si = static_cast<const int64_t*>(values);
+    const uint64_t* ui = static_cast<const uint64_t*>(values);
+    const double* di = static_cast<const double*>(values);
+    for (uint64_t i = 0; i < n; ++i) {
+      if (is_null && is_null[i]) continue;  // std::monostate
+      switch (value_type) {
+        case 1: v[i] = si[i] != 0; break;
+        case 2: v[i] = static_cast<int8_t>(si[i]); break;
+        case 3: v[i] = static_cast<uint8_t>(ui[i]); break;
+        case 4: v[i] = static_cast<int16_t>(si[i]); break;
+        case 5: v[i] = static_cast<uint16_t>(ui[i]); break;
+        case 6: v[i] = static_cast<int32_t>(si[i]); break;
+        case 7: v[i] = static_cast<uint32_t>(ui[i]); break;
+        case 8: v[i] = static_cast<int64_t>(si[i]); break;
+        case 9: v[i] = static_cast<uint64_t>(ui[i]); break;
+        case 10: v[i] = mygramdb::storage::TimeValue{si[i]}; break;
+        case 11: v[i] = std::string(strings[i]); break;
+        default: v[i] = di[i]; break;
+      }
+    }
+    const std::string err = table->index->AddFilterColumn(name, v);
+    return err.empty() ? MGX_OK : Fail(MGX_ERR_INVALID_ARGUMENT, err);
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_search(mgxs_table* table, uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
+                uint32_t n_cond, const char* const* cond_columns, const uint32_t* cond_ops, const char* const* cond_values,
+                int sort_by_score, int descending, uint32_t limit, uint32_t offset, uint64_t* total, uint32_t* n_docs,
+                uint32_t* docs, double* scores) {
+  if (!table || !total || !n_docs || (limit && !docs)) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_search: null argument");
+  try {
+    const BatchQuery q = MakeQuery(n_terms, terms, n_not, not_terms, n_cond, cond_columns, cond_ops, cond_values,
+                                   sort_by_score, descending, limit, offset);
+    auto r = mygramdb::search_pipeline::ExecuteBatch(*table->index, {q});
+    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
+    const auto& res = (*r)[0];
+    *total = res.total;
+    const size_t n = limit ? std::min<size_t>(res.results.size(), limit) : 0;
+    *n_docs = static_cast<uint32_t>(n);
+    for (size_t k = 0; k < n; ++k) {
+      docs[k] = res.results[k];
+      if (scores) scores[k] = k < res.scores.size() ? res.scores[k] : 0.0;
+    }
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_facet(mgxs_table* table, uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
+               uint32_t n_cond, const char* const* cond_columns, const uint32_t* cond_ops, const char* const* cond_values,
+               const char* column, uint32_t limit, uint32_t offset, uint64_t* matched, uint64_t* total_values,
+               uint32_t* n_out, uint64_t* counts, char* display, size_t display_cap, uint32_t* display_off) {
+  if (!table || !column || !matched || !total_values || !n_out || (limit && (!counts || !display || !display_off)))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_facet: null argument");
+  try {
+    const BatchQuery q = MakeQuery(n_terms, terms, n_not, not_terms, n_cond, cond_columns, cond_ops, cond_values, 0, 1, limit, offset);
+    auto r = mygramdb::search_pipeline::ExecuteFacet(*table->index, q, column);
+    if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
+    *matched = r->matched_documents;
+    *total_values = r->total_values;
+    *n_out = static_cast<uint32_t>(r->value_counts.size());
+    size_t at = 0;
+    for (size_t k = 0; k < r->value_counts.size(); ++k) {
+      counts[k] = r->value_counts[k].second;
+      display_off[k] = static_cast<uint32_t>(at);
+      if (at + r->display[k].size() > display_cap) return Fail(MGX_ERR_OUT_OF_RANGE, "mgxs_facet: display buffer too small");
+      std::memcpy(display + at, r->display[k].data(), r->display[k].size());
+      at += r->display[k].size();
+    }
+    display_off[r->value_counts.size()] = static_cast<uint32_t>(at);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 int mgxs_batcher_create(mgxs_table* table, uint32_t max_batch, uint32_t max_delay_us, int depth, int planner_threads,
                         mgxs_batcher** out) {
   if (out) *out = nullptr;

@@ -270,6 +270,39 @@ class DeviceIndex:
         check(load().mgx_index_add_filter_bitmap(self._h, a.ctypes.data, len(a), C.byref(out)))
         return int(out.value)
 
+    def add_filter_column(self, values, is_null=None, value_ids=None, n_values=0):
+        """mgx_index_add_filter_column: a typed filter column by doc slot. `values`: int64 (signed class), uint64
+        (unsigned class / string ranks) or float64 array."""
+        v = np.ascontiguousarray(values)
+        cls = {"i": 0, "u": 1, "f": 2}[v.dtype.kind]
+        v = v.astype({0: np.int64, 1: np.uint64, 2: np.float64}[cls])
+        keep = [v]
+        nul = None
+        if is_null is not None:
+            nul = np.ascontiguousarray(is_null, dtype=np.uint8)
+            keep.append(nul)
+        ids = None
+        if value_ids is not None:
+            ids = np.ascontiguousarray(value_ids, dtype=np.uint32)
+            keep.append(ids)
+        d = _capi.FilterColumnDesc(C.sizeof(_capi.FilterColumnDesc), _capi.ABI_VERSION, cls, int(n_values), v.ctypes.data,
+                                   nul.ctypes.data if nul is not None else None, ids.ctypes.data if ids is not None else None)
+        out = C.c_uint32()
+        check(load().mgx_index_add_filter_column(self._h, C.byref(d), C.byref(out)))
+        return int(out.value)
+
+    def filter_compare(self, column_id, op, literal, eq_epsilon=0.0, null_matches=False, never_matches=False):
+        """mgx_index_filter_compare -> filter bitmap id. op: 0 = , 1 != , 2 < , 3 <= , 4 > , 5 >= ; literal: a python int or
+        float in the column's class."""
+        if isinstance(literal, float):
+            bits = int(np.float64(literal).view(np.uint64))
+        else:
+            bits = int(literal) & 0xFFFFFFFFFFFFFFFF
+        out = C.c_uint32()
+        check(load().mgx_index_filter_compare(self._h, column_id, op, bits, float(eq_epsilon), int(null_matches),
+                                              int(never_matches), C.byref(out)))
+        return int(out.value)
+
 
 # --------------------------------------------------------------------------------------------------------------------
 # queries
@@ -885,10 +918,23 @@ class Index:
                     cq.universe_first, cq.universe_count = q.universe
             cqueries.append(cq)
             shells.append(None)
+        if into == "raw":  # (facet: the compiled C queries themselves)
+            return cqueries, keep, shells
         if into is not None:
             into.reset(cqueries, keep, shells, orders)
             return into
         return PreparedBatch(self, cqueries, keep, shells, orders)
+
+    def facet_counts(self, query, column_id, n_values):
+        """mgx_facet_counts: (matched documents, counts per value id) of the query's whole result set."""
+        cqueries, keep, shells = self.prepare([query], into="raw")
+        if shells[0] is not None:  # resolved on the host: an empty result
+            return 0, np.zeros(n_values, np.uint64)
+        counts = np.zeros(max(n_values, 1), np.uint64)
+        matched = C.c_uint64()
+        check(load().mgx_facet_counts(self.device_index._h, C.byref(cqueries[0]), column_id, counts.ctypes.data,
+                                      C.byref(matched)))
+        return int(matched.value), counts[:n_values]
 
     def search_batch(self, queries):
         b = self.prepare(queries)

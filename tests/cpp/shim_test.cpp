@@ -397,6 +397,52 @@ int main() {
       EXPECT((*f2)[0].scores.size() == (*f2)[0].results.size() && (*f2)[0].scores[0] > (*f2)[0].scores.back());
     }
   }
+  {  // FILTER conditions + FACET on typed columns fed through AddDocument(doc, text, filters):
+     // tests/server/search_pipeline_test.cpp:725-910 (SearchPipelineFilterParityTest), facet_handler_test.cpp:203-258
+    using namespace mygramdb::search_pipeline;
+    using mygramdb::query::FilterCondition;
+    using mygramdb::query::FilterOp;
+    using mygramdb::storage::FilterValue;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "text zero", {{"status", FilterValue{int64_t{1}}}, {"category", FilterValue{std::string("tech")}}, {"score", FilterValue{85.5}}});
+    index.AddDocument(2, "text one", {{"status", FilterValue{int64_t{2}}}, {"category", FilterValue{std::string("sports")}}, {"score", FilterValue{92.0}}});
+    index.AddDocument(3, "text two", {{"status", FilterValue{int64_t{1}}}, {"category", FilterValue{std::string("tech")}}, {"score", FilterValue{78.0}}});
+    index.AddDocument(4, "text three", {{"status", FilterValue{int64_t{3}}}, {"category", FilterValue{std::string("music")}}, {"score", FilterValue{60.0}}});
+    index.AddDocument(5, "text four", {});  // NULL in every column
+    auto run = [&](std::vector<FilterCondition> conds) {
+      BatchQuery q;
+      q.terms = {"text"};
+      q.order = SortOrder::ASC;
+      q.filter_conditions = std::move(conds);
+      auto r = ExecuteBatch(index, {q});
+      EXPECT(r.has_value());
+      return r ? (*r)[0].results : V{};
+    };
+    EXPECT(run({{"status", FilterOp::EQ, "1"}}) == (V{1, 3}));                                   // :778
+    EXPECT(run({{"status", FilterOp::NE, "1"}}) == (V{2, 4, 5}));                                // :792 (NULL passes NE)
+    EXPECT(run({{"category", FilterOp::EQ, "tech"}}) == (V{1, 3}));                              // :804
+    EXPECT(run({{"CATEGORY", FilterOp::EQ, "tech"}}) == (V{1, 3}));                              // :818
+    EXPECT(run({{"status", FilterOp::EQ, "1"}, {"category", FilterOp::EQ, "tech"}}) == (V{1, 3}));  // :832
+    EXPECT(run({{"status", FilterOp::EQ, "999"}}).empty());                                      // :847
+    EXPECT(run({{"status", FilterOp::EQ, "1"}, {"score", FilterOp::GT, "80.0"}}) == (V{1}));     // :893
+    EXPECT(run({{"score", FilterOp::LTE, "78"}}) == (V{3, 4}));
+    EXPECT(run({{"nosuch", FilterOp::EQ, "1"}}).empty());
+    EXPECT(run({{"nosuch", FilterOp::NE, "1"}}) == (V{1, 2, 3, 4, 5}));
+    BatchQuery all;
+    auto f = ExecuteFacet(index, all, "category");
+    EXPECT(f.has_value());
+    if (f) {
+      EXPECT(f->matched_documents == 5 && f->total_values == 3);
+      EXPECT(!f->value_counts.empty() && f->display[0] == "tech" && f->value_counts[0].second == 2);
+      EXPECT(f->value_counts[0].first == std::string("\x0B") + "tech");  // SerializeFilterValue: string tag + bytes
+    }
+    BatchQuery paged;
+    paged.limit = 1;
+    paged.offset = 1;
+    auto g = ExecuteFacet(index, paged, "status");
+    EXPECT(g.has_value() && g->total_values == 3 && g->value_counts.size() == 1 && g->value_counts[0].second == 1);
+    EXPECT(!ExecuteFacet(index, all, "nosuch").has_value());
+  }
   {  // tests/server/search_pipeline_test.cpp:1492-1512 MixedScriptBoundaryFragmentRequiresExactTextMatch, and the
      // caller-driven verify_text filter
     using namespace mygramdb::search_pipeline;

@@ -223,3 +223,41 @@ def test_normalize_text_vectors():
         assert O.normalize_text(v["text"], v["nfkc"], v["width"], v["lower"]) == v["expected"], v
     bad = doc["invalid_utf8"]
     assert O.normalize_text(bytes.fromhex(bad["hex"]), bad["nfkc"], bad["width"], bad["lower"]) == bad["expected"]
+
+
+def test_filter_oracle_against_the_reference_filter_parity_vectors():
+    """oracle/filters.py (ApplyFilters / ApplyFiltersWithBitmap / facet counts restated) against the reference's own
+    expectations: tests/server/search_pipeline_test.cpp:725-910, tests/server/facet_handler_test.cpp:203-258."""
+    import json
+    import os
+    from oracle import filters as F
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "filters.json")))
+    fx = g["fixture"]
+
+    def col(name):
+        vals = [tuple(v) if v is not None else None for v in fx[name]]
+        return lambda d: vals[d]
+    columns = {n: col(n) for n in ("status", "category", "score")}
+    for c in g["cases"]:
+        docs = c.get("docs", fx["docs"])
+        conds = [tuple(x) for x in c["conditions"]]
+        a = F.apply_filters_with_bitmap(docs, conds, columns)
+        b = F.apply_filters(docs, conds, columns)
+        assert a == b, c  # the reference asserts both paths agree on every one of these
+        if "expect" in c:
+            assert a == c["expect"], c
+    for f in g["facet"]:
+        lookup = lambda d, f=f: ("string", f["docs"][str(d)])
+        counts = F.facet_counts(f["results"], lookup)
+        shown = {k[1].decode(): v for k, v in counts.items()}
+        if "counts" in f:
+            assert shown == f["counts"], f
+        if "page" in f:
+            order = sorted(shown.items(), key=lambda kv: -kv[1])
+            assert len(order) == f["total_values"]
+            assert [list(x) for x in order[f["offset"]: f["offset"] + f["limit"]]] == f["page"]
+    # ParseFilterValue corner cases (std::from_chars: whole string, no '+', no whitespace)
+    assert F.parse_filter_value("80.0")["double"] == 80.0 and F.parse_filter_value("80.0")["int64"] is None
+    assert F.parse_filter_value("+1")["int64"] is None and F.parse_filter_value(" 1")["double"] is None
+    assert F.parse_filter_value("-5")["uint64"] is None and F.parse_filter_value("-5")["int64"] == -5
+    assert F.parse_filter_value("1e999")["double"] is None and F.parse_filter_value("18446744073709551616")["uint64"] is None
