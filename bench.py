@@ -315,7 +315,7 @@ def main():
     cxx_exchange = exchange and dist.get_backend() == "nccl"  # (gloo: the CPU rehearsal of dist.py, tests only)
     if not exchange or cxx_exchange:
         shim_table = S.Table(table.index)
-        comm = mdist.Comm() if cxx_exchange else None  # RCCL communicator behind the C ABI (mgx_comm_create)
+        comm = mdist.Comm(device=local_rank) if cxx_exchange else None  # RCCL communicator behind the C ABI (mgx_comm_create)
         ex = S.Executor(shim_table, depth=depth, planner_threads=planners, comm=comm)
         qbs = [S.QueryBatch(tb) for tb in term_batches]
         # setup (outside the clock, before the driver's own warm-up steps): every slot's arenas, pinned blocks, streams and

@@ -370,6 +370,12 @@ typedef struct mgx_comm mgx_comm;
 int mgx_comm_unique_id(uint8_t* id /* [MGX_COMM_ID_BYTES] */);
 int mgx_comm_create(const uint8_t* id, int rank, int world, int device, mgx_comm** out);
 void mgx_comm_destroy(mgx_comm* comm);
+/* ncclCommAbort: this rank leaves the communicator NOW — its enqueued collectives are cancelled instead of waited for, and
+ * every later exchange on `comm` fails with MGX_ERR_INTERNAL. What a rank must do when it cannot issue a batch's
+ * collectives (a local failure between compile and exchange): its peers have issued theirs and would otherwise wait for
+ * ever; with this rank gone their collectives fail or time out under the job's own watchdog, and the process exits
+ * non-zero. The handle stays valid for mgx_comm_destroy. */
+int mgx_comm_abort(mgx_comm* comm);
 int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
 int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
 /* mgx_batch_execute for a shard of a table (every rank calls it for the same batch, in the same order; follow it with

@@ -25,7 +25,7 @@ EXPORTS = [
     "mgx_index_add_filter_bitmap", "mgx_index_add_filter_column", "mgx_index_filter_compare", "mgx_facet_counts",
     "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",
-    "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy",
+    "mgx_batch_merge_shards", "mgx_batch_export_buffer", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_destroy", "mgx_comm_abort",
     "mgx_batch_exchange", "mgx_batch_exchange_df", "mgx_batch_execute_sharded", "mgx_batch_execute_gather", "mgx_batch_algorithmic_bytes", "mgx_batch_kernel_time_ms", "mgx_batch_destroy",
     "mgx_and", "mgx_or", "mgx_not", "mgx_threshold", "mgx_retain", "mgx_score_documents", "mgx_sort_by_score",
     "mgxt_corpus_generate", "mgxt_corpus_view", "mgxt_corpus_destroy", "mgxt_measure_read_bandwidth", "mgxt_fail_device_allocs",

@@ -3062,6 +3062,7 @@ struct Rccl {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
@@ -3087,6 +3088,7 @@ static Rccl& LoadRccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -3141,8 +3143,19 @@ void mgx_comm_destroy(mgx_comm* comm) {
   delete comm;
 }
 
+int mgx_comm_abort(mgx_comm* comm) {
+  if (!comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_comm_abort: null argument");
+  if (!comm->comm) return MGX_OK;  // (already aborted)
+  mgx::Rccl& r = mgx::LoadRccl();
+  void* c = comm->comm;
+  comm->comm = nullptr;
+  const int rc = r.CommAbort ? r.CommAbort(c) : r.CommDestroy(c);
+  return rc != 0 ? mgx::RcclFail("ncclCommAbort", rc) : MGX_OK;
+}
+
 int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
   if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange_df: null argument");
+  if (!comm->comm) return mgx::Fail(MGX_ERR_INTERNAL, "mgx_batch_exchange_df: the communicator was aborted");
   uint64_t* counts = nullptr;
   uint32_t n = 0;
   int rc = mgx_batch_df_buffer(batch, &counts, &n);
@@ -3160,6 +3173,7 @@ int mgx_batch_exchange_df(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
 
 int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
   if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange: null argument");
+  if (!comm->comm) return mgx::Fail(MGX_ERR_INTERNAL, "mgx_batch_exchange: the communicator was aborted");
   if (batch->n_queries == 0) return MGX_OK;
   if (!batch->executed) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_exchange: not executed");
   hipStream_t s = nullptr;
@@ -3243,6 +3257,7 @@ int mgx_batch_execute_gather(mgx_batch* batch, int world, mgx_gather_fn gather, 
 
 int mgx_batch_execute_sharded(mgx_batch* batch, mgx_comm* comm, void* hip_stream) {
   if (!batch || !comm) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_execute_sharded: null argument");
+  if (!comm->comm) return mgx::Fail(MGX_ERR_INTERNAL, "mgx_batch_execute_sharded: the communicator was aborted");
   return mgx_batch_execute_gather(batch, comm->world, &mgx::RcclGather, comm->comm, hip_stream);
 }
 

@@ -12,6 +12,7 @@
 //     of the doc's own windows, so tf is the greedy count over that gram's window positions.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -410,8 +411,11 @@ uint32_t Crc32(const uint8_t* d, uint64_t n) {  // zlib's crc32 (IEEE 802.3, ref
   return c ^ 0xFFFFFFFFu;
 }
 
-// Roaring portable bytes -> ascending doc ids (appended). false: malformed.
-bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out) {
+// Roaring portable bytes -> ascending doc ids (appended). false: malformed, or more ids than `budget` allows (a run
+// container is 4 bytes for up to 65536 ids: an untrusted dump of under a megabyte could otherwise expand to gigabytes
+// before any range check). *budget is decremented by what was decoded.
+bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out, uint64_t* budget, bool* over_budget) {
+  *over_budget = false;
   Reader r{data, len};
   const uint32_t cookie = r.U32();
   uint32_t n = 0;
@@ -447,13 +451,21 @@ bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out
     if (is_run) {
       const uint32_t n_runs = r.U16();
       uint32_t next_free = 0;  // runs ascend and do not touch: a container yields at most 65536 ids whatever its bytes say
+      uint32_t decoded = 0;
       for (uint32_t k = 0; k < n_runs && r.ok; ++k) {
         const uint32_t start = r.U16(), last = start + r.U16();
         if (last > 0xFFFFu || start < next_free) return false;
+        const uint32_t cnt = last - start + 1;
+        if (cnt > *budget) { *over_budget = true; return false; }
+        *budget -= cnt;
+        decoded += cnt;
         for (uint32_t v = start; v <= last; ++v) out->push_back(hi | v);
         next_free = last + 1;
       }
+      if (r.ok && decoded != cards[i]) return false;  // the header's cardinality must be what the runs hold
     } else if (cards[i] <= 4096) {
+      if (cards[i] > *budget) { *over_budget = true; return false; }
+      *budget -= cards[i];
       uint32_t prev = 0;
       for (uint32_t k = 0; k < cards[i] && r.ok; ++k) {
         const uint32_t v = r.U16();
@@ -463,6 +475,15 @@ bool DecodeRoaring(const uint8_t* data, uint64_t len, std::vector<uint32_t>* out
       }
     } else {
       if (!r.Need(8192)) return false;
+      uint32_t pop = 0;
+      for (uint32_t w = 0; w < 1024; ++w) {
+        uint64_t bits = 0;
+        for (int b = 0; b < 8; ++b) bits |= static_cast<uint64_t>(data[r.at + w * 8 + b]) << (8 * b);
+        pop += static_cast<uint32_t>(__builtin_popcountll(bits));
+      }
+      if (pop != cards[i]) return false;  // (the stated cardinality is checked, not trusted)
+      if (pop > *budget) { *over_budget = true; return false; }
+      *budget -= pop;
       for (uint32_t w = 0; w < 1024; ++w) {
         uint64_t bits = 0;
         for (int b = 0; b < 8; ++b) bits |= static_cast<uint64_t>(data[r.at + w * 8 + b]) << (8 * b);
@@ -529,6 +550,11 @@ int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, ui
   std::vector<Term> terms;
   terms.reserve(n_terms);
   uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  // Decoded-size caps of an untrusted dump: a posting list holds distinct doc ids, so at most n_docs of them when the
+  // caller gave the range (2^32 otherwise); all lists together at most MGX_MGIX_MAX_POSTINGS (default 2^33 ids = 32 GiB
+  // of host memory — a table beyond that is loaded shard by shard).
+  static const uint64_t kTotalCap = std::getenv("MGX_MGIX_MAX_POSTINGS") ? static_cast<uint64_t>(atoll(std::getenv("MGX_MGIX_MAX_POSTINGS"))) : (1ull << 33);
+  uint64_t total_budget = kTotalCap;
   for (uint64_t t = 0; t < n_terms; ++t) {
     const uint32_t tl = r.U32();
     if (!r.Need(tl)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated term");
@@ -544,6 +570,8 @@ int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, ui
     const uint32_t size = pr.U32();
     if (strategy == 0) {
       if (size > (pr.n - pr.at) / 4) return fail(MGX_ERR_INVALID_ARGUMENT, "delta list longer than its bytes");
+      if (size > total_budget) return fail(MGX_ERR_INVALID_ARGUMENT, "the dump decodes to more doc ids than MGX_MGIX_MAX_POSTINGS allows");
+      total_budget -= size;
       term.docs.reserve(size);
       uint32_t prev = 0;
       for (uint32_t i = 0; i < size; ++i) {  // PostingList::DecodeDelta, posting_list.cpp:954-971
@@ -554,7 +582,16 @@ int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, ui
       }
     } else if (strategy == 1) {
       if (size > pr.n - pr.at) return fail(MGX_ERR_INVALID_ARGUMENT, "roaring bitmap longer than its bytes");
-      if (!DecodeRoaring(pr.p + pr.at, size, &term.docs)) return fail(MGX_ERR_INVALID_ARGUMENT, "malformed roaring bitmap");
+      uint64_t budget = std::min<uint64_t>(n_docs ? n_docs : (1ull << 32), total_budget);
+      const uint64_t before = budget;
+      bool over = false;
+      if (!DecodeRoaring(pr.p + pr.at, size, &term.docs, &budget, &over)) {
+        if (over && n_docs && before == n_docs)  // more distinct ids in one list than the range has slots
+          return fail(MGX_ERR_OUT_OF_RANGE, "a doc id lies outside the given range");
+        return fail(MGX_ERR_INVALID_ARGUMENT, over ? "the dump decodes to more doc ids than MGX_MGIX_MAX_POSTINGS allows"
+                                                   : "malformed roaring bitmap");
+      }
+      total_budget -= before - budget;
     } else {
       return fail(MGX_ERR_INVALID_ARGUMENT, "unknown posting strategy");
     }

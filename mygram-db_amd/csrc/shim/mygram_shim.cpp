@@ -1457,6 +1457,13 @@ struct BatchExecutor::Impl {
   std::deque<Chunk> chunks;
   bool stop = false;
   bool enqueuing = false;  // a dispatcher is inside EnqueueReady's loop (guarded by mu)
+  // Sharded tables: every rank issues the same collectives in the same order. A rank that cannot (a ticket that failed to
+  // plan or compile here, an exchange call that returned an error) has left that lock-step: its peers have enqueued this
+  // ticket's all-gather and would pair it with the NEXT ticket's. The communicator is then poisoned: aborted
+  // (mgx_comm_abort: this rank's enqueued collectives are cancelled, the peers' fail or time out instead of pairing
+  // wrongly), and every later ticket fails at once with the first error — the process is expected to exit non-zero.
+  bool comm_poisoned = false;  // guarded by mu
+  std::string poison_message;
 
   Impl(const index::Index& ix, Options o) : index(ix), opt(o) {}
 
@@ -1504,6 +1511,14 @@ struct BatchExecutor::Impl {
     for (;;) {
       Slot* slot = ByTicket(next_enqueue);
       if (!slot || (slot->state != kCompiled && slot->state != kFailed)) break;
+      if (opt.comm && comm_poisoned && slot->state == kCompiled) {
+        slot->error = MakeError(ErrorCode::kInternalError, "the table's communicator was aborted after an earlier failure: " + poison_message);
+        slot->state = kFailed;
+      } else if (opt.comm && slot->state == kFailed && !comm_poisoned) {
+        comm_poisoned = true;  // (this ticket never reached its collectives on this rank)
+        poison_message = slot->error.message();
+        (void)mgx_comm_abort(opt.comm);
+      }
       if (slot->state == kCompiled && !slot->mq.empty()) {
         lock.unlock();
         const auto t0 = clock::now();
@@ -1517,6 +1532,11 @@ struct BatchExecutor::Impl {
         if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
         slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
         lock.lock();
+        if (rc != MGX_OK && comm && !comm_poisoned) {
+          comm_poisoned = true;
+          poison_message = slot->error.message();
+          (void)mgx_comm_abort(comm);
+        }
       }
       slot->state = slot->error.code() == ErrorCode::kSuccess && slot->state == kCompiled ? kEnqueued : kFailed;
       ++next_enqueue;

@@ -103,6 +103,7 @@ class ShardedTable:
                  dense_threshold=0.0, n_threads=0):
         self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.device = device
         self.index = engine.Index(corpus=corpus, first_doc_id=first_doc_id, ngram_size=ngram_size,
                                   kanji_ngram_size=kanji_ngram_size, cross_boundary=cross_boundary, device=device,
                                   dense_threshold=dense_threshold, n_threads=n_threads)
@@ -167,7 +168,7 @@ class ShardedTable:
         if exchange and dist.get_backend() == "nccl":
             # the production path: both collectives are RCCL calls inside the library (mgx_batch_exchange[_df])
             if getattr(self, "comm", None) is None:
-                self.comm = Comm()
+                self.comm = Comm(device=self.device)  # (the table's device, not whatever torch's current one is)
             if batch.n:
                 batch.exchange_df(self.comm, stream)
             batch.execute_sharded(self.comm, stream)

@@ -140,6 +140,24 @@ def main():
             assert g.total == total, (q.terms, g.total, total)
             assert g.docs.tolist() == docs.tolist(), q.terms
             assert np.array_equal(g.scores, scores), q.terms
+        # The df cache must not change what a rank contributes to the df all-reduce: rank 0 ALONE first runs a text-level
+        # term through a plain (unsharded) execute of its shard — its index now knows the term's LOCAL count — then both
+        # ranks run the sharded batch, rank 1 counting for the first time. (The round-2 cache stored whatever count came
+        # back — here rank 0's local one under the table-wide key — and a warm rank contributed 0 to the reduction.)
+        cold_terms = [str(w) for w in words[-3:]]
+        if rank == 0:
+            lone = table.index.prepare([mg.engine.Query([cold_terms[0], cold_terms[1]], sort_score=True, limit=5)])
+            lone.execute()
+            lone.fetch()
+        dist.barrier()
+        cq = [mg.engine.Query([cold_terms[0], cold_terms[1]], sort_score=True, limit=10),
+              mg.engine.Query([cold_terms[1], cold_terms[2], common[0]], sort_score=True, limit=10)]
+        for _ in range(2):  # (second round: both ranks warm)
+            cb = table.prepare(cq)
+            table.run(cb)
+            for q, g in zip(cq, cb.fetch()):
+                total, docs, scores = O.search_scored(oidx, ostore, q.terms, n, avg, limit=q.limit)
+                assert g.total == total and g.docs.tolist() == docs.tolist() and np.array_equal(g.scores, scores), q.terms
         # fresh batches of different shapes, each dropped before the next is prepared (a serving loop): the exchange
         # buffers belong to the batch, so a recycled Python id / device address must never leak a stale blob or layout
         for rnd in range(6):

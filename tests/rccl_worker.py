@@ -67,6 +67,37 @@ def main():
             total, d, s = O.search_scored(oidx, ostore, terms, n, avg, limit=10)
             assert totals[qi] == total and docs[qi, :n_docs[qi]].tolist() == d.tolist(), terms
             assert np.array_equal(scores[qi, :n_docs[qi]], s), terms
+    # (3) df cache and the all-reduce: a text-level term's df was cached by the batches above (the index keeps this shard's
+    # LOCAL count); a later sharded batch must still contribute that count to the reduction — with the round-2 cache (the
+    # reduced value stored, zero contributed) a warm rank would have scored with df 0
+    warm = [mg.engine.Query(["the", "an"], sort_score=True, limit=10)]
+    for _ in range(2):
+        bw = table.prepare(warm)
+        table.run(bw)
+        g = bw.fetch()[0]
+        total, d, s = O.search_scored(oidx, ostore, warm[0].terms, n, avg, limit=10)
+        assert g.total == total and g.docs.tolist() == d.tolist() and np.array_equal(g.scores, s)
+    # (4) a rank-local failure between compile and exchange poisons the communicator: that ticket fails, and every later
+    # ticket fails at once instead of pairing its collectives with another batch's on the peers
+    lib = mg._capi.load()
+    ex2 = S.Executor(S.Table(table.index), depth=2, planner_threads=2, comm=mdist.Comm())
+    t_ok = ex2.submit(qb, limit=10)
+    ex2.wait(t_ok)
+    lib.mgxt_fail_device_allocs(0, 1000)  # every device allocation of the next batch fails
+    t_bad = ex2.submit(S.QueryBatch([t + ["zq"] for t in term_lists[:8]] + term_lists), limit=100)
+    failed = False
+    try:
+        ex2.wait(t_bad)
+    except S.ShimError:
+        failed = True
+    lib.mgxt_fail_device_allocs(0, 0)
+    assert failed, "the injected allocation failure must surface as an error"
+    t_after = ex2.submit(qb, limit=10)
+    try:
+        ex2.wait(t_after)
+        raise AssertionError("a ticket after the failure must not run on an aborted communicator")
+    except S.ShimError as e:
+        assert "aborted" in str(e), str(e)
     dist.destroy_process_group()
     print("ok")
 
