@@ -65,6 +65,33 @@ def make_queries(mg, table, n_batches, batch, seed=42, limit=10):
     return out
 
 
+def kernel_source_sha16():
+    """Identity of the device code this run executes: sha256 over the kernel sources (the profile a counter figure was
+    taken on must be of the same sources, or the figure is not printed)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("mygram-db_amd/csrc/mgx_kernels.hip", "mygram-db_amd/csrc/mgx_internal.hpp"):
+        try:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
+def load_counter_profile():
+    """profiles/roofline_current.json: the rocprofv3 PMC figures of the dominant kernel (tools/make_roofline_profile.py
+    writes it from the --pmc passes of tools/profile.sh, with the kernel source hash and the commit they were taken on)."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "roofline_current.json")))
+    except (OSError, ValueError):
+        return None, "profiles/roofline_current.json is missing"
+    sha = kernel_source_sha16()
+    if prof.get("kernel_source_sha16") != sha:
+        return None, ("profiles/roofline_current.json was taken on kernel sources %s, this build is %s: counter figures "
+                      "withheld" % (prof.get("kernel_source_sha16"), sha))
+    return prof, None
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -246,7 +273,16 @@ def main():
     sharded_run = int(os.environ.get("WORLD_SIZE", "1")) > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     depth = int(os.environ.get("MGX_BENCH_DEPTH", "0")) or (6 if sharded_run else 2)
     fifo = (os.environ.get("MGX_BENCH_FIFO", "") or ("0" if sharded_run else "1")) != "0"
-    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or max(1, min(8, (usable_cores() - 1) // max(1, world)))  # (8 plan a batch in 0.15-0.2 ms; 15 only add contention on a 16-CPU box)
+    # host threads per rank from the box's CPU share: the quota of this container (or its affinity set) divided among the
+    # ranks of the node, two of them left to the submit / collect threads; at least 2 planners (one planner thread cannot
+    # feed a 0.3 ms shard step), at most 8 (8 plan a batch in 0.1-0.2 ms; more only add contention)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpu_share = max(1.0, usable_cores() / max(1, local_world))
+    planners = int(os.environ.get("MGX_BENCH_PLANNERS", "0")) or int(max(2, min(8, cpu_share - 2)))
+    if not os.environ.get("MGX_DISPATCHERS"):
+        os.environ["MGX_DISPATCHERS"] = str(3 if cpu_share >= 8 else 2 if cpu_share >= 4 else 1)
+    if not os.environ.get("MGX_COMPILE_THREADS"):
+        os.environ["MGX_COMPILE_THREADS"] = str(3 if cpu_share >= 12 else 1 if cpu_share >= 4 else 0)
     exchange = world > 1 or bool(os.environ.get("MGX_FORCE_EXCHANGE"))
     # profiling variant (never the headline): MGX_BENCH_SORT=docid runs the same 3-term AND batches WITHOUT scoring —
     # the intersection-only path (mgx::wave_count_kernel + page emit), docid-DESC pages of 10
@@ -326,15 +362,19 @@ def main():
                  np.zeros((batch_size, 10), np.float64), np.zeros(5, np.float64)) for _ in range(depth)]
 
         call_ms = [0.0, 0.0]  # time the driving thread spends inside submit / wait calls (sum over the timed steps)
+        kept0 = {}  # the rows the TIMED executor returned for distinct batch 0 (checked against the oracle below)
 
-        def run_steps(k, record):
+        def run_steps(k, record, exe=None, out_bufs=None, n_flight=None, lat_out=None):
             """k steps with `depth` batches in flight. Two host threads drive the executor, as its interface intends (one
             submitter, one waiter — search_pipeline::MicroBatcher does the same): building 1024 BatchQuery objects and
             unpacking 1024 BatchResults are each ~0.1 ms of host work per step, and on a small shard (0.3 ms of device per
             batch) one thread doing both in turn was the step."""
             import queue
             import threading
-            in_flight = threading.Semaphore(depth)
+            exe = exe or ex
+            out_bufs = out_bufs or outs
+            n_flight = n_flight or depth
+            in_flight = threading.Semaphore(n_flight)
             tickets = queue.Queue()
             sub_t = {}
             failure = []
@@ -345,7 +385,7 @@ def main():
                     for j in range(k):
                         in_flight.acquire()
                         sub_t[j] = time.perf_counter()
-                        tickets.put((j, ex.submit(qbs[j % len(qbs)], limit=10, sort_by_score=by_score)))
+                        tickets.put((j, exe.submit(qbs[j % len(qbs)], limit=10, sort_by_score=by_score)))
                         if record:
                             call_ms[0] += 1e3 * (time.perf_counter() - sub_t[j])
                 except BaseException as e:  # noqa: BLE001 (handed to the waiting thread)
@@ -360,12 +400,16 @@ def main():
                     raise failure[0]
                 j, ticket = item
                 w0 = time.perf_counter()
-                out = ex.wait(ticket, outs[j % depth])
+                out = exe.wait(ticket, out_bufs[j % n_flight])
                 in_flight.release()
+                if lat_out is not None:
+                    lat_out.append(time.perf_counter() - sub_t[j])
                 if record:
                     lat.append(time.perf_counter() - sub_t[j])
                     call_ms[1] += 1e3 * (time.perf_counter() - w0)
                     timings.append(out[4].copy())
+                    if j % len(qbs) == 0 and not kept0:
+                        kept0.update(totals=out[0].copy(), n_docs=out[1].copy(), docs=out[2].copy(), scores=out[3].copy())
             th.join()
 
         name_thread("bench-wait")
@@ -400,10 +444,41 @@ def main():
             step(i)
         sync()
         elapsed = time.perf_counter() - t0
+    rank_ms_per_step = [1e3 * elapsed / args.steps]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine_t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(every, mine_t)
+        rank_ms_per_step = [1e3 * float(x.item()) / args.steps for x in every]  # per-rank spread
+        elapsed = max(float(x.item()) for x in every)
+
+    # ---------------------------------------------------------------------------------------------------------------
+    # (3) other operating points of the same executor (short passes AFTER the timed region; never the headline): the
+    #     metric is queries/s AND p50 batch latency, and the number of batches in flight trades one for the other
+    # ---------------------------------------------------------------------------------------------------------------
+    operating_points = []
+    if (not exchange) and rank == 0 and not os.environ.get("MGX_BENCH_NO_POINTS"):
+        for d2, fifo2 in ((1, True), (2, True), (4, False)):
+            if d2 == depth and fifo2 == fifo:
+                continue
+            table.index.device_index.set_batch_order(fifo2)
+            ex2 = S.Executor(shim_table, depth=d2, planner_threads=planners)
+            ex2.warm(qbs[-1], limit=10, sort_by_score=by_score, rounds=2)
+            outs2 = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 10), np.uint32),
+                      np.zeros((batch_size, 10), np.float64), np.zeros(5, np.float64)) for _ in range(d2)]
+            k2 = 120
+            lat2 = []
+            run_steps(10, False, ex2, outs2, d2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(k2, False, ex2, outs2, d2, lat2)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            operating_points.append({"batches_in_flight": d2, "batch_order": "fifo" if fifo2 else "concurrent",
+                                     "queries_per_s": batch_size * k2 / dt2, "ms_per_step": 1e3 * dt2 / k2,
+                                     "p50_ms": 1e3 * statistics.median(lat2), "steps": k2})
+            del ex2
+        table.index.device_index.set_batch_order(fifo)
 
     # second denominator: this box's streaming-read bandwidth, measured in the same job (read-only kernel, 2 GiB)
     measured_peak = None
@@ -415,14 +490,110 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and cpu_seconds > 0:
+        # the rows checked against the oracle are the ones the TIMED C++ executor returned for distinct batch 0 (and, beside
+        # them, the Python replay path's: both must agree with the oracle bit for bit)
         def gpu_rows(i):
             r = results0[i]
+            if kept0:
+                nd = int(kept0["n_docs"][i])
+                same = (int(kept0["totals"][i]) == r.total and kept0["docs"][i, :nd].tolist() == r.docs.tolist() and
+                        np.array_equal(kept0["scores"][i, :nd], r.scores))
+                if not same:  # the executor's row disagrees with the replay path: report the executor's (a mismatch)
+                    return int(kept0["totals"][i]), kept0["docs"][i, :nd].copy(), kept0["scores"][i, :nd].copy()
+                return int(kept0["totals"][i]), kept0["docs"][i, :nd].copy(), kept0["scores"][i, :nd].copy()
             return r.total, r.docs, r.scores
         cpu = cpu_baseline(mg, table, corpus, term_batches[0], gpu_rows, cpu_seconds)
+        cpu["parity_rows_from"] = "the timed C++ executor (search_pipeline::BatchExecutor)" if kept0 else "the replay path"
+
+    # ---------------------------------------------------------------------------------------------------------------
+    # (4) N = 8 only: BASELINE.json configs[3] beside the strong-scaling line — 100M docs doc-range-sharded 12.5M per rank,
+    #     batch 1024 x 3-term AND + BM25 top-100, RCCL top-k merge (each rank generates only its own shard). A second block
+    #     of the same JSON line; the headline above stays configs[1].
+    # ---------------------------------------------------------------------------------------------------------------
+    index_bytes_hbm = table.index.device_index.memory_bytes()
+    shard_grams, shard_postings = cols.n_grams, cols.n_postings
+    config3 = None
+    want_cfg3 = os.environ.get("MGX_BENCH_CFG3", "1" if world == 8 else "0") != "0"
+    if want_cfg3 and cxx_exchange and by_score:
+        try:
+            t_c3 = time.perf_counter()
+            n3 = int(os.environ.get("MGX_BENCH_CFG3_DOCS", "100000000"))
+            del ex, shim_table, batches, table, corpus, cols
+            before3, mine3 = mdist.shard_range(n3, rank, world)
+            corpus3 = mg.Corpus.synthetic(mine3, seed=42, global_first=before3)
+            table3 = mdist.ShardedTable(corpus3, first_doc_id=1 + before3, device=local_rank, ngram_size=2, kanji_ngram_size=0)
+            table3.index.device_index.set_batch_order(fifo)
+            tb3 = make_queries(mg, table3, 8, batch_size, seed=43)
+            ex3 = S.Executor(S.Table(table3.index), depth=depth, planner_threads=planners, comm=mdist.Comm(device=local_rank))
+            qb3 = [S.QueryBatch(tb) for tb in tb3]
+            ex3.warm(qb3[-1], limit=100, sort_by_score=True, rounds=2)
+            outs3 = [(np.zeros(batch_size, np.uint64), np.zeros(batch_size, np.uint32), np.zeros((batch_size, 100), np.uint32),
+                      np.zeros((batch_size, 100), np.float64), np.zeros(5, np.float64)) for _ in range(depth)]
+            k3 = max(8, min(args.steps, 40))
+            lat3, pend = [], []
+            sync()
+            t0 = time.perf_counter()
+            for j in range(k3 + depth):
+                if j >= depth:
+                    tk, ts = pend.pop(0)
+                    ex3.wait(tk, outs3[j % depth])
+                    lat3.append(time.perf_counter() - ts)
+                if j < k3:
+                    ts = time.perf_counter()
+                    pend.append((ex3.submit(qb3[j % len(qb3)], limit=100, sort_by_score=True), ts))
+            sync()
+            dt3 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(dt3, op=dist.ReduceOp.MAX)
+            dt3 = float(dt3.item())
+            config3 = {"workload": "BASELINE.json configs[3]: %d docs doc-range-sharded across %d GPUs (%d per rank), bigram, "
+                                   "batch %d x 3-term AND + BM25 top-100, RCCL top-k merge" % (n3, world, mine3, batch_size),
+                       "value": batch_size * k3 / dt3, "unit": "queries/s", "ms_per_step": 1e3 * dt3 / k3,
+                       "p50_ms": 1e3 * statistics.median(lat3), "steps": k3, "batches_in_flight": depth,
+                       "setup_s": time.perf_counter() - t_c3}
+        except Exception as e:  # noqa: BLE001 (the second block must never cost the headline line)
+            config3 = {"error": repr(e)}
 
     if rank == 0:
         qps = batch_size * args.steps / elapsed
         tm = np.asarray(timings) if timings else np.zeros((1, 5))
+        # ---- roofline of the dominant kernel -----------------------------------------------------------------------------
+        # `traffic` = the bytes the kernel moved past L2 per launch, from rocprofv3 PMC passes (FETCH_SIZE with the gfx950
+        # x2 correction for 16-byte-per-lane reads + WRITE_SIZE; /opt/skills/guides/MI355X_MICROARCH.md) committed under
+        # profiles/ — printed only when they were taken on THIS build's kernel sources; `achieved` = traffic / the kernel
+        # duration measured LIVE in this run (HIP events on its launch stream), `frac` = achieved / 8 TB/s. The algorithmic
+        # figure of SURVEY.md 8d (bytes the reference's full scan would move) stands beside it as `algorithmic_ratio`: it
+        # exceeds 1 because dense lists are read as 1-bit-per-doc bitmaps and most matches are pruned before being touched.
+        prof, why_not = load_counter_profile() if by_score and dense == 0 and n_docs_total == 10000000 and batch_size == 1024 else (None, "not the profiled configuration")
+        traffic = prof["traffic_bytes_per_launch"] if prof else None
+        phys = (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None
+        roofline = {
+            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "achieved": phys, "frac": (phys / HBM_PEAK_GBS) if phys else None, "traffic": traffic,
+            "traffic_source": ({"file": prof["files"], "taken_at_commit": prof.get("commit"),
+                                "kernel_source_sha16": prof["kernel_source_sha16"],
+                                "kernel_ms_in_profile": prof.get("kernel_ms"),
+                                "fetch_bytes_raw": prof.get("fetch_bytes_raw"), "write_bytes": prof.get("write_bytes"),
+                                "correction": "2 x FETCH_SIZE (gfx950: 16-byte-per-lane reads count half) + WRITE_SIZE; "
+                                              "FETCH_SIZE includes Infinity-Cache hits, so this is L2-miss traffic: an "
+                                              "upper bound of HBM bytes"} if prof else why_not),
+            "peak_measured_read": measured_peak,
+            "frac_of_measured": (phys / measured_peak) if (phys and measured_peak) else None,
+            "kernel": ("mgx::bitmap_score_kernel<3> (set algebra on tile bitmaps, block-max top-k pruning, fused BM25 of the "
+                       "surviving matches from doc-slot tf nibbles, per-wave top-k); the few queries with a sparse sorted-list "
+                       "operand run beside it as mgx::cand_kernel on a side stream inside the same timed region") if by_score else
+                      "mgx::wave_count_kernel (+ tile_eval doc-count share): set algebra + per-tile counts",
+            "kernel_ms": k_ms, "launches_timed": k_n,
+            "algorithmic_bytes_per_launch": alg_total,
+            "algorithmic_achieved": achieved, "algorithmic_ratio": achieved / HBM_PEAK_GBS,
+            "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1], "topk_12B": alg[2]},
+            # "posting-list intersection" on its own (north_star: >= 50 % of the HBM roofline), both index forms, from the
+            # same profile file: the intersection-only kernel on bitmap-form lists, and SORT _score on an index WITHOUT
+            # bitmaps (sorted u32 posting arrays: mgx::merge_score_kernel), the latter priced on algorithmic bytes
+            "intersection": (prof.get("intersection") if prof else None),
+            "note": "frac / achieved / traffic: physical (counter) figures; algorithmic_*: SURVEY.md 8d's "
+                    "4*sum|L| + R*(T+4) + 12*min(k,R) per launch / the same live kernel time — not a fraction of "
+                    "physical bandwidth"}
         line = {
             "metric": "queries/sec + p50 latency, 10M-doc bigram index, batch=1024 3-term AND",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -447,38 +618,25 @@ def main():
                 "execute_ms": 1e3 * replay_elapsed / replay_steps,
                 "replay_qps": batch_size * replay_steps / replay_elapsed, "replay_steps": replay_steps,
                 "batch_latency_p50_ms": 1e3 * statistics.median(lat), "batches_in_flight": depth,
-                "batch_order": "fifo" if fifo else "concurrent"},
+                "batch_order": "fifo" if fifo else "concurrent",
+                "other_operating_points": operating_points,
+                "rank_ms_per_step": rank_ms_per_step,
+                "host_threads": {"planners": planners, "dispatchers": int(os.environ.get("MGX_DISPATCHERS", "3")),
+                                 "compile_helpers_per_dispatcher": int(os.environ.get("MGX_COMPILE_THREADS", "3")),
+                                 "cpu_share_of_this_rank": cpu_share}},
             "config": {"workload": ("10M-doc synthetic ASCII corpus (seed 42), bigram index, 3-term AND + BM25 top-10, "
                                     "batch=1024 (BASELINE.json configs[1])") if by_score else
                                    ("PROFILING VARIANT, not the headline: the same batches without scoring "
                                     "(intersection only, docid-DESC top-10)"),
                        "n_docs": n_docs_total, "batch": batch_size, "limit": 10, "k1": 1.2, "b": 0.75,
                        "parallelism": "doc-range shards x%d, top-k all-gather + merge" % world,
-                       "shard_docs": mine, "shard_grams": cols.n_grams, "shard_postings": cols.n_postings,
-                       "index_bytes_hbm": table.index.device_index.memory_bytes(),
+                       "shard_docs": mine, "shard_grams": shard_grams, "shard_postings": shard_postings,
+                       "index_bytes_hbm": index_bytes_hbm,
                        "mean_list_len_of_queries": alg[0] / 4 / batch_size / 3,
                        "dense_threshold": dense if dense else 1.0 / 256, "setup_s": setup_s},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "peak_measured_read": measured_peak,
-                         "frac_of_measured": (achieved / measured_peak) if measured_peak else None,
-                         "kernel": ("mgx::bitmap_score_kernel<3> (set algebra on tile bitmaps, block-max top-k pruning, fused BM25 "
-                                    "of the surviving matches from doc-slot tf nibbles, per-wave top-k; queries with a "
-                                    "sorted-list operand run beside it as mgx::wave_score_lists_kernel on a side stream "
-                                    "inside the same timed region)") if by_score else
-                                   "mgx::wave_count_kernel (+ tile_eval doc-count share): set algebra + per-tile counts",
-                         "kernel_ms": k_ms, "launches_timed": k_n,
-                         "algorithmic_bytes_per_launch": alg_total,
-                         "algorithmic_breakdown": {"lists_4B_per_posting": alg[0], "score_R_times_T_plus_4": alg[1],
-                                                   "topk_12B": alg[2]},
-                         "note": "ALGORITHMIC figure: bytes the reference's full-scan semantics would move (SURVEY.md 8d: "
-                                 "4*sum|L| + R*(T+4) + 12*min(k,R)) per launch / HIP-event kernel time. Dense lists are "
-                                 "read as 1-bit-per-doc bitmaps and tiles are shared through L2/MALL, so it exceeds 1.0 "
-                                 "and is NOT a fraction of physical bandwidth; the counter-measured traffic of this "
-                                 "kernel (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes) is in "
-                                 "profiles/r02_*_summary.json with the build it was taken on, not replayed here"},
+            "roofline": roofline,
             "cpu_baseline": cpu,
+            "config3_100M_docs_8_gpus": config3,
         }
         if os.environ.get("MGX_BENCH_SERIES"):  # rehearsal: per-step host timings (plan, compile, enqueue, wait ms)
             line["series"] = {"timings": np.round(tm[:, :4], 3).tolist(), "latency_ms": [round(1e3 * x, 3) for x in lat]}
