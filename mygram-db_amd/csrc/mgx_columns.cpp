@@ -131,6 +131,190 @@ struct Columns {
   uint64_t n_docs = 0, bm25_doc_count = 0, bm25_total_len = 0;
 };
 
+// The build for LARGE dictionaries: no per-gram state while the docs are read. Every (gram key, doc, tf) posting becomes a
+// 24-byte record; chunks of docs are turned into records in parallel and each chunk sorts its own by key; the key space
+// is cut at splitters (quantiles of the first chunk's keys) into ranges, and every range is assembled on its own — the
+// chunks' pieces concatenated in doc order, stably sorted by key — so gram ids (ranks of the keys), posting offsets and
+// the posting arrays of a range are written without looking at any other. Memory: ~2 x 24 B per posting at the peak.
+static int BuildColumnsSorted(const mgx_build_params& bp, const uint8_t* text_bytes, const uint64_t* text_off,
+                              uint32_t first_doc_id, uint64_t n_docs, unsigned n_threads, Columns** out, std::string* err) {
+  const int ascii_n = bp.ngram_size;
+  const int kanji_n = bp.kanji_ngram_size > 0 ? bp.kanji_ngram_size : bp.ngram_size;
+  const bool cross = bp.cross_boundary_ngrams != 0;
+  struct Rec {
+    Key key;
+    uint32_t doc;
+    uint32_t tf;
+  };
+  auto cols = std::make_unique<Columns>();
+  cols->params = bp;
+  cols->first_doc_id = first_doc_id;
+  cols->n_docs = n_docs;
+  cols->doc_len.assign(n_docs, 0);
+  const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>((n_docs + 16383) / 16384, n_threads * 16ull));
+  const uint64_t chunk_docs = (n_docs + n_chunks - 1) / n_chunks;
+  std::vector<std::vector<Rec>> runs(n_chunks);
+  std::vector<uint64_t> chunk_count(n_chunks, 0), chunk_total(n_chunks, 0);
+  std::atomic<uint64_t> next{0};
+  std::atomic<int> failed{0};
+  auto parallel = [&](uint64_t n_jobs, auto&& fn) {
+    next = 0;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < n_threads; ++t)
+      th.emplace_back([&]() {
+        DocScratch s;
+        for (;;) {
+          const uint64_t c = next.fetch_add(1);
+          if (c >= n_jobs || failed.load()) break;
+          fn(c, s);
+        }
+      });
+    for (auto& t : th) t.join();
+  };
+  // ---- A: records of every chunk, sorted by key (docs ascend inside equal keys: the sort is stable) -------------------
+  parallel(n_chunks, [&](uint64_t c, DocScratch& s) {
+    std::vector<Rec>& run = runs[c];
+    const uint64_t d0 = c * chunk_docs, d1 = std::min(n_docs, d0 + chunk_docs);
+    std::vector<std::pair<Key, uint32_t>> wins;
+    for (uint64_t d = d0; d < d1; ++d) {
+      const uint8_t* t = text_bytes + text_off[d];
+      const size_t len = static_cast<size_t>(text_off[d + 1] - text_off[d]);
+      uint32_t dl = 0;
+      if (!DocWindows(t, len, ascii_n, kanji_n, cross, s, &dl)) {
+        failed = 1;
+        return;
+      }
+      cols->doc_len[d] = dl;
+      if (len > 0) {
+        chunk_count[c]++;
+        chunk_total[c] += dl;
+      }
+      wins.clear();
+      for (size_t p = 0; p < s.keys.size(); ++p)
+        if (s.keys[p]) wins.emplace_back(s.keys[p], static_cast<uint32_t>(p));
+      std::sort(wins.begin(), wins.end());
+      for (size_t i = 0; i < wins.size();) {
+        // greedy non-overlapping count over this gram's window positions (bm25_scorer.cpp:34-43)
+        uint32_t tf = 0;
+        uint64_t next_ok = 0;
+        size_t j = i;
+        for (; j < wins.size() && wins[j].first == wins[i].first; ++j)
+          if (wins[j].second >= next_ok) {
+            ++tf;
+            next_ok = static_cast<uint64_t>(wins[j].second) + s.wsize[wins[j].second];
+          }
+        run.push_back(Rec{wins[i].first, first_doc_id + static_cast<uint32_t>(d), tf});
+        i = j;
+      }
+    }
+    std::stable_sort(run.begin(), run.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+  });
+  if (failed.load()) {
+    *err = "an n-gram longer than 15 UTF-8 bytes is not supported by the column builder";
+    return MGX_ERR_NOT_IMPLEMENTED;
+  }
+  for (uint64_t c = 0; c < n_chunks; ++c) {
+    cols->bm25_doc_count += chunk_count[c];
+    cols->bm25_total_len += chunk_total[c];
+  }
+  // ---- B: key ranges from the quantiles of a sample of every chunk's keys -----------------------------------------------
+  const uint64_t n_ranges = std::max<uint64_t>(1, n_threads * 16ull);
+  std::vector<Key> sample;
+  for (const auto& run : runs)
+    for (size_t i = 0; i < run.size(); i += 1024) sample.push_back(run[i].key);
+  std::sort(sample.begin(), sample.end());
+  std::vector<Key> split;  // range r = keys in [split[r-1], split[r])
+  for (uint64_t r = 1; r < n_ranges && !sample.empty(); ++r) {
+    const Key k = sample[sample.size() * r / n_ranges];
+    if (split.empty() || k > split.back()) split.push_back(k);
+  }
+  const uint64_t R = split.size() + 1;
+  // where every chunk's run crosses the splitters
+  std::vector<std::vector<size_t>> cut(n_chunks, std::vector<size_t>(R + 1, 0));
+  parallel(n_chunks, [&](uint64_t c, DocScratch&) {
+    const auto& run = runs[c];
+    for (uint64_t r = 1; r < R; ++r)
+      cut[c][r] = static_cast<size_t>(std::lower_bound(run.begin(), run.end(), split[r - 1],
+                                                        [](const Rec& a, const Key& k) { return a.key < k; }) - run.begin());
+    cut[c][R] = run.size();
+  });
+  // ---- C: every range on its own: gather in chunk (= doc) order, stable sort by key, count keys and postings -------------
+  std::vector<std::vector<Rec>> ranges(R);
+  std::vector<uint64_t> range_keys(R, 0);
+  parallel(R, [&](uint64_t r, DocScratch&) {
+    std::vector<Rec>& v = ranges[r];
+    size_t total = 0;
+    for (uint64_t c = 0; c < n_chunks; ++c) total += cut[c][r + 1] - cut[c][r];
+    v.reserve(total);
+    for (uint64_t c = 0; c < n_chunks; ++c) v.insert(v.end(), runs[c].begin() + cut[c][r], runs[c].begin() + cut[c][r + 1]);
+    std::stable_sort(v.begin(), v.end(), [](const Rec& a, const Rec& b) { return a.key < b.key; });
+    uint64_t nk = 0;
+    for (size_t i = 0; i < v.size(); ++i) nk += (i == 0 || v[i].key != v[i - 1].key) ? 1 : 0;
+    range_keys[r] = nk;
+  });
+  std::vector<std::vector<Rec>>().swap(runs);
+  std::vector<uint64_t> gbase(R + 1, 0), pbase(R + 1, 0);
+  for (uint64_t r = 0; r < R; ++r) {
+    gbase[r + 1] = gbase[r] + range_keys[r];
+    pbase[r + 1] = pbase[r] + ranges[r].size();
+  }
+  const uint64_t G = gbase[R], P = pbase[R];
+  if (G > 0xFFFFFFF0ull) {
+    *err = "more than 2^32 distinct n-grams";
+    return MGX_ERR_OUT_OF_RANGE;
+  }
+  cols->sorted_keys.resize(G);
+  cols->offsets.assign(G + 1, 0);
+  cols->docids.assign(P + 4, 0xFFFFFFFFu);
+  cols->tf.assign(P + 4, 0);
+  std::vector<std::vector<std::pair<uint64_t, uint32_t>>> ovf(R);
+  parallel(R, [&](uint64_t r, DocScratch&) {
+    std::vector<Rec>& v = ranges[r];
+    uint64_t g = gbase[r], pos = pbase[r];
+    for (size_t i = 0; i < v.size(); ++i, ++pos) {
+      if (i == 0 || v[i].key != v[i - 1].key) {
+        cols->sorted_keys[g] = v[i].key;
+        cols->offsets[g] = pos;
+        ++g;
+      }
+      cols->docids[pos] = v[i].doc;
+      cols->tf[pos] = static_cast<uint8_t>(v[i].tf >= 255 ? 255 : v[i].tf);
+      if (v[i].tf >= 255) ovf[r].emplace_back(pos, v[i].tf);
+    }
+    std::vector<Rec>().swap(v);
+  });
+  cols->offsets[G] = P;
+  for (uint64_t g = 0; g < G; ++g)
+    if (cols->offsets[g + 1] - cols->offsets[g] > 0xFFFFFFFFull) {
+      *err = "a posting list exceeds 2^32 entries";
+      return MGX_ERR_OUT_OF_RANGE;
+    }
+  for (const auto& o : ovf)
+    for (const auto& e : o) {
+      cols->tf_ovf_pos.push_back(e.first);
+      cols->tf_ovf_val.push_back(e.second);
+    }
+  cols->key_off.resize(G + 1);
+  cols->key_off[0] = 0;
+  uint64_t nbytes = 0;
+  for (uint64_t g = 0; g < G; ++g) nbytes += static_cast<uint64_t>(cols->sorted_keys[g] & 0xFF);
+  if (nbytes > 0xFFFFFFF0ull) {
+    *err = "the n-gram keys exceed 4 GiB";
+    return MGX_ERR_OUT_OF_RANGE;
+  }
+  cols->key_bytes.resize(nbytes);
+  uint64_t at = 0;
+  for (uint64_t g = 0; g < G; ++g) {
+    const Key k = cols->sorted_keys[g];
+    const size_t nb = static_cast<size_t>(k & 0xFF);
+    for (size_t i = 0; i < nb; ++i) cols->key_bytes[at + i] = static_cast<uint8_t>(k >> (8 * (15 - i)));
+    at += nb;
+    cols->key_off[g + 1] = static_cast<uint32_t>(at);
+  }
+  *out = cols.release();
+  return MGX_OK;
+}
+
 int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const uint64_t* text_off,
                  uint32_t first_doc_id, uint64_t n_docs, Columns** out, std::string* err) {
   const int ascii_n = bp.ngram_size;
@@ -164,6 +348,26 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
     }
     for (auto& t : th) t.join();
   };
+
+  // ---- which build: a small dictionary (a bigram index of an alphabetic corpus: hundreds of grams) or a large one
+  // (CJK trigrams: 10^7..10^8 distinct grams)? The dictionary-first build below keeps a count per (chunk, gram): fine
+  // for the former, 50 GB for the latter. The first chunk's distinct grams decide.
+  {
+    DocScratch s;
+    KeyTable probe;
+    const uint64_t d1 = std::min<uint64_t>(n_docs, std::max<uint64_t>(chunk_docs, 1));
+    bool big = false;
+    for (uint64_t d = 0; d < d1 && !big; ++d) {
+      uint32_t dl = 0;
+      if (!DocWindows(text_bytes + text_off[d], static_cast<size_t>(text_off[d + 1] - text_off[d]), ascii_n, kanji_n, cross, s, &dl)) break;
+      for (Key k : s.keys)
+        if (k) probe.Insert(k, 0);
+      big = probe.used > (1u << 16);
+    }
+    const char* force = std::getenv("MGX_BUILD_SORTED");  // 1: always the sort-based build, 0: never (tests)
+    if (force ? atoi(force) != 0 : big)
+      return BuildColumnsSorted(bp, text_bytes, text_off, first_doc_id, n_docs, n_threads, out, err);
+  }
 
   // ---- pass 1: dictionary of all grams, doc_len, BM25 stats ----------------------------------------------------
   std::vector<KeyTable> chunk_sets(n_chunks);

@@ -282,3 +282,27 @@ def test_mgix_dump_rejects_damage():
     with pytest.raises(mg._capi.MgxError) as e:  # a caller's range that does not hold the dump's ids
         mg.Columns.from_mgix(bytes(data), first_doc_id=1, n_docs=1000)
     assert e.value.code == 3
+
+
+def test_sort_based_build_equals_the_dictionary_first_build(monkeypatch):
+    """The column builder has two builds — dictionary first (small dictionaries: a bigram index) and sort-based (large ones:
+    CJK trigrams, 10^7..10^8 grams; chosen from the first chunk's distinct grams). Both must produce identical columns, and
+    the sort-based one is checked against the oracle like the other."""
+    rng = np.random.default_rng(5)
+    alphabet = [chr(0x4E00 + i) for i in range(400)] + [chr(0x3042 + i) for i in range(40)] + list("abc ")
+    cjk = ["".join(alphabet[j] for j in rng.integers(0, len(alphabet), size=int(rng.integers(0, 40)))) for _ in range(6000)]
+    ascii_texts = [mg.Corpus.synthetic(4000, seed=9).text(i).decode() for i in range(4000)] + ["ab" * 300, "", "a" * 700]
+
+    def build(texts, ngram, kanji, mode, threads):
+        monkeypatch.setenv("MGX_BUILD_SORTED", mode)
+        c = mg.Columns(mg.Corpus.from_texts(texts), 7, ngram, kanji, True, n_threads=threads)
+        return (c.n_grams, c.key_bytes.tobytes(), c.key_off.tolist(), c.offsets.tolist(), c.docids[: c.n_postings].tolist(),
+                c.tf[: c.n_postings].tolist(), c.doc_len.tolist(), c.bm25_doc_count, c.bm25_total_len,
+                c.tf_overflow_pos.tolist(), c.tf_overflow_val.tolist())
+    for texts, ngram, kanji in ((cjk, 3, 3), (cjk, 2, 1), (ascii_texts, 2, 0)):
+        a = build(texts, ngram, kanji, "0", 3)
+        b = build(texts, ngram, kanji, "1", 5)
+        assert a == b
+    monkeypatch.setenv("MGX_BUILD_SORTED", "1")
+    _check_columns_against_oracle(["東京都", "東京は日本の首都です", "aあ東京b", "ab" * 260, "", "京", "abababa"], 10, 2, 1, True)
+    _check_columns_against_oracle([mg.Corpus.synthetic(800, seed=3).text(i).decode() for i in range(800)], 1, 2, 0, True)

@@ -41,26 +41,33 @@ def cfg5(mg, args):
 
 
 def cfg3(mg, args):
-    """CJK trigram index; 50% AND of 2-4 multi-gram terms, 20% (a OR b) AND c, 20% a AND NOT b, 10% FUZZY 1."""
+    """CJK trigram index; 50% AND of 2-4 multi-gram terms, 20% (a OR b) AND c, 20% a AND NOT b, 10% FUZZY 1.
+    The corpus is made as UTF-8 bytes with numpy (10M docs as Python strings would take minutes): 3000 ideographs
+    (Zipf) + 80 kana, 16-48 code points per doc, every code point 3 bytes."""
     rng = np.random.default_rng(3)
-    ideo = [chr(0x4E00 + i) for i in range(3000)]
-    kana = [chr(0x3042 + i) for i in range(80)]
+    cps = np.concatenate([0x4E00 + np.arange(3000), 0x3042 + np.arange(80)]).astype(np.uint32)
     wi = 1.0 / np.arange(1, 3001)
-    alphabet = np.asarray(ideo + kana)
     p = np.concatenate([wi / wi.sum() * 0.9, np.full(80, 0.1 / 80)])
     lens = rng.integers(16, 49, size=args.docs)
-    flat = rng.choice(len(alphabet), size=int(lens.sum()), p=p)
-    texts, at = [], 0
-    for n in lens:
-        texts.append("".join(alphabet[flat[at:at + n]]))
-        at += n
-    idx = mg.Index(texts=texts, ngram_size=3, kanji_ngram_size=3)
+    flat = cps[rng.choice(len(cps), size=int(lens.sum()), p=p)]
+    b = np.empty((len(flat), 3), np.uint8)
+    b[:, 0] = 0xE0 | (flat >> 12)
+    b[:, 1] = 0x80 | ((flat >> 6) & 0x3F)
+    b[:, 2] = 0x80 | (flat & 0x3F)
+    del flat
+    text_off = np.concatenate([[0], np.cumsum(lens.astype(np.uint64) * 3)]).astype(np.uint64)
+    corpus = mg.Corpus(np.concatenate([b.reshape(-1), np.zeros(16, np.uint8)]), text_off)
+    del b
+    t0 = time.perf_counter()
+    idx = mg.Index(corpus=corpus, ngram_size=3, kanji_ngram_size=3)
+    build_s = time.perf_counter() - t0
 
     def term():
-        d = texts[int(rng.integers(0, len(texts)))]
+        d = int(rng.integers(0, args.docs))
         n = int(rng.integers(3, 7))
-        s = int(rng.integers(0, max(1, len(d) - n)))
-        return d[s:s + n]
+        s = int(rng.integers(0, max(1, int(lens[d]) - n)))
+        a = int(text_off[d]) + 3 * s
+        return corpus.text_bytes[a:a + 3 * n].tobytes().decode("utf-8")
 
     qs = []
     for i in range(args.batch):
@@ -68,14 +75,15 @@ def cfg3(mg, args):
         if r < 5:
             qs.append(mg.engine.Query([term() for _ in range(int(rng.integers(2, 5)))], limit=100))
         elif r < 7:
-            a, b, cc = term(), term(), term()
-            qs.append(mg.engine.Query(expr=("and", ("or", a, b), cc), limit=100))
+            a, b2, cc = term(), term(), term()
+            qs.append(mg.engine.Query(expr=("and", ("or", a, b2), cc), limit=100))
         elif r < 9:
             qs.append(mg.engine.Query([term()], [term()], limit=100))
         else:
             qs.append(mg.engine.Query([term()], fuzzy=1, limit=100))
     return idx, qs, {"workload": "cfg3 share: %d CJK docs (3000 ideographs Zipf + 80 kana, 16-48 cp), trigram, batch %d "
-                                 "mixed AND/OR/NOT/FUZZY, docid DESC limit 100" % (args.docs, args.batch)}
+                                 "mixed AND/OR/NOT/FUZZY, docid DESC limit 100" % (args.docs, args.batch),
+                     "index_build_s": build_s, "_corpus": corpus}
 
 
 def cfg2doc(mg, args):
@@ -152,6 +160,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--check", type=int, default=0, help="sample this many queries of the batch against the CPU oracle")
     args = ap.parse_args()
     args.docs = args.docs or {"cfg3": 1_000_000, "cfg5": 12_500_000, "cfg2doc": 10_000_000, "text2": 2_000_000, "cfg4": 12_500_000, "score5": 10_000_000}[args.config]
     args.batch = args.batch or {"cfg3": 4096, "cfg5": 8192, "cfg2doc": 1024, "text2": 1024, "cfg4": 1024, "score5": 1024}[args.config]
@@ -185,6 +194,32 @@ def main():
     cfg.update({"index_bytes_hbm": idx.device_index.memory_bytes(), "grams": idx.columns.n_grams,
                 "postings": idx.columns.n_postings, "setup_s": setup,
                 "mean_total": float(np.mean([r.total for r in res])), "device_queries": batch.n})
+    corpus_for_check = cfg.pop("_corpus", None)
+    if args.check:
+        # a seeded sample of the batch against the oracle at THIS size (docids, totals, funnel counters)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from gpu_util import Pair
+        from oracle import oracle as O
+        c = idx.columns
+        pr = Pair.__new__(Pair)
+        pr.dev, pr.corpus, pr.filters = idx, corpus_for_check, {}
+        pr.oidx = O.Index.from_csr(idx.ngram_size, idx.kanji_ngram_size, idx.cross_boundary, c.key_bytes, c.key_off, c.offsets, c.docids)
+        pr.ostore = O.DocumentStore.from_arrays(corpus_for_check.text_bytes, corpus_for_check.text_off) if corpus_for_check is not None else None
+        pr.N, pr.total_len, pr.avgdl = c.bm25_doc_count, c.bm25_total_len, c.avg_doc_length()
+        rng = np.random.default_rng(99)
+        bad = 0
+        picks = rng.choice(len(qs), size=min(args.check, len(qs)), replace=False).tolist()
+        for i in picks:
+            q, g = qs[i], res[i]
+            if q.fuzzy:
+                r = O.execute_fuzzy(pr.oidx, pr.ostore, q.terms, q.fuzzy, ngram_size=idx.ngram_size,
+                                    kanji_ngram_size=idx.kanji_ngram_size, cross_boundary=idx.cross_boundary)
+                want_total, want_page = len(r["results"]), r["results"][::-1][: q.limit]
+            else:
+                want_total, want_page, _, _ = pr.oracle_query(q)
+            if g.total != want_total or g.docs.tolist() != want_page.tolist():
+                bad += 1
+        cfg["oracle_checked"], cfg["oracle_mismatches"] = len(picks), bad
     print(json.dumps({"metric": "queries/sec", "value": len(qs) * args.steps / dt, "unit": "queries/s",
                       "ms_per_step": 1e3 * dt / args.steps, "tile_kernel_ms": k_ms, "steps": args.steps, "config": cfg}))
 
