@@ -278,8 +278,12 @@ struct mgx_index {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t side_stream = nullptr;  // the few queries the wave kernel cannot take run here, beside the main launch
-  std::mutex mu;  // serialises the single-operator entry points and filter registration
-  std::unique_ptr<mgx::BatchResources> single_res;  // arenas of the single-operator batches (used under mu)
+  std::mutex mu;  // filter registration (rows / columns of the filter pool), text attachment
+  // The single-operator entry points (Index::SearchAnd & co. through the shim: what an UNMODIFIED call site uses, from
+  // every worker thread of the server at once, command_handler.cpp:66) each lease one of these for the call: its own
+  // arenas, pinned block and stream — no lock is held while the operator runs, nothing is allocated in steady state.
+  std::mutex pool_mu;
+  std::vector<std::unique_ptr<mgx::BatchResources>> single_pool;  // free ones
   mgx::DevIndex dev{};
   DevBuf d_offsets, d_docids, d_tf, d_doc_len, d_skip_row, d_tile_off, d_gram_bitmaps, d_filter_bitmaps;
   DevBuf d_text, d_text_off;  // mgx_index_attach_text
@@ -3323,21 +3327,62 @@ void mgx_batch_destroy(mgx_batch* batch) {
 // single operators
 // =================================================================================================================
 
+namespace {
+// One set of batch resources (arenas, pinned result block, stream) leased from the index for the duration of a call.
+struct SingleLease {
+  mgx_index* idx;
+  std::unique_ptr<mgx::BatchResources> res;
+  explicit SingleLease(mgx_index* i) : idx(i) {
+    {
+      std::lock_guard<std::mutex> lock(idx->pool_mu);
+      if (!idx->single_pool.empty()) {
+        res = std::move(idx->single_pool.back());
+        idx->single_pool.pop_back();
+      }
+    }
+    if (!res) res = std::make_unique<mgx::BatchResources>();
+    res->Reset();
+  }
+  ~SingleLease() {
+    std::lock_guard<std::mutex> lock(idx->pool_mu);
+    if (idx->single_pool.size() < 64) idx->single_pool.push_back(std::move(res));
+  }
+  hipError_t Stream(hipStream_t* s) {
+    if (!res->stream) {
+      const hipError_t e = hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
+    *s = res->stream;
+    return hipSuccess;
+  }
+  // ships what Upload() staged in the lease's pinned mirror (calls that do not go through a batch's execute)
+  hipError_t Ship(hipStream_t s) {
+    for (const mgx::Arena::Chunk& c : res->upload.chunks)
+      if (c.used) {
+        const hipError_t e = hipMemcpyAsync(c.dev, c.host, c.used, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+      }
+    res->uploaded = true;
+    return hipSuccess;
+  }
+};
+}  // namespace
+
 static int RunSingle(mgx_index* idx, mgx::QuerySpec&& spec, uint32_t** out_docs, uint64_t* out_n) {
   *out_docs = nullptr;
   *out_n = 0;
-  std::lock_guard<std::mutex> lock(idx->mu);
   std::vector<mgx::QuerySpec> specs;
   specs.push_back(std::move(spec));
-  // single operators share one set of arenas per index (they run one at a time, under idx->mu): no allocation per call
-  if (!idx->single_res) idx->single_res = std::make_unique<mgx::BatchResources>();
-  idx->single_res->Reset();
+  MGX_HIP(hipSetDevice(idx->device));
+  SingleLease lease(idx);
+  hipStream_t stream = nullptr;
+  MGX_HIP(lease.Stream(&stream));
   mgx_batch batch_obj;
   mgx_batch* b = &batch_obj;
-  b->res = idx->single_res.get();
+  b->res = lease.res.get();
   int rc = mgx::PrepareInto(b, idx, std::move(specs));
   if (rc) return rc;
-  rc = mgx::ExecuteImpl(b, idx->stream);
+  rc = mgx::ExecuteImpl(b, stream);
   if (rc) return rc;
   mgx_result_view v{};
   rc = mgx::FetchImpl(b, &v);
@@ -3368,21 +3413,27 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
     mgx::QuerySpec spec;
     int rc = mgx::CompileQuery(idx, q, &spec);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(idx->mu);
-    if (column_id >= idx->filter_columns.size())
-      return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_facet_counts: unknown filter column");
-    const mgx_index::FilterColumn& col = *idx->filter_columns[column_id];
+    const mgx_index::FilterColumn* colp = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(idx->mu);  // (columns are added under mu; the objects themselves never move)
+      if (column_id >= idx->filter_columns.size())
+        return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_facet_counts: unknown filter column");
+      colp = idx->filter_columns[column_id].get();
+    }
+    const mgx_index::FilterColumn& col = *colp;
     if (!col.d_value_ids.p) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_facet_counts: the column was added without value ids");
     std::vector<mgx::QuerySpec> specs;
     specs.push_back(std::move(spec));
-    if (!idx->single_res) idx->single_res = std::make_unique<mgx::BatchResources>();
-    idx->single_res->Reset();
+    MGX_HIP(hipSetDevice(idx->device));
+    SingleLease lease(idx);
+    hipStream_t stream = nullptr;
+    MGX_HIP(lease.Stream(&stream));
     mgx_batch batch_obj;
     mgx_batch* b = &batch_obj;
-    b->res = idx->single_res.get();
+    b->res = lease.res.get();
     rc = mgx::PrepareInto(b, idx, std::move(specs));
     if (rc) return rc;
-    rc = mgx::ExecuteImpl(b, idx->stream);
+    rc = mgx::ExecuteImpl(b, stream);
     if (rc) return rc;
     if (b->bitmap.qids.size() != 1) return mgx::Fail(MGX_ERR_INTERNAL, "mgx_facet_counts: the query did not compile to a result bitmap");
     DevBuf d_counts;
@@ -3390,15 +3441,15 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
       mgx::ResourceScope none(nullptr);
       MGX_HIP(d_counts.Alloc(std::max<size_t>(col.n_values, 1) * sizeof(unsigned long long)));
     }
-    MGX_HIP(hipMemsetAsync(d_counts.p, 0, d_counts.bytes, idx->stream));
+    MGX_HIP(hipMemsetAsync(d_counts.p, 0, d_counts.bytes, stream));
     MGX_LAUNCH(mgx::LaunchFacetCount(b->d_rbits.as<uint64_t>(), idx->dev.n_tiles * mgx::kWordsPerTile,
                                      col.d_value_ids.as<uint32_t>(), idx->dev.n_docs, col.n_values,
-                                     d_counts.as<unsigned long long>(), idx->stream));
+                                     d_counts.as<unsigned long long>(), stream));
     uint64_t total = 0;
     if (col.n_values)
-      MGX_HIP(hipMemcpyAsync(counts_out, d_counts.p, static_cast<size_t>(col.n_values) * 8, hipMemcpyDeviceToHost, idx->stream));
-    MGX_HIP(hipMemcpyAsync(&total, b->d_totals.p, 8, hipMemcpyDeviceToHost, idx->stream));
-    MGX_HIP(hipStreamSynchronize(idx->stream));
+      MGX_HIP(hipMemcpyAsync(counts_out, d_counts.p, static_cast<size_t>(col.n_values) * 8, hipMemcpyDeviceToHost, stream));
+    MGX_HIP(hipMemcpyAsync(&total, b->d_totals.p, 8, hipMemcpyDeviceToHost, stream));
+    MGX_HIP(hipStreamSynchronize(stream));
     *matched = total;
     return MGX_OK;
   } catch (const std::exception& e) {
@@ -3537,18 +3588,22 @@ int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, cons
   MGX_SINGLE_PROLOGUE("mgx_retain");
   if (n_cand && !candidates) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_retain: null candidates");
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
     MGX_HIP(hipSetDevice(idx->device));
+    SingleLease lease(idx);
+    hipStream_t stream = nullptr;
+    MGX_HIP(lease.Stream(&stream));
+    mgx::ResourceScope scope(lease.res.get());
     std::vector<uint8_t> keep(n_cand, 1);
     if (n_cand && n) {
       DevBuf d_c, d_g, d_k;
       MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
       MGX_HIP(mgx::Upload(d_g, gram_ids, n));
       MGX_HIP(d_k.Alloc(n_cand));
+      MGX_HIP(lease.Ship(stream));
       MGX_LAUNCH(mgx::LaunchRetain(idx->dev, d_c.as<uint32_t>(), n_cand, d_g.as<uint32_t>(), n, d_k.as<uint8_t>(),
-                                   idx->stream));
-      MGX_HIP(hipMemcpyAsync(keep.data(), d_k.p, n_cand, hipMemcpyDeviceToHost, idx->stream));
-      MGX_HIP(hipStreamSynchronize(idx->stream));
+                                   stream));
+      MGX_HIP(hipMemcpyAsync(keep.data(), d_k.p, n_cand, hipMemcpyDeviceToHost, stream));
+      MGX_HIP(hipStreamSynchronize(stream));
     }
     uint32_t* o = static_cast<uint32_t*>(std::malloc((n_cand ? n_cand : 1) * 4));
     if (!o) return mgx::Fail(MGX_ERR_INTERNAL, "out of host memory");
@@ -3574,17 +3629,21 @@ int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_c
       return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_score_documents: unknown gram id");
   if (n_cand == 0) return MGX_OK;
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
     MGX_HIP(hipSetDevice(idx->device));
+    SingleLease lease(idx);
+    hipStream_t stream = nullptr;
+    MGX_HIP(lease.Stream(&stream));
+    mgx::ResourceScope scope(lease.res.get());
     DevBuf d_c, d_g, d_i, d_s;
     MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
     MGX_HIP(mgx::Upload(d_g, gram_ids, n_terms));
     MGX_HIP(mgx::Upload(d_i, idfs, n_terms));
     MGX_HIP(d_s.Alloc(n_cand * 8));
+    MGX_HIP(lease.Ship(stream));
     MGX_LAUNCH(mgx::LaunchScoreCandidates(idx->dev, d_c.as<uint32_t>(), n_cand, d_g.as<uint32_t>(), d_i.as<double>(),
-                                          n_terms, k1, b, avg_doc_length, d_s.as<double>(), idx->stream));
-    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, idx->stream));
-    MGX_HIP(hipStreamSynchronize(idx->stream));
+                                          n_terms, k1, b, avg_doc_length, d_s.as<double>(), stream));
+    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, stream));
+    MGX_HIP(hipStreamSynchronize(stream));
     return MGX_OK;
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_score_documents: ") + e.what());
@@ -3604,19 +3663,23 @@ int mgx_score_documents_text(mgx_index* idx, const uint32_t* candidates, uint64_
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_score_documents_text: null term bytes");
   if (n_cand == 0) return MGX_OK;
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
     MGX_HIP(hipSetDevice(idx->device));
+    SingleLease lease(idx);
+    hipStream_t stream = nullptr;
+    MGX_HIP(lease.Stream(&stream));
+    mgx::ResourceScope scope(lease.res.get());
     DevBuf d_c, d_t, d_o, d_i, d_s;
     MGX_HIP(mgx::Upload(d_c, candidates, n_cand));
     MGX_HIP(mgx::Upload(d_t, term_bytes, n_terms ? term_off[n_terms] : 0, 16));
     MGX_HIP(mgx::Upload(d_o, term_off, n_terms + 1));
     MGX_HIP(mgx::Upload(d_i, idfs, n_terms));
     MGX_HIP(d_s.Alloc(n_cand * 8));
+    MGX_HIP(lease.Ship(stream));
     MGX_LAUNCH(mgx::LaunchScoreCandidatesText(idx->dev, d_c.as<uint32_t>(), n_cand, d_t.as<uint8_t>(),
                                               d_o.as<uint32_t>(), d_i.as<double>(), n_terms, k1, b, avg_doc_length,
-                                              d_s.as<double>(), idx->stream));
-    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, idx->stream));
-    MGX_HIP(hipStreamSynchronize(idx->stream));
+                                              d_s.as<double>(), stream));
+    MGX_HIP(hipMemcpyAsync(scores_out, d_s.p, n_cand * 8, hipMemcpyDeviceToHost, stream));
+    MGX_HIP(hipStreamSynchronize(stream));
     return MGX_OK;
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_score_documents_text: ") + e.what());
@@ -3648,8 +3711,11 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
     // the full-sort fallback (result_sorter.cpp:661-716 sorts whatever it is given; deep OFFSETs are benchmarked,
     // docs/releases/v1.3.5.md:238): every pair sorted best first by the bitonic network, then the page is cut out
     try {
-      std::lock_guard<std::mutex> lock(idx->mu);
       MGX_HIP(hipSetDevice(idx->device));
+      SingleLease lease(idx);
+      hipStream_t stream = nullptr;
+      MGX_HIP(lease.Stream(&stream));
+      mgx::ResourceScope scope(lease.res.get());
       uint64_t n2 = 2048;
       while (n2 < n) n2 <<= 1;
       DevBuf d_r, d_s, d_k, d_d, d_o;
@@ -3658,15 +3724,16 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
       MGX_HIP(d_k.Alloc(n2 * 8));
       MGX_HIP(d_d.Alloc(n2 * 4));
       MGX_HIP(d_o.Alloc((end - start) * 4));
-      MGX_HIP(hipMemsetAsync(d_k.as<uint64_t>() + n, 0, (n2 - n) * 8, idx->stream));
-      MGX_HIP(hipMemsetAsync(d_d.as<uint32_t>() + n, 0, (n2 - n) * 4, idx->stream));
+      MGX_HIP(hipMemsetAsync(d_k.as<uint64_t>() + n, 0, (n2 - n) * 8, stream));
+      MGX_HIP(hipMemsetAsync(d_d.as<uint32_t>() + n, 0, (n2 - n) * 4, stream));
+      MGX_HIP(lease.Ship(stream));
       MGX_LAUNCH(mgx::LaunchMakeSortKeys(d_r.as<uint32_t>(), d_s.as<double>(), n, descending, d_k.as<uint64_t>(),
-                                         d_d.as<uint32_t>(), idx->stream));
-      MGX_LAUNCH(mgx::LaunchSortPairs(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n2, idx->stream));
+                                         d_d.as<uint32_t>(), stream));
+      MGX_LAUNCH(mgx::LaunchSortPairs(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n2, stream));
       MGX_LAUNCH(mgx::LaunchSortPage(d_k.as<uint64_t>(), d_d.as<uint32_t>(), static_cast<uint32_t>(start),
-                                     static_cast<uint32_t>(end), descending, d_o.as<uint32_t>(), nullptr, idx->stream));
-      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
-      MGX_HIP(hipStreamSynchronize(idx->stream));
+                                     static_cast<uint32_t>(end), descending, d_o.as<uint32_t>(), nullptr, stream));
+      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, stream));
+      MGX_HIP(hipStreamSynchronize(stream));
       return succeed();
     } catch (const std::exception& e) {
       return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
@@ -3675,8 +3742,11 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
   if (n > 65536) {
     // long arrays: per-wave top-(offset+limit) over strided shares, then the merge kernel of the batch path
     try {
-      std::lock_guard<std::mutex> lock(idx->mu);
       MGX_HIP(hipSetDevice(idx->device));
+      SingleLease lease(idx);
+      hipStream_t stream = nullptr;
+      MGX_HIP(lease.Stream(&stream));
+      mgx::ResourceScope scope(lease.res.get());
       const uint32_t needed = static_cast<uint32_t>(std::min<uint64_t>(static_cast<uint64_t>(offset) + limit, n));
       uint32_t cap = 64;
       while (cap < needed) cap <<= 1;
@@ -3702,36 +3772,41 @@ int mgx_sort_by_score(mgx_index* idx, const uint32_t* results, const double* sco
       MGX_HIP(d_o.Alloc(static_cast<size_t>(limit) * 4));
       MGX_HIP(d_ps.Alloc(static_cast<size_t>(limit) * 8));
       MGX_HIP(d_pn.Alloc(4));
+      MGX_HIP(lease.Ship(stream));
       MGX_LAUNCH(mgx::LaunchMakeSortKeys(d_r.as<uint32_t>(), d_s.as<double>(), n, descending, d_k.as<uint64_t>(),
-                                         d_d.as<uint32_t>(), idx->stream));
+                                         d_d.as<uint32_t>(), stream));
       MGX_LAUNCH(mgx::LaunchTopKScan(d_k.as<uint64_t>(), d_d.as<uint32_t>(), n, needed, cap, descending, n_blocks,
-                                     d_ck.as<uint64_t>(), d_cd.as<uint32_t>(), d_cn.as<uint32_t>(), idx->stream));
+                                     d_ck.as<uint64_t>(), d_cd.as<uint32_t>(), d_cn.as<uint32_t>(), stream));
       MGX_LAUNCH(mgx::LaunchMergeTopK(d_q.as<mgx::DevQuery>(), d_id.as<uint32_t>(), 1, n_lists, d_ck.as<uint64_t>(),
                                       d_cd.as<uint32_t>(), d_cn.as<uint32_t>(), /*kq=*/0, /*kj=*/needed, /*dj=*/needed,
                                       /*cq=*/0, /*cj=*/1, nullptr, nullptr, nullptr, 0, d_o.as<uint32_t>(),
                                       d_ps.as<double>(), d_pn.as<uint32_t>(), limit, nullptr, nullptr, nullptr,
-                                      idx->stream));
-      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
-      MGX_HIP(hipStreamSynchronize(idx->stream));
+                                      stream));
+      MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, stream));
+      MGX_HIP(hipStreamSynchronize(stream));
       return succeed();
     } catch (const std::exception& e) {
       return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());
     }
   }
   try {
-    std::lock_guard<std::mutex> lock(idx->mu);
     MGX_HIP(hipSetDevice(idx->device));
+    SingleLease lease(idx);
+    hipStream_t stream = nullptr;
+    MGX_HIP(lease.Stream(&stream));
+    mgx::ResourceScope scope(lease.res.get());
     DevBuf d_r, d_s, d_k, d_d, d_o;
     MGX_HIP(mgx::Upload(d_r, results, n));
     MGX_HIP(mgx::Upload(d_s, scores, n));
     MGX_HIP(d_k.Alloc(n * 8));
     MGX_HIP(d_d.Alloc(n * 4));
     MGX_HIP(d_o.Alloc((end - start) * 4));
+    MGX_HIP(lease.Ship(stream));
     MGX_LAUNCH(mgx::LaunchSortByScore(d_r.as<uint32_t>(), d_s.as<double>(), n, descending,
                                       static_cast<uint32_t>(start), static_cast<uint32_t>(end), d_k.as<uint64_t>(),
-                                      d_d.as<uint32_t>(), d_o.as<uint32_t>(), idx->stream));
-    MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, idx->stream));
-    MGX_HIP(hipStreamSynchronize(idx->stream));
+                                      d_d.as<uint32_t>(), d_o.as<uint32_t>(), stream));
+    MGX_HIP(hipMemcpyAsync(o, d_o.p, (end - start) * 4, hipMemcpyDeviceToHost, stream));
+    MGX_HIP(hipStreamSynchronize(stream));
     return succeed();
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_sort_by_score: ") + e.what());

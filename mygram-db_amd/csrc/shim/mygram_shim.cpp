@@ -181,11 +181,16 @@ std::string FilterValueToDisplayString(const FilterValue& value) {  // Deseriali
 namespace index {
 
 namespace {
+// the Index whose device this thread touched last, and the one finalised last in the process: where the index-less
+// ResultSorter::SortByScore (the reference's signature) runs
+thread_local const Index* tl_last_index = nullptr;
+std::atomic<const Index*> g_last_finalized{nullptr};
 thread_local std::string tl_device_error;
 // every std::vector-returning method: cleared on entry ...
 void ClearDeviceError() { tl_device_error.clear(); }
 }  // namespace
 const std::string& LastDeviceError() { return tl_device_error; }
+const Index* LastUsedIndex() { return tl_last_index ? tl_last_index : g_last_finalized.load(); }
 // ... and set where the C ABI (or the index build) reports a failure
 static void SetDeviceError(const std::string& msg) { tl_device_error = msg.empty() ? "device failure" : msg; }
 void ClearDeviceErrorForSorter() { ClearDeviceError(); }
@@ -290,7 +295,11 @@ Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, boo
   impl_->query_kanji = kanji_ngram_size;
 }
 
-Index::~Index() = default;
+Index::~Index() {
+  if (tl_last_index == this) tl_last_index = nullptr;
+  const Index* me = this;
+  g_last_finalized.compare_exchange_strong(me, nullptr);
+}
 
 std::unique_ptr<Index> Index::Adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size,
                                     int kanji_ngram_size, bool cross_boundary_ngrams) {
@@ -301,6 +310,7 @@ std::unique_ptr<Index> Index::Adopt(mgx_columns* columns, mgx_index* device_inde
   im->owns_handles = false;
   im->finalized = true;
   if (mgx_columns_view_get(columns, &im->view) != MGX_OK) im->last_error = mgx_last_error();
+  g_last_finalized.store(idx.get());
   return idx;
 }
 
@@ -397,9 +407,11 @@ void Index::AddDocumentBatch(const std::vector<DocumentItem>& documents) {
 }
 
 std::string Index::Finalize() const {
+  tl_last_index = this;  // (every search / scoring entry point passes through here)
   std::lock_guard<std::mutex> lock(impl_->mu);
   if (impl_->finalized) return impl_->last_error;
   impl_->finalized = true;
+  g_last_finalized.store(this);
   // dense id range [first, last]; ids never added are documents without text
   const DocId first = impl_->pending.empty() ? 1 : impl_->pending.begin()->first;
   const DocId last = impl_->pending.empty() ? 1 : impl_->pending.rbegin()->first;
@@ -760,7 +772,23 @@ std::vector<DocId> ResultSorter::SortByScore(const index::Index& index, const st
   return Take(out, n);
 }
 
+std::vector<DocId> ResultSorter::SortByScore(const std::vector<DocId>& results, const std::vector<double>& scores,
+                                             SortOrder order, uint32_t limit, uint32_t offset) {
+  index::ClearDeviceErrorForSorter();
+  if (results.empty()) return {};
+  const index::Index* idx = index::LastUsedIndex();
+  if (idx == nullptr) {
+    index::SetDeviceError("ResultSorter::SortByScore: no Index has been used in this process (the sort runs on its device)");
+    return {};
+  }
+  return SortByScore(*idx, results, scores, order, limit, offset);
+}
+
 }  // namespace query
+
+namespace storage {
+size_t DocumentStore::Size() const { return static_cast<size_t>(index_->Bm25DocCount()); }
+}  // namespace storage
 
 // =================================================================================================================
 // search_pipeline::ExecuteBatch / BatchExecutor

@@ -222,6 +222,27 @@ class Index {
   void FlushPendingFilterColumns() const;  // internal: AddDocument's filter values -> device columns, after Finalize
 };
 
+}  // namespace mygramdb::index
+
+namespace mygramdb::storage {
+// The slice of storage::DocumentStore (src/storage/document_store.h) the BM25 call sites touch: they hand the store to
+// BM25Scorer::ScoreDocuments for the candidates' texts (search_handler.cpp:454, http_server.cpp:572). Here the texts —
+// and the tf / doc-length columns made from them — live with the device index, so the store is a view of an Index; a
+// maintainer constructs it next to the Index and the call sites compile unchanged.
+class DocumentStore {
+ public:
+  explicit DocumentStore(const index::Index& index) : index_(&index) {}
+  [[nodiscard]] const index::Index& index() const { return *index_; }
+  [[nodiscard]] bool IsStoreTextsEnabled() const { return true; }  // document_store.h: SORT _score / HIGHLIGHT need texts
+  [[nodiscard]] size_t Size() const;                                 // documents with a text
+
+ private:
+  const index::Index* index_;
+};
+}  // namespace mygramdb::storage
+
+namespace mygramdb::index {
+
 struct BM25Params {  // src/index/bm25_scorer.h:20-23
   double k1 = 1.2;
   double b = 0.75;
@@ -240,6 +261,13 @@ class BM25Scorer {
       const std::vector<DocId>& candidates, const std::vector<std::string>& search_terms,
       const std::vector<uint64_t>& term_doc_freqs, const Index& index, uint64_t total_docs, double avg_doc_length,
       const BM25Params& params);
+  // the reference's exact signature (src/index/bm25_scorer.h:79-82)
+  static mygram::utils::Expected<std::vector<ScoredDoc>, mygram::utils::Error> ScoreDocuments(
+      const std::vector<DocId>& candidates, const std::vector<std::string>& search_terms,
+      const std::vector<uint64_t>& term_doc_freqs, const storage::DocumentStore& doc_store, uint64_t total_docs,
+      double avg_doc_length, const BM25Params& params) {
+    return ScoreDocuments(candidates, search_terms, term_doc_freqs, doc_store.index(), total_docs, avg_doc_length, params);
+  }
 };
 
 }  // namespace mygramdb::index
@@ -271,6 +299,11 @@ class ResultSorter {
   static std::vector<DocId> SortByScore(const index::Index& index, const std::vector<DocId>& results,
                                         const std::vector<double>& scores, SortOrder order, uint32_t limit,
                                         uint32_t offset);
+  // the reference's exact signature (src/query/result_sorter.h:75-76): the sort runs on the device of the Index this
+  // thread used last (ScoreDocuments, a search, ...) — at the call sites that is the table just scored
+  // (search_handler.cpp:454,469) — or, on a thread that has used none, of the Index finalised last in the process.
+  static std::vector<DocId> SortByScore(const std::vector<DocId>& results, const std::vector<double>& scores,
+                                        SortOrder order, uint32_t limit, uint32_t offset);
 };
 
 }  // namespace mygramdb::query

@@ -397,6 +397,29 @@ int main() {
       EXPECT((*f2)[0].scores.size() == (*f2)[0].results.size() && (*f2)[0].scores[0] > (*f2)[0].scores.back());
     }
   }
+  {  // the reference's EXACT signatures at the BM25 call sites (search_handler.cpp:454,469 / http_server.cpp:572,584):
+     // ScoreDocuments(..., const DocumentStore&, ...) and SortByScore(results, scores, order, limit, offset)
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "alpha");
+    index.AddDocument(2, "alpha alpha alpha");
+    index.AddDocument(3, "beta");
+    mygramdb::storage::DocumentStore doc_store(index);
+    const V cands = index.SearchAnd({"al"});
+    EXPECT(cands == (V{1, 2}));
+    auto a = BM25Scorer::ScoreDocuments(cands, {"al"}, {index.PostingSize("al")}, doc_store, index.Bm25DocCount(),
+                                        index.Bm25AvgDocLength(), BM25Params{});
+    auto b = BM25Scorer::ScoreDocuments(cands, {"al"}, {index.PostingSize("al")}, index, index.Bm25DocCount(),
+                                        index.Bm25AvgDocLength(), BM25Params{});
+    EXPECT(a.has_value() && b.has_value());
+    if (a && b) {
+      EXPECT(a->size() == 2 && (*a)[0].score == (*b)[0].score && (*a)[1].score == (*b)[1].score && (*a)[1].score > (*a)[0].score);
+      std::vector<double> scores{(*a)[0].score, (*a)[1].score};
+      EXPECT(ResultSorter::SortByScore(cands, scores, SortOrder::DESC, 10, 0) == (V{2, 1}));
+      EXPECT(ResultSorter::SortByScore(cands, scores, SortOrder::ASC, 1, 0) == (V{1}));
+      EXPECT(mygramdb::index::LastDeviceError().empty());
+    }
+    EXPECT(doc_store.IsStoreTextsEnabled() && doc_store.Size() == 3);
+  }
   {  // FILTER conditions + FACET on typed columns fed through AddDocument(doc, text, filters):
      // tests/server/search_pipeline_test.cpp:725-910 (SearchPipelineFilterParityTest), facet_handler_test.cpp:203-258
     using namespace mygramdb::search_pipeline;
@@ -561,11 +584,17 @@ int main() {
     for (DocId d = 1; d <= 6000; d += 7) cand.push_back(d);
     const V ok = index.FilterByNgrams(cand, {"a", "b"});
     EXPECT(!ok.empty() && mygramdb::index::LastDeviceError().empty());
+    // (an operator leases arenas the index keeps from call to call — the steady state allocates nothing — so the failure
+    // is injected where an allocation must happen: the first calls on an index that has only been built)
+    Index cold(1, 0, 0.0);
+    for (DocId d = 1; d <= 6000; ++d) cold.AddDocument(d, d % 3 == 0 ? "ab" : "a");
+    EXPECT(cold.Finalize().empty());
     mgxt_fail_device_allocs(0, 1000);
-    const V failed = index.FilterByNgrams(cand, {"a", "b"});
+    const V failed = cold.FilterByNgrams(cand, {"a", "b"});
     EXPECT(failed.empty() && !mygramdb::index::LastDeviceError().empty());
-    const V sorted = ResultSorter::SortByScore(index, ok, std::vector<double>(ok.size(), 1.0), SortOrder::DESC, 10, 0);
+    const V sorted = ResultSorter::SortByScore(cold, ok, std::vector<double>(ok.size(), 1.0), SortOrder::DESC, 10, 0);
     EXPECT(sorted.empty() && !mygramdb::index::LastDeviceError().empty());
+    EXPECT(cold.SearchAnd({"a", "b"}).empty() && !mygramdb::index::LastDeviceError().empty());
     {
       Index fresh(2, 0, 0.0);  // its device index cannot even be built
       fresh.AddDocument(1, "hello");

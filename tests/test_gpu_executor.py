@@ -97,3 +97,55 @@ def test_micro_batcher_many_client_threads(pair):
     total, docs, scores = mb.search(term_lists[0], limit=10)
     assert total == got[0][0] and docs.tolist() == got[0][1].tolist()
     assert mb.stats()["closed_by_delay"] >= 1
+
+
+def test_single_operators_from_many_threads_at_once():
+    """Index::SearchAnd / SearchOr / SearchByThreshold / FilterByNgrams / ScoreDocuments / SortByScore are const and
+    re-entrant in the reference — every worker thread of the server calls them concurrently under the table's shared lock
+    (command_handler.cpp:66). Here each call leases its own arenas, pinned block and stream from the index: 12 threads x
+    40 mixed calls against the oracle."""
+    import threading
+    import numpy as np
+    from gpu_util import Pair
+    from oracle import oracle as O
+    p = Pair(corpus=mg.Corpus.synthetic(60_000, seed=23))
+    c = p.dev.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    grams = [c.gram(g).decode() for g in np.argsort(-sizes)[:60] if b" " not in c.gram(g)]
+    errors = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        try:
+            for k in range(40):
+                terms = [grams[int(i)] for i in rng.choice(len(grams), size=int(rng.integers(1, 4)), replace=False)]
+                kind = k % 5
+                if kind == 0:
+                    lim, rev = int(rng.choice([0, 10, 500])), bool(k % 2)
+                    assert p.dev.search_and(terms, lim, rev).tolist() == p.oidx.search_and(terms, lim, rev).tolist()
+                elif kind == 1:
+                    assert p.dev.search_or(terms).tolist() == p.oidx.search_or(terms).tolist()
+                elif kind == 2:
+                    th = int(rng.integers(1, len(terms) + 1))
+                    assert p.dev.search_by_threshold(terms, th).tolist() == p.oidx.search_by_threshold(terms, th).tolist()
+                elif kind == 3:
+                    cand = np.sort(rng.choice(60_000, size=300, replace=False)).astype(np.uint32) + 1
+                    assert p.dev.filter_by_ngrams(cand, terms).tolist() == p.oidx.filter_by_ngrams(cand, terms).tolist()
+                else:
+                    res = p.oidx.search_and(terms)
+                    if len(res) == 0:
+                        continue
+                    dfs = [p.oidx.posting_size(t) for t in terms]
+                    want = O.score_documents(p.ostore, res, terms, dfs, p.N, p.avgdl)
+                    got = p.dev.score_documents(res, terms, dfs, p.N, p.avgdl)
+                    assert np.array_equal(got, want)
+                    assert p.dev.sort_by_score(res, got, True, 20, 3).tolist() == O.sort_by_score(res, want, True, 20, 3).tolist()
+        except Exception as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(100 + i,)) for i in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
