@@ -110,6 +110,39 @@ typedef struct mgx_mgix_info {
 } mgx_mgix_info;
 int mgx_columns_from_mgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, uint64_t n_docs, mgx_columns** out,
                           mgx_mgix_info* info /* may be NULL */);
+/* The reference's table dump ("MGDB" version 2: what DUMP SAVE writes, src/storage/dump_format_v2.cpp:520-770) -> one
+ * table's columns, normalized texts and filter values: the MGIX index stream (as mgx_columns_from_mgix) AND the document
+ * store stream ("MGDS", src/storage/document_store_persistence.cpp:59-175). File and section CRC32s are verified. When the
+ * store kept the normalized texts (memory.verify_text on: what BM25 needs in the reference too) the columns are built from
+ * them — tf and doc lengths included, so the loaded index ranks — and must agree with the dump's own index gram by gram and
+ * list by list; otherwise the columns hold the index's doc ids alone. `table`: NULL or "" = the first table of the dump. */
+typedef struct mgx_dump mgx_dump;
+typedef struct mgx_dump_view {
+  const char* table_name;
+  mgx_mgix_info index_info;
+  uint32_t first_doc_id; /* the range spans every doc id the store or the index mentions */
+  uint64_t n_docs;
+  uint64_t n_existing;   /* documents in the store (DocumentStore::Size) */
+  const uint8_t* exists; /* n_docs: 1 = the store holds this id (DocumentStore::GetAllDocIds, the NOT universe) */
+  const uint8_t* text_bytes; /* normalized texts by slot (mgx_index_attach_text takes them as they are) */
+  const uint64_t* text_off;  /* n_docs + 1 */
+  uint32_t n_filter_columns;
+  int32_t has_texts;
+} mgx_dump_view;
+typedef struct mgx_dump_filter_column {
+  const char* name;
+  uint32_t value_type;   /* the storage::FilterValue alternative (src/storage/document_store.h:73-87): 1 bool .. 12 double */
+  const uint64_t* values;     /* n_docs, widened as mgx_filter_column_desc wants them (strings: unused) */
+  const uint8_t* is_null;     /* n_docs */
+  const uint8_t* string_bytes; /* value_type 11: doc i's string is string_bytes[string_off[i] .. string_off[i+1]) */
+  const uint64_t* string_off;
+} mgx_dump_filter_column;
+int mgx_dump_open(const uint8_t* data, uint64_t len, const char* table, mgx_dump** out);
+int mgx_dump_view_get(const mgx_dump* dump, mgx_dump_view* out);
+int mgx_dump_filter_column_get(const mgx_dump* dump, uint32_t i, mgx_dump_filter_column* out);
+/* Hands the table's columns to the caller (release with mgx_columns_destroy); a second call returns NULL. */
+int mgx_dump_take_columns(mgx_dump* dump, mgx_columns** out);
+void mgx_dump_destroy(mgx_dump* dump);
 int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out);
 /* Gram dictionary lookup (host-side replacement of Index::TakePostingSnapshot's map lookup, index.cpp:728-747).
  * *found = 0 and *gram_id = 0 for an unknown gram. */

@@ -25,6 +25,9 @@ const char* mgxs_last_error(void);
 /* Index::Adopt: the handles stay the caller's and must outlive the table. */
 int mgxs_table_adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size, int kanji_ngram_size,
                      int cross_boundary_ngrams, mgxs_table** out);
+/* Index::FromDump: a table of a reference dump (DUMP SAVE, "MGDB" v2) as a searchable, ranking table — postings, texts, the
+ * store's id set and its filter columns on the device. table_name NULL / "": the first table. */
+int mgxs_table_from_dump(const uint8_t* data, uint64_t len, const char* table_name, int device, mgxs_table** out);
 /* Doc-range shards: the table-wide BM25Stats and per-gram posting sizes (by this shard's gram ids) every rank must
  * agree on, so that idf — and every score — is identical on all ranks. */
 int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double avg_doc_length,

@@ -20,7 +20,8 @@ GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
 
 EXPORTS = [
     "mgx_abi_version", "mgx_last_error", "mgx_free", "mgx_device_count",
-    "mgx_columns_build", "mgx_columns_from_mgix", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
+    "mgx_columns_build", "mgx_columns_from_mgix", "mgx_dump_open", "mgx_dump_view_get", "mgx_dump_filter_column_get",
+    "mgx_dump_take_columns", "mgx_dump_destroy", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_add_filter_column", "mgx_index_filter_compare", "mgx_facet_counts",
     "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
@@ -76,6 +77,17 @@ class Query(C.Structure):
                 ("expr", C.c_void_p), ("n_expr", C.c_uint32), ("universe_first", C.c_uint32),
                 ("universe_count", C.c_uint64), ("exact_text", C.c_uint32), ("score_terms", C.c_void_p),
                 ("n_score_terms", C.c_uint32)]
+
+
+class DumpView(C.Structure):
+    _fields_ = [("table_name", C.c_char_p), ("index_info", MgixInfo), ("first_doc_id", C.c_uint32), ("n_docs", C.c_uint64),
+                ("n_existing", C.c_uint64), ("exists", C.c_void_p), ("text_bytes", C.c_void_p), ("text_off", C.c_void_p),
+                ("n_filter_columns", C.c_uint32), ("has_texts", C.c_int32)]
+
+
+class DumpFilterColumn(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("value_type", C.c_uint32), ("values", C.c_void_p), ("is_null", C.c_void_p),
+                ("string_bytes", C.c_void_p), ("string_off", C.c_void_p)]
 
 
 class FilterColumnDesc(C.Structure):
@@ -141,6 +153,12 @@ def load():
     L.mgx_batch_execute.argtypes = [vp, vp]
     L.mgx_batch_fetch.argtypes = [vp, C.POINTER(ResultView)]
     L.mgx_index_attach_text.argtypes = [vp, vp, vp]
+    L.mgx_dump_open.argtypes = [C.c_char_p, u64, C.c_char_p, C.POINTER(vp)]
+    L.mgx_dump_view_get.argtypes = [vp, C.POINTER(DumpView)]
+    L.mgx_dump_filter_column_get.argtypes = [vp, u32, C.POINTER(DumpFilterColumn)]
+    L.mgx_dump_take_columns.argtypes = [vp, C.POINTER(vp)]
+    L.mgx_dump_destroy.argtypes = [vp]
+    L.mgx_dump_destroy.restype = None
     L.mgx_index_set_batch_order.argtypes = [vp, C.c_uint32]
     L.mgx_index_add_filter_column.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
     L.mgx_index_filter_compare.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.c_double, i32, i32, C.POINTER(C.c_uint32)]

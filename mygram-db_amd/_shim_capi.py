@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmygram_shim.so")
 EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats", "mgxs_table_destroy",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
-           "mgxs_submit", "mgxs_wait", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
+           "mgxs_submit", "mgxs_wait", "mgxs_table_from_dump", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -47,6 +47,7 @@ def load():
     L.mgxs_executor_warm.argtypes = [vp, u32, vp, vp, u32, u32, i32, i32, i32]
     L.mgxs_wait.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.mgxs_table_add_filter_column.argtypes = [vp, C.c_char_p, i32, u64, vp, vp, vp]
+    L.mgxs_table_from_dump.argtypes = [C.c_char_p, u64, C.c_char_p, i32, C.POINTER(vp)]
     L.mgxs_search.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, i32, i32, u32, u32, C.POINTER(u64), C.POINTER(u32), vp, vp]
     L.mgxs_facet.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, C.c_char_p, u32, u32, C.POINTER(u64), C.POINTER(u64),
                              C.POINTER(u32), vp, vp, C.c_size_t, vp]
@@ -125,6 +126,17 @@ class Table:
                 keys = (C.c_char_p * len(absent))(*[k for k, _ in absent])
                 vals = np.asarray([v for _, v in absent], dtype=np.uint64)
                 _check(load().mgxs_table_set_absent_grams(self._h, len(absent), C.cast(keys, C.c_void_p), vals.ctypes.data))
+
+    @classmethod
+    def from_dump(cls, data, table_name=None, device=0):
+        """Index::FromDump: a table of a reference dump ("MGDB" v2) with its texts, id set and filter columns."""
+        self = cls.__new__(cls)
+        self._index = None
+        raw = bytes(data)
+        h = C.c_void_p()
+        _check(load().mgxs_table_from_dump(raw, len(raw), table_name.encode() if table_name else None, device, C.byref(h)))
+        self._h = h
+        return self
 
     def __del__(self):
         if getattr(self, "_h", None):

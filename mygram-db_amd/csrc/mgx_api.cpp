@@ -587,6 +587,39 @@ int mgx_columns_from_mgix(const uint8_t* data, uint64_t len, uint32_t first_doc_
   }
 }
 
+int mgx_dump_open(const uint8_t* data, uint64_t len, const char* table, mgx_dump** out) {
+  if (out) *out = nullptr;
+  if (!data || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dump_open: null argument");
+  try {
+    mgx::DumpData* d = nullptr;
+    std::string err;
+    const int rc = mgx::DumpOpen(data, len, table, &d, &err);
+    if (rc != MGX_OK) return mgx::Fail(rc, err);
+    *out = reinterpret_cast<mgx_dump*>(d);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_dump_open: ") + e.what());
+  }
+}
+int mgx_dump_view_get(const mgx_dump* dump, mgx_dump_view* out) {
+  if (!dump || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dump_view_get: null argument");
+  mgx::DumpView(reinterpret_cast<const mgx::DumpData*>(dump), out);
+  return MGX_OK;
+}
+int mgx_dump_filter_column_get(const mgx_dump* dump, uint32_t i, mgx_dump_filter_column* out) {
+  if (!dump || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dump_filter_column_get: null argument");
+  if (!mgx::DumpFilterColumn(reinterpret_cast<const mgx::DumpData*>(dump), i, out))
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_dump_filter_column_get: no such column");
+  return MGX_OK;
+}
+int mgx_dump_take_columns(mgx_dump* dump, mgx_columns** out) {
+  if (out) *out = nullptr;
+  if (!dump || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_dump_take_columns: null argument");
+  *out = reinterpret_cast<mgx_columns*>(mgx::DumpTakeColumns(reinterpret_cast<mgx::DumpData*>(dump)));
+  return MGX_OK;
+}
+void mgx_dump_destroy(mgx_dump* dump) { mgx::DumpDestroy(reinterpret_cast<mgx::DumpData*>(dump)); }
+
 int mgx_columns_view_get(const mgx_columns* cols, mgx_columns_view* out) {
   if (!cols || !out) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_columns_view_get: null argument");
   mgx::ColumnsView(reinterpret_cast<const mgx::Columns*>(cols), out);

@@ -835,4 +835,319 @@ int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, ui
   return MGX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Dump v2 ("MGDB" version 2: what DUMP SAVE writes, src/storage/dump_format_v2.cpp:520-770) -> columns + texts + filter values
+// ---------------------------------------------------------------------------------------------------------------
+// "MGDB" | u32 version = 2 | HeaderV2 (dump_format_v2.h:71-80, written field by field :300-327): u32 header_size, u32 flags,
+// u64 dump_timestamp, u64 total_file_size, u32 file_crc32 (zlib CRC of the whole file with these four bytes zeroed,
+// dump_format_internal.cpp:98-133; at offset 32), u32 section_count, string gtid | sections, each
+// {u32 type, u32 crc32 of the data, u64 data_length, data} (dump_format.h:111-118). Strings are u32 length + bytes.
+// A kTableData section (type 3; :160-290): string table_name | u32 stats_len + stats | u64 index_len + the MGIX stream |
+// u64 docs_len + the document store stream "MGDS" (document_store_persistence.cpp:59-175): u32 version (1..3),
+// u32 next_doc_id, string gtid, u64 doc_count, then per document u32 doc_id, string primary key, u32 filter_count x
+// {string column, u8 FilterValue alternative, value: nothing for NULL, u32 len + bytes for a string, the raw little-endian
+// scalar otherwise}, v2+: string normalized text, v3+: string original text.
+struct DumpData {
+  std::string table;
+  mgx_mgix_info info{};
+  Columns* cols = nullptr;  // owned until mgx_dump_columns hands it over
+  uint32_t first_doc_id = 1;
+  uint64_t n_docs = 0, n_existing = 0;
+  std::vector<uint8_t> exists, text_bytes;
+  std::vector<uint64_t> text_off;
+  struct Col {
+    std::string name;
+    uint32_t type = 0;
+    std::vector<uint64_t> values;
+    std::vector<uint8_t> is_null, str_bytes;
+    std::vector<uint64_t> str_off;
+  };
+  std::vector<Col> filter_cols;
+  bool has_scores = false;  // the texts were stored: tf / doc_len columns exist
+  ~DumpData() { DestroyColumns(cols); }
+};
+
+namespace {
+bool ReadStr(Reader& r, uint64_t max_len, std::string* out) {
+  const uint32_t n = r.U32();
+  if (!r.ok || n > max_len || !r.Need(n)) return false;
+  out->assign(reinterpret_cast<const char*>(r.p + r.at), n);
+  r.at += n;
+  return true;
+}
+}  // namespace
+
+int DumpOpen(const uint8_t* data, uint64_t len, const char* table, DumpData** out, std::string* err) {
+  auto fail = [&](int code, const std::string& what) {
+    *err = "mgx_dump_open: " + what;
+    return code;
+  };
+  if (len < 44 || std::memcmp(data, "MGDB", 4) != 0) return fail(MGX_ERR_INVALID_ARGUMENT, "not a MygramDB dump (bad magic)");
+  Reader r{data, len};
+  r.at = 4;
+  const uint32_t version = r.U32();
+  if (version != 2) return fail(MGX_ERR_NOT_IMPLEMENTED, "only dump format version 2 is read (version " + std::to_string(version) + ")");
+  (void)r.U32();  // header_size
+  (void)r.U32();  // flags
+  (void)r.U64();  // timestamp
+  const uint64_t total = r.U64();
+  const uint32_t file_crc = r.U32();
+  const uint32_t n_sections = r.U32();
+  std::string gtid;
+  if (!ReadStr(r, 64 * 1024, &gtid)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated header");
+  if (total != len) return fail(MGX_ERR_INVALID_ARGUMENT, "the file is not the size its header states (truncated?)");
+  {  // whole-file CRC with its own four bytes (offset 32) read as zero
+    std::vector<uint8_t> head(data, data + 36);
+    std::memset(head.data() + 32, 0, 4);
+    uint32_t c = Crc32(head.data(), 36);
+    // (continue the running CRC over the rest: Crc32() finalises, so un-finalise / re-run through the table)
+    uint32_t run = c ^ 0xFFFFFFFFu;
+    static uint32_t table_[256];
+    static const bool init = [] {
+      for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t v = i;
+        for (int k = 0; k < 8; ++k) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+        table_[i] = v;
+      }
+      return true;
+    }();
+    (void)init;
+    for (uint64_t i = 36; i < len; ++i) run = table_[(run ^ data[i]) & 0xFFu] ^ (run >> 8);
+    if ((run ^ 0xFFFFFFFFu) != file_crc) return fail(MGX_ERR_INVALID_ARGUMENT, "file CRC32 mismatch");
+  }
+  const uint8_t* tdata = nullptr;
+  uint64_t tlen = 0;
+  std::string tname;
+  for (uint32_t sct = 0; sct < n_sections; ++sct) {
+    const uint32_t type = r.U32(), crc = r.U32();
+    const uint64_t dl = r.U64();
+    if (!r.Need(dl)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated section");
+    const uint8_t* sd = data + r.at;
+    r.at += dl;
+    if (type != 3) continue;  // config / statistics / metadata sections: not on this path
+    if (Crc32(sd, dl) != crc) return fail(MGX_ERR_INVALID_ARGUMENT, "section CRC32 mismatch");
+    Reader tr{sd, dl};
+    std::string name;
+    if (!ReadStr(tr, 4096, &name)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated table section");
+    if (table != nullptr && table[0] != '\0' && name != table) continue;
+    if (tdata != nullptr) continue;  // (the first table, or the named one)
+    tname = name;
+    tdata = sd + tr.at;
+    tlen = dl - tr.at;
+  }
+  if (tdata == nullptr) return fail(MGX_ERR_INDEX_NOT_FOUND, table && table[0] ? std::string("table \"") + table + "\" is not in the dump" : "the dump holds no table");
+  Reader tr{tdata, tlen};
+  const uint32_t stats_len = tr.U32();
+  if (!tr.Need(stats_len)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated table statistics");
+  tr.at += stats_len;
+  const uint64_t ilen = tr.U64();
+  if (!tr.Need(ilen)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated index stream");
+  const uint8_t* istream = tdata + tr.at;
+  tr.at += ilen;
+  const uint64_t dlen = tr.U64();
+  if (!tr.Need(dlen)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated document stream");
+  Reader dr{tdata + tr.at, dlen};
+  auto dump = std::make_unique<DumpData>();
+  dump->table = tname;
+  // ---- the index stream: n-gram parameters + doc-id postings (cross-checked against the texts below) -------------------
+  Columns* from_index = nullptr;
+  {
+    const int rc = ColumnsFromMgix(istream, ilen, 1, 0, &from_index, &dump->info, err);
+    if (rc != MGX_OK) return rc;
+  }
+  std::unique_ptr<Columns, void (*)(Columns*)> index_cols(from_index, DestroyColumns);
+  // ---- the document stream ------------------------------------------------------------------------------------------------
+  if (!dr.Need(4) || std::memcmp(dr.p, "MGDS", 4) != 0) return fail(MGX_ERR_INVALID_ARGUMENT, "bad document store magic");
+  dr.at = 4;
+  const uint32_t dsv = dr.U32();
+  if (dsv < 1 || dsv > 3) return fail(MGX_ERR_NOT_IMPLEMENTED, "unsupported document store version");
+  (void)dr.U32();  // next_doc_id
+  std::string g2;
+  if (!ReadStr(dr, 64 * 1024, &g2)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated document store header");
+  const uint64_t doc_count = dr.U64();
+  if (!dr.ok || doc_count > (dr.n - dr.at) / 12) return fail(MGX_ERR_INVALID_ARGUMENT, "document count exceeds the stream");
+  struct Doc {
+    uint32_t id;
+    uint64_t text_at, text_len;
+    std::vector<std::pair<uint32_t, std::pair<uint8_t, std::pair<uint64_t, uint64_t>>>> filters;  // column -> (type, (value | str at, str len))
+  };
+  std::vector<Doc> docs;
+  docs.reserve(doc_count);
+  std::vector<std::string> col_names;
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (uint64_t d = 0; d < doc_count; ++d) {
+    Doc doc{};
+    doc.id = dr.U32();
+    std::string pk;
+    if (!ReadStr(dr, 1u << 20, &pk)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated document");
+    const uint32_t nf = dr.U32();
+    if (!dr.ok || nf > 4096) return fail(MGX_ERR_INVALID_ARGUMENT, "implausible filter count");
+    for (uint32_t f = 0; f < nf; ++f) {
+      std::string cname;
+      if (!ReadStr(dr, 4096, &cname)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated filter name");
+      const uint8_t type = dr.U8();
+      uint64_t v = 0, sl = 0;
+      switch (type) {
+        case 0: break;                                            // std::monostate
+        case 1: case 2: case 3: v = dr.U8(); if (type == 2) v = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int8_t>(v))); break;
+        case 4: v = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int16_t>(dr.U16()))); break;
+        case 5: v = dr.U16(); break;
+        case 6: v = static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(dr.U32()))); break;
+        case 7: v = dr.U32(); break;
+        case 8: case 9: case 10: case 12: v = dr.U64(); break;    // int64, uint64, TimeValue seconds, double bits
+        case 11: {
+          sl = dr.U32();
+          if (!dr.Need(sl)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated filter string");
+          v = dr.at;  // (offset of the bytes inside the document stream)
+          dr.at += sl;
+          break;
+        }
+        default: return fail(MGX_ERR_INVALID_ARGUMENT, "unknown filter value type");
+      }
+      if (!dr.ok) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated filter value");
+      uint32_t ci = 0;
+      while (ci < col_names.size() && col_names[ci] != cname) ++ci;
+      if (ci == col_names.size()) col_names.push_back(cname);
+      doc.filters.push_back({ci, {type, {v, sl}}});
+    }
+    if (dsv >= 2) {
+      const uint32_t tl = dr.U32();
+      if (!dr.Need(tl)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated text");
+      doc.text_at = dr.at;
+      doc.text_len = tl;
+      dr.at += tl;
+    }
+    if (dsv >= 3) {
+      const uint32_t ol = dr.U32();
+      if (!dr.Need(ol)) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated original text");
+      dr.at += ol;
+    }
+    if (!dr.ok) return fail(MGX_ERR_INVALID_ARGUMENT, "truncated document");
+    lo = std::min(lo, doc.id);
+    hi = std::max(hi, doc.id);
+    docs.push_back(std::move(doc));
+  }
+  // the doc-id range: everything the store or the index mentions
+  if (index_cols->n_docs) {
+    lo = std::min<uint32_t>(lo, index_cols->first_doc_id);
+    hi = std::max<uint32_t>(hi, static_cast<uint32_t>(index_cols->first_doc_id + index_cols->n_docs - 1));
+  }
+  if (lo == 0xFFFFFFFFu) {
+    lo = 1;
+    hi = 0;
+  }
+  dump->first_doc_id = lo;
+  dump->n_docs = hi >= lo ? static_cast<uint64_t>(hi) - lo + 1 : 0;
+  dump->n_existing = docs.size();
+  dump->exists.assign(dump->n_docs, 0);
+  std::vector<const Doc*> by_slot(dump->n_docs, nullptr);
+  for (const Doc& d : docs) {
+    if (by_slot[d.id - lo] != nullptr) return fail(MGX_ERR_INVALID_ARGUMENT, "a doc id appears twice in the document store");
+    by_slot[d.id - lo] = &d;
+    dump->exists[d.id - lo] = 1;
+  }
+  dump->text_off.assign(dump->n_docs + 1, 0);
+  uint64_t tbytes = 0;
+  for (uint64_t sl = 0; sl < dump->n_docs; ++sl) {
+    dump->text_off[sl] = tbytes;
+    if (by_slot[sl]) tbytes += by_slot[sl]->text_len;
+  }
+  dump->text_off[dump->n_docs] = tbytes;
+  dump->text_bytes.assign(tbytes + 16, 0);
+  for (uint64_t sl = 0; sl < dump->n_docs; ++sl)
+    if (by_slot[sl] && by_slot[sl]->text_len)
+      std::memcpy(dump->text_bytes.data() + dump->text_off[sl], dr.p + by_slot[sl]->text_at, by_slot[sl]->text_len);
+  // filter columns by slot
+  dump->filter_cols.resize(col_names.size());
+  for (size_t c = 0; c < col_names.size(); ++c) {
+    DumpData::Col& col = dump->filter_cols[c];
+    col.name = col_names[c];
+    col.values.assign(dump->n_docs, 0);
+    col.is_null.assign(dump->n_docs, 1);
+  }
+  for (const Doc& d : docs)
+    for (const auto& f : d.filters) {
+      DumpData::Col& col = dump->filter_cols[f.first];
+      const uint8_t type = f.second.first;
+      if (type == 0) continue;
+      if (col.type == 0) col.type = type;
+      if (col.type != type)
+        return fail(MGX_ERR_NOT_IMPLEMENTED, "filter column \"" + col.name + "\" holds values of more than one type");
+      col.is_null[d.id - lo] = 0;
+      col.values[d.id - lo] = f.second.second.first;
+    }
+  for (DumpData::Col& col : dump->filter_cols) {
+    if (col.type != 11) continue;  // strings: bytes by slot
+    col.str_off.assign(dump->n_docs + 1, 0);
+    uint64_t at = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> where(dump->n_docs, {0, 0});
+    for (const Doc& d : docs)
+      for (const auto& f : d.filters)
+        if (&dump->filter_cols[f.first] == &col && f.second.first == 11) where[d.id - lo] = f.second.second;
+    for (uint64_t sl = 0; sl < dump->n_docs; ++sl) {
+      col.str_off[sl] = at;
+      at += where[sl].second;
+    }
+    col.str_off[dump->n_docs] = at;
+    col.str_bytes.assign(at + 1, 0);
+    for (uint64_t sl = 0; sl < dump->n_docs; ++sl)
+      if (where[sl].second) std::memcpy(col.str_bytes.data() + col.str_off[sl], dr.p + where[sl].first, where[sl].second);
+  }
+  // ---- columns: from the texts when the store kept them (tf and doc lengths need them), else the index's doc ids alone ----
+  if (tbytes != 0) {
+    mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, dump->info.ngram_size, dump->info.kanji_ngram_size,
+                        dump->info.cross_boundary_ngrams, 0};
+    Columns* built = nullptr;
+    const int rc = BuildColumns(bp, dump->text_bytes.data(), dump->text_off.data(), lo, dump->n_docs, &built, err);
+    if (rc != MGX_OK) return rc;
+    std::unique_ptr<Columns, void (*)(Columns*)> guard(built, DestroyColumns);
+    // the dump's own index must say the same: same grams, same lists
+    if (built->sorted_keys != index_cols->sorted_keys) return fail(MGX_ERR_INVALID_ARGUMENT, "the dump's index and its stored texts disagree (different n-grams)");
+    const uint64_t P = built->offsets.back();
+    if (index_cols->offsets != built->offsets || !std::equal(built->docids.begin(), built->docids.begin() + P, index_cols->docids.begin()))
+      return fail(MGX_ERR_INVALID_ARGUMENT, "the dump's index and its stored texts disagree (different posting lists)");
+    dump->cols = guard.release();
+    dump->has_scores = true;
+  } else {
+    Columns* c = index_cols.release();
+    // (re-based to the common doc range)
+    c->first_doc_id = lo;
+    c->n_docs = dump->n_docs;
+    dump->cols = c;
+  }
+  *out = dump.release();
+  return MGX_OK;
+}
+
+void DumpDestroy(DumpData* d) { delete d; }
+void DumpView(const DumpData* d, mgx_dump_view* v) {
+  v->table_name = d->table.c_str();
+  v->index_info = d->info;
+  v->first_doc_id = d->first_doc_id;
+  v->n_docs = d->n_docs;
+  v->n_existing = d->n_existing;
+  v->exists = d->exists.data();
+  v->text_bytes = d->text_bytes.data();
+  v->text_off = d->text_off.data();
+  v->n_filter_columns = static_cast<uint32_t>(d->filter_cols.size());
+  v->has_texts = d->has_scores ? 1 : 0;
+}
+bool DumpFilterColumn(const DumpData* d, uint32_t i, mgx_dump_filter_column* o) {
+  if (i >= d->filter_cols.size()) return false;
+  const DumpData::Col& c = d->filter_cols[i];
+  o->name = c.name.c_str();
+  o->value_type = c.type;
+  o->values = c.values.data();
+  o->is_null = c.is_null.data();
+  o->string_bytes = c.str_bytes.empty() ? nullptr : c.str_bytes.data();
+  o->string_off = c.str_off.empty() ? nullptr : c.str_off.data();
+  return true;
+}
+Columns* DumpTakeColumns(DumpData* d) {
+  Columns* c = d->cols;
+  d->cols = nullptr;
+  return c;
+}
+
 }  // namespace mgx

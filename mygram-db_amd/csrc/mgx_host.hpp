@@ -16,6 +16,12 @@ int ColumnsFromMgix(const uint8_t* data, uint64_t len, uint32_t first_doc_id, ui
 void ColumnsView(const Columns* c, mgx_columns_view* v);
 bool ColumnsLookup(const Columns* c, const uint8_t* gram, size_t len, uint32_t* id);
 void DestroyColumns(Columns* c);
+struct DumpData;
+int DumpOpen(const uint8_t* data, uint64_t len, const char* table, DumpData** out, std::string* err);
+void DumpDestroy(DumpData* d);
+void DumpView(const DumpData* d, mgx_dump_view* v);
+bool DumpFilterColumn(const DumpData* d, uint32_t i, mgx_dump_filter_column* o);
+Columns* DumpTakeColumns(DumpData* d);
 
 // thread-local last-error message
 void SetError(const std::string& msg);

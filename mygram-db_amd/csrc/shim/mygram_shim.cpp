@@ -314,6 +314,79 @@ std::unique_ptr<Index> Index::Adopt(mgx_columns* columns, mgx_index* device_inde
   return idx;
 }
 
+std::unique_ptr<Index> Index::FromDump(const void* data, size_t len, const std::string& table, std::string* error,
+                                       int device) {
+  auto fail = [&](const std::string& msg) {
+    if (error) *error = msg;
+    return std::unique_ptr<Index>();
+  };
+  mgx_dump* dump = nullptr;
+  if (mgx_dump_open(static_cast<const uint8_t*>(data), len, table.empty() ? nullptr : table.c_str(), &dump) != MGX_OK)
+    return fail(mgx_last_error());
+  std::unique_ptr<mgx_dump, void (*)(mgx_dump*)> guard(dump, mgx_dump_destroy);
+  mgx_dump_view v{};
+  mgx_dump_view_get(dump, &v);
+  const mgx_mgix_info& info = v.index_info;
+  auto idx = std::make_unique<Index>(info.ngram_size, info.kanji_ngram_size, 0.0, info.cross_boundary_ngrams != 0,
+                                     info.normalize_nfkc != 0, std::string(info.normalize_width), info.normalize_lower != 0, device);
+  Impl* im = idx->impl_.get();
+  if (mgx_dump_take_columns(dump, &im->cols) != MGX_OK || im->cols == nullptr) return fail(mgx_last_error());
+  mgx_columns_view_get(im->cols, &im->view);
+  const auto& cv = im->view;
+  im->finalized = true;
+  if (cv.n_docs == 0) return fail("the dump's table holds no document");
+  mgx_index_desc d{sizeof(mgx_index_desc), MGX_ABI_VERSION, device, 0, cv.first_doc_id, cv.n_docs, cv.n_grams,
+                   cv.offsets,              cv.docids,       cv.tf,  cv.doc_len, 0.0,
+                   cv.tf_overflow_pos,      cv.tf_overflow_val, cv.n_tf_overflow};
+  if (mgx_index_create(&d, &im->dev) != MGX_OK) return fail(mgx_last_error());
+  if (v.has_texts && mgx_index_attach_text(im->dev, v.text_bytes, v.text_off) != MGX_OK) return fail(mgx_last_error());
+  // DocumentStore::GetAllDocIds: the ids the store holds (deleted ids leave gaps in the range)
+  if (v.n_existing != v.n_docs) {
+    std::vector<DocId> existing;
+    for (uint64_t i = 0; i < v.n_docs; ++i)
+      if (v.exists[i]) existing.push_back(v.first_doc_id + static_cast<DocId>(i));
+    im->has_gaps = true;
+    if (mgx_index_add_filter_bitmap(im->dev, existing.data(), existing.size(), &im->exists_bitmap) != MGX_OK)
+      return fail(mgx_last_error());
+  }
+  g_last_finalized.store(idx.get());
+  for (uint32_t c = 0; c < v.n_filter_columns; ++c) {
+    mgx_dump_filter_column fc{};
+    if (mgx_dump_filter_column_get(dump, c, &fc) != MGX_OK) return fail(mgx_last_error());
+    std::vector<storage::FilterValue> vals(v.n_docs);
+    for (uint64_t i = 0; i < v.n_docs; ++i) {
+      if (fc.is_null[i]) continue;
+      const uint64_t w = fc.values[i];
+      switch (fc.value_type) {
+        case 1: vals[i] = w != 0; break;
+        case 2: vals[i] = static_cast<int8_t>(static_cast<int64_t>(w)); break;
+        case 3: vals[i] = static_cast<uint8_t>(w); break;
+        case 4: vals[i] = static_cast<int16_t>(static_cast<int64_t>(w)); break;
+        case 5: vals[i] = static_cast<uint16_t>(w); break;
+        case 6: vals[i] = static_cast<int32_t>(static_cast<int64_t>(w)); break;
+        case 7: vals[i] = static_cast<uint32_t>(w); break;
+        case 8: vals[i] = static_cast<int64_t>(w); break;
+        case 9: vals[i] = static_cast<uint64_t>(w); break;
+        case 10: vals[i] = storage::TimeValue{static_cast<int64_t>(w)}; break;
+        case 11:
+          vals[i] = std::string(reinterpret_cast<const char*>(fc.string_bytes + fc.string_off[i]),
+                                static_cast<size_t>(fc.string_off[i + 1] - fc.string_off[i]));
+          break;
+        case 12: {
+          double dv;
+          std::memcpy(&dv, &w, 8);
+          vals[i] = dv;
+          break;
+        }
+        default: break;
+      }
+    }
+    const std::string err = idx->AddFilterColumn(fc.name, vals);
+    if (!err.empty()) return fail(err);
+  }
+  return idx;
+}
+
 bool Index::AddDocument(DocId doc_id, std::string_view text) {
   std::lock_guard<std::mutex> lock(impl_->mu);
   if (impl_->finalized) {

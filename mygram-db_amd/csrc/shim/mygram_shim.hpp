@@ -193,6 +193,14 @@ class Index {
   static std::unique_ptr<Index> Adopt(mgx_columns* columns, mgx_index* device_index, int ngram_size,
                                       int kanji_ngram_size, bool cross_boundary_ngrams);
 
+  // A table of a reference dump (DUMP SAVE, "MGDB" v2: src/storage/dump_format_v2.cpp:520-770) as a searchable, ranking
+  // Index: what Index::LoadFromStream + DocumentStore::LoadFromStream restore in the reference (dump_format_internal.cpp:
+  // 285-305) — postings, normalized texts (BM25 needs them, as in the reference), the store's id set (the NOT universe)
+  // and every filter column (FILTER conditions, FACET). `table` empty: the first table. Normalisation settings come from
+  // the dump's index header. nullptr + *error on failure.
+  static std::unique_ptr<Index> FromDump(const void* data, size_t len, const std::string& table, std::string* error,
+                                         int device = 0);
+
   // Doc-range shards (one Index per GPU): the table-wide BM25Stats and every gram's table-wide posting size, by this
   // shard's gram ids — what idf must be computed from so that all ranks score identically. Returns "" or an error.
   std::string SetGlobalStats(uint64_t total_docs, double avg_doc_length, std::vector<uint64_t> global_posting_sizes);

@@ -57,6 +57,21 @@ int mgxs_table_adopt(mgx_columns* columns, mgx_index* device_index, int ngram_si
   }
 }
 
+int mgxs_table_from_dump(const uint8_t* data, uint64_t len, const char* table_name, int device, mgxs_table** out) {
+  if (out) *out = nullptr;
+  if (!data || !out) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_from_dump: null argument");
+  try {
+    std::string err;
+    auto t = std::make_unique<mgxs_table>();
+    t->index = Index::FromDump(data, len, table_name ? table_name : "", &err, device);
+    if (!t->index) return Fail(MGX_ERR_INVALID_ARGUMENT, err);
+    *out = t.release();
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 int mgxs_table_set_global_stats(mgxs_table* table, uint64_t total_docs, double avg_doc_length,
                                 const uint64_t* global_posting_sizes, uint64_t n_grams) {
   if (!table || (n_grams && !global_posting_sizes))

@@ -546,6 +546,60 @@ class Index:
         self._global_dict = None
         return self
 
+    @classmethod
+    def from_dump(cls, data, table=None, device=0, dense_threshold=0.0):
+        """A table of a reference dump (DUMP SAVE, "MGDB" v2: src/storage/dump_format_v2.cpp) as a ranking index: columns
+        built from the dump's stored texts (and checked against its own MGIX index), texts attached, filter columns kept in
+        `dump_filter_columns` [(name, value type 1..12, values, is_null, strings)]; `exists` marks the doc ids the store
+        holds."""
+        L = load()
+        raw = bytes(data)
+        h = C.c_void_p()
+        check(L.mgx_dump_open(raw, len(raw), table.encode() if table else None, C.byref(h)))
+        try:
+            v = _capi.DumpView()
+            check(L.mgx_dump_view_get(h, C.byref(v)))
+            n = int(v.n_docs)
+            info = v.index_info
+            self = cls.__new__(cls)
+            self.table_name = v.table_name.decode()
+            self.ngram_size, self.kanji_ngram_size = int(info.ngram_size), int(info.kanji_ngram_size)
+            self.cross_boundary = bool(info.cross_boundary_ngrams)
+            self.normalize_nfkc, self.normalize_lower = bool(info.normalize_nfkc), bool(info.normalize_lower)
+            self.normalize_width = info.normalize_width.decode()
+            self.exists = np.ctypeslib.as_array(C.cast(v.exists, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+            toff = np.ctypeslib.as_array(C.cast(v.text_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+            tb = np.ctypeslib.as_array(C.cast(v.text_bytes, C.POINTER(C.c_uint8)), shape=(int(toff[-1]) + 16,)).copy()
+            self.corpus = Corpus(tb, toff)
+            self.dump_filter_columns = []
+            for i in range(int(v.n_filter_columns)):
+                fc = _capi.DumpFilterColumn()
+                check(L.mgx_dump_filter_column_get(h, i, C.byref(fc)))
+                vals = np.ctypeslib.as_array(C.cast(fc.values, C.POINTER(C.c_uint64)), shape=(max(n, 1),))[:n].copy()
+                nul = np.ctypeslib.as_array(C.cast(fc.is_null, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].copy()
+                strings = None
+                if fc.value_type == 11:
+                    so = np.ctypeslib.as_array(C.cast(fc.string_off, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+                    sb = np.ctypeslib.as_array(C.cast(fc.string_bytes, C.POINTER(C.c_uint8)), shape=(int(so[-1]) + 1,)).tobytes()
+                    strings = [sb[int(so[k]): int(so[k + 1])] for k in range(n)]
+                self.dump_filter_columns.append((fc.name.decode(), int(fc.value_type), vals, nul.astype(bool), strings))
+            ch = C.c_void_p()
+            check(L.mgx_dump_take_columns(h, C.byref(ch)))
+            cols = Columns.__new__(Columns)
+            cols.ngram_size, cols.kanji_ngram_size, cols.cross_boundary = self.ngram_size, self.kanji_ngram_size, self.cross_boundary
+            cols._adopt(ch)
+            has_texts = bool(v.has_texts)
+        finally:
+            L.mgx_dump_destroy(h)
+        self.columns = cols
+        self.device_index = DeviceIndex(cols, device, dense_threshold, with_scoring=has_texts)
+        self._text_attached = False
+        self.total_docs = cols.bm25_doc_count if has_texts else 0
+        self.avg_doc_length = cols.avg_doc_length() if has_texts else 0.0
+        self._global_sizes = None
+        self._global_dict = None
+        return self
+
     # ---- dictionary -------------------------------------------------------------------------------------------
     def posting_size(self, gram):
         if self._global_dict is not None:

@@ -131,3 +131,39 @@ def test_random_typed_columns_conditions_and_facets_match_the_oracle():
     want = F.apply_filters_with_bitmap(sorted(base), [("flag", "=", "1")], columns)
     exp = {F.display_string(k0): v for k0, v in F.facet_counts(want, columns["category"]).items()}
     assert matched == len(want) and dict(page) == exp
+
+
+def test_a_table_loaded_from_a_dump_v2_file_ranks_filters_and_facets():
+    """Index::FromDump / engine.Index.from_dump on tests/golden/dump_v2_small.bin (a DUMP SAVE file written from the
+    reference's writer code: 37 live docs of ids 1..40, bigram index, status / category / score / flag columns): SORT _score
+    equals an index built from the same texts, NOT keeps to the ids the store holds, FILTER and FACET read the dump's
+    filter values."""
+    from mygram_db_amd import _shim_capi as S
+    raw = open(os.path.join(HERE, "golden", "dump_v2_small.bin"), "rb").read()
+    exp = json.load(open(os.path.join(HERE, "golden", "dump_v2_expected.json"), encoding="utf-8"))
+    texts = [exp["texts"].get(str(i + 1), "") for i in range(40)]
+    loaded = mg.Index.from_dump(raw, "app_db.articles")
+    direct = mg.Index(texts=texts, first_doc_id=1, ngram_size=2, kanji_ngram_size=2)
+    assert loaded.table_name == "app_db.articles" and loaded.total_docs == direct.total_docs
+    qs = [Query(["alpha"], sort_score=True, limit=10), Query(["tokyo", "data"], sort_score=True, limit=5),
+          Query(["東京"], sort_score=True, limit=10), Query(["search"], ["beta"], limit=20, descending=False)]
+    for a, b in zip(loaded.search_batch(qs), direct.search_batch(qs)):
+        assert a.total == b.total and a.docs.tolist() == b.docs.tolist() and np.array_equal(a.scores, b.scores)
+    t = S.Table.from_dump(raw, "app_db.articles")
+    live = set(exp["ids"])
+    # a search + FILTER conditions on the dump's columns
+    total, docs, _ = t.search(["alpha"], conditions=[("status", "=", "1")], descending=False, limit=40)
+    want = [d for d in exp["ids"] if "alpha" in texts[d - 1] and d % 10 != 0 and d % 3 == 1]
+    assert docs.tolist() == want and total == len(want)
+    total, docs, _ = t.search(["a"], conditions=[("score", ">=", "5"), ("category", "!=", "tech")], descending=False, limit=40)
+    want = [d for d in exp["ids"] if "a" in texts[d - 1] and d % 10 != 0 and d / 4.0 >= 5 and ["tech", "food", "music"][d % 3] != "tech"]
+    assert docs.tolist() == want
+    # FACET over every document of the store: deleted ids (7, 8, 23) are not documents; NULL values are not counted
+    matched, n_values, page = t.facet("category")
+    assert matched == len(live)
+    cnt = {}
+    for d in exp["ids"]:
+        if d % 10 != 0:
+            c = ["tech", "food", "music"][d % 3].encode()
+            cnt[c] = cnt.get(c, 0) + 1
+    assert dict(page) == cnt and n_values == 3
