@@ -1118,6 +1118,45 @@ __device__ __forceinline__ void wave_scatter_segment(const uint32_t* __restrict_
   }
 }
 
+// wave_scatter_segment with four 16-byte loads per lane in flight (1024 postings per wave and step): a long segment — a
+// dense list without a bitmap row holds thousands of postings per tile — was a chain of one load round trip per 256.
+__device__ __forceinline__ void wave_scatter_segment_x4(const uint32_t* __restrict__ ids, uint64_t lo, uint64_t hi,
+                                                        uint32_t tile_first_doc, uint32_t* __restrict__ bm32) {
+  const uint64_t p0 = lo & ~3ull;
+  for (uint64_t base = p0; base < hi; base += 4ull * 64 * 4) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t p = base + (static_cast<uint64_t>(u) * 64 + lane_id()) * 4;
+      v[u] = p < hi ? *reinterpret_cast<const uint4*>(ids + p) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t p = base + (static_cast<uint64_t>(u) * 64 + lane_id()) * 4;
+      if (p >= hi) continue;
+      const uint32_t e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      // (ids merged per 32-bit word before the ds_or: merging per 64-bit word and ds_or_b64 measured slower, 3.4 -> 4.4 ms
+      // of staging on the lists-only benchmark batch)
+      uint32_t curw = 0xFFFFFFFFu, curm = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p + j >= lo && p + j < hi) {
+          const uint32_t bit = e[j] - tile_first_doc;
+          const uint32_t w = bit >> 5, m = 1u << (bit & 31);
+          if (w == curw) {
+            curm |= m;
+          } else {
+            if (curm) atomicOr(&bm32[curw], curm);
+            curw = w;
+            curm = m;
+          }
+        }
+      }
+      if (curm) atomicOr(&bm32[curw], curm);
+    }
+  }
+}
+
 // This lane's four 64-bit words (256 doc slots) of one operand for `tile`; for scored posting-list operands
 // *seg_rel = list-relative index of the tile's first posting (the rank base of the tf column).
 __device__ __forceinline__ void wave_fetch_operand(const DevIndex& ix, const DevBatch& bt, const DevLeaf lf,
@@ -2694,11 +2733,12 @@ __global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, D
           a = lower_bound_u32(ix.docids, l0, l1, tile_first);
           e = lower_bound_u32(ix.docids, a, l1, tile_first + kTileDocs);
         }
+        if (MGX_ABLATE(bt, 4u)) e = a;  // (timing ablation: no scatter)
         if (lane == 0) seg[j] = a;
 #pragma unroll
         for (int k = 0; k < 4; ++k) b[lane * 4 + k] = 0;
         wave_lds_sync();
-        wave_scatter_segment(ix.docids, a, e, static_cast<uint32_t>(tile_first), reinterpret_cast<uint32_t*>(b));
+        wave_scatter_segment_x4(ix.docids, a, e, static_cast<uint32_t>(tile_first), reinterpret_cast<uint32_t*>(b));
         wave_lds_sync();
         if ((need_rank >> j) & 1u) {  // per-word prefix popcounts: rank of a member = prefix[word] + bits below it
           uint32_t c[4], mine = 0;
@@ -2728,6 +2768,7 @@ __global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, D
     wave_lds_sync();
     // ---- the driver's candidates, kMergeU per lane and step; survivors wait in the queue until 64 can be scored at once --
     uint32_t n_wait = 0;  // wave-uniform: queued survivors (slot in tile << 16 | driver posting offset in the tile segment)
+    if (MGX_ABLATE(bt, 2u)) db = da;  // (timing ablation: staging only)
     for (uint64_t p0 = da; p0 < db || n_wait != 0; p0 += 64 * kMergeU) {
       if (p0 < db) {
         bool alive[kMergeU];
@@ -2741,23 +2782,18 @@ __global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, D
         for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
           const uint32_t ins = prog[pc];
           const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
-          uint64_t any = 0;
-          uint32_t c = 0;
+          if (op == kOpCount) {  // (the only place the alive lanes are counted: a ballot per candidate row)
+            uint32_t c = 0;
 #pragma unroll
-          for (int u = 0; u < kMergeU; ++u) {
-            const uint64_t am = __ballot(alive[u]);
-            any |= am;
-            c += static_cast<uint32_t>(__popcll(am));
-          }
-          if (op == kOpCount) {
+            for (int u = 0; u < kMergeU; ++u) c += static_cast<uint32_t>(__popcll(__ballot(alive[u])));
             cnt[0] += (arg & 1u) ? c : 0;
             cnt[1] += (arg & 2u) ? c : 0;
             cnt[2] += (arg & 4u) ? c : 0;
             cnt[3] += (arg & 8u) ? c : 0;
+            if (c == 0) break;  // nothing left: the rest of the program counts zeros
             continue;
           }
           if (arg == driver_leaf) continue;
-          if (any == 0) break;
           const uint64_t* const ob = bm + static_cast<size_t>(slot_of[arg]) * kWordsPerTile;
 #pragma unroll
           for (int u = 0; u < kMergeU; ++u) {
@@ -2777,6 +2813,10 @@ __global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, D
         wave_lds_sync();
       }
       // ---- BM25 of the queued survivors, 64 at a time (the last, partial round when the segment is exhausted) ----------
+      if (MGX_ABLATE(bt, 1u)) {  // (timing ablation: no scoring)
+        cnt_res += n_wait;
+        n_wait = 0;
+      }
       while (n_wait >= 64 || (p0 + 64 * kMergeU >= db && n_wait != 0)) {
         const uint32_t take = n_wait < 64 ? n_wait : 64;
         const bool alive = lane < take;
@@ -2790,38 +2830,104 @@ __global__ __launch_bounds__(kMergeBlock) void merge_score_kernel(DevIndex ix, D
         const uint32_t slot = tile * kTileDocs + sl;
         const uint32_t d = static_cast<uint32_t>(tile_first) + sl;
         double score = 0.0;
-        uint32_t dl = 0;
-        if (alive) {
-          dl = ix.dl8[slot];
-          if (dl == 255u) dl = ix.doc_len[slot];
-        }
-        const double length_norm = q.one_minus_b + q.b * static_cast<double>(dl) / q.avgdl_clamped;
-        for (uint32_t i = 0; i < q.n_score; ++i) {
-          const DevScoreTerm st = bt.score_terms[q.score_begin + i];
-          const DevLeaf lf = leaf[st.leaf];
-          uint32_t tfv = 0;
-          if (alive) {
-            if (st.leaf == driver_leaf) {
-              tfv = posting_tf(ix, p);
-            } else if (lf.kind == kLeafList) {
-              const uint32_t j = slot_of[st.leaf];
-              const uint64_t word = bm[static_cast<size_t>(j) * kWordsPerTile + w];
-              if (word & bit) {
-                const uint32_t rank = pref[static_cast<size_t>(j) * kWordsPerTile + w] +
-                                      static_cast<uint32_t>(__popcll(word & (bit - 1ull)));
-                tfv = posting_tf(ix, seg[j] + rank);
+        constexpr uint32_t kUn = 4;
+        if (q.n_score <= kUn) {
+          // every gather of the round — doc length and each term's tf byte — is issued before any of them is looked at:
+          // with the loads inside a loop over the terms the round was a chain of one memory round trip per term
+          uint32_t dl = alive ? static_cast<uint32_t>(ix.dl8[slot]) : 0u;
+          uint32_t raw[kUn];   // the byte (or nibble byte) as loaded
+          uint32_t how[kUn];   // 0 absent, 1 tf byte of a posting (driver / ranked list), 2 nibble byte
+          uint64_t at[kUn];    // posting index (how == 1)
+          double idf[kUn];
+#pragma unroll
+          for (uint32_t i = 0; i < kUn; ++i) {
+            raw[i] = 0;
+            how[i] = 0;
+            at[i] = 0;
+            idf[i] = 0.0;
+            if (i < q.n_score) {  // wave-uniform
+              const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+              const DevLeaf lf = leaf[st.leaf];
+              idf[i] = st.idf;
+              if (alive) {
+                if (st.leaf == driver_leaf) {
+                  how[i] = 1;
+                  at[i] = p;
+                } else if (lf.kind == kLeafList) {
+                  const uint32_t j = slot_of[st.leaf];
+                  const uint64_t word = bm[static_cast<size_t>(j) * kWordsPerTile + w];
+                  if (word & bit) {
+                    how[i] = 1;
+                    at[i] = seg[j] + pref[static_cast<size_t>(j) * kWordsPerTile + w] +
+                            static_cast<uint32_t>(__popcll(word & (bit - 1ull)));
+                  }
+                } else if (lf.kind == kLeafGramBitmap) {
+                  how[i] = 2;
+                  at[i] = static_cast<uint64_t>(lf.b) * ix.nib_row_stride + (slot >> 1);
+                }
+                if (how[i] == 1) raw[i] = ix.tf[at[i]];
+                else if (how[i] == 2) raw[i] = ix.tfnib[at[i]];
               }
-            } else if (lf.kind == kLeafGramBitmap) {
-              const uint32_t nb = ix.tfnib[static_cast<uint64_t>(lf.b) * ix.nib_row_stride + (slot >> 1)];
-              tfv = (nb >> ((slot & 1u) * 4u)) & 15u;
-              if (tfv == 15u) tfv = exact_tf(ix, lf.a, lf.row, slot);
             }
           }
-          if (tfv != 0) {
-            const double tf = static_cast<double>(tfv);
-            const double numerator = tf * q.k1_plus_1;
-            const double denominator = tf + q.k1 * length_norm;
-            score += st.idf * numerator / denominator;
+          if (dl == 255u) dl = ix.doc_len[slot];
+          const double length_norm = q.one_minus_b + q.b * static_cast<double>(dl) / q.avgdl_clamped;
+#pragma unroll
+          for (uint32_t i = 0; i < kUn; ++i) {
+            if (i < q.n_score) {
+              uint32_t tfv = 0;
+              if (how[i] == 1) {
+                tfv = raw[i];
+                if (tfv == 255u && ix.n_tf_ovf != 0) tfv = posting_tf(ix, at[i]);  // the saturated byte: the side table
+              } else if (how[i] == 2) {
+                tfv = (raw[i] >> ((slot & 1u) * 4u)) & 15u;
+                if (tfv == 15u) {
+                  const DevLeaf lf = leaf[bt.score_terms[q.score_begin + i].leaf];
+                  tfv = exact_tf(ix, lf.a, lf.row, slot);
+                }
+              }
+              if (tfv != 0) {
+                const double tf = static_cast<double>(tfv);
+                const double numerator = tf * q.k1_plus_1;
+                const double denominator = tf + q.k1 * length_norm;
+                score += idf[i] * numerator / denominator;
+              }
+            }
+          }
+        } else {
+          uint32_t dl = 0;
+          if (alive) {
+            dl = ix.dl8[slot];
+            if (dl == 255u) dl = ix.doc_len[slot];
+          }
+          const double length_norm = q.one_minus_b + q.b * static_cast<double>(dl) / q.avgdl_clamped;
+          for (uint32_t i = 0; i < q.n_score; ++i) {
+            const DevScoreTerm st = bt.score_terms[q.score_begin + i];
+            const DevLeaf lf = leaf[st.leaf];
+            uint32_t tfv = 0;
+            if (alive) {
+              if (st.leaf == driver_leaf) {
+                tfv = posting_tf(ix, p);
+              } else if (lf.kind == kLeafList) {
+                const uint32_t j = slot_of[st.leaf];
+                const uint64_t word = bm[static_cast<size_t>(j) * kWordsPerTile + w];
+                if (word & bit) {
+                  const uint32_t rank = pref[static_cast<size_t>(j) * kWordsPerTile + w] +
+                                        static_cast<uint32_t>(__popcll(word & (bit - 1ull)));
+                  tfv = posting_tf(ix, seg[j] + rank);
+                }
+              } else if (lf.kind == kLeafGramBitmap) {
+                const uint32_t nb = ix.tfnib[static_cast<uint64_t>(lf.b) * ix.nib_row_stride + (slot >> 1)];
+                tfv = (nb >> ((slot & 1u) * 4u)) & 15u;
+                if (tfv == 15u) tfv = exact_tf(ix, lf.a, lf.row, slot);
+              }
+            }
+            if (tfv != 0) {
+              const double tf = static_cast<double>(tfv);
+              const double numerator = tf * q.k1_plus_1;
+              const double denominator = tf + q.k1 * length_norm;
+              score += st.idf * numerator / denominator;
+            }
           }
         }
         wave_topk_offer(tk, alive, score_key(score, desc), desc ? d : ~d);

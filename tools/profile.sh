@@ -9,6 +9,7 @@ set -u
 TAG=${1:?tag}; KERNEL=${2:-bitmap_score_kernel}; shift; shift || true
 for kv in "$@"; do export "$kv"; done
 export MGX_BENCH_CPU_SECONDS=${MGX_BENCH_CPU_SECONDS:-0}
+export MGX_BENCH_NO_POINTS=1   # (the extra operating points of bench.py run four batches time-sliced: not what is profiled)
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
