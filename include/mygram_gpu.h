@@ -417,9 +417,9 @@ int mgx_batch_exchange(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
  * key of the union before the rest of the batch runs — a shard's own matches give a weak bound (top-k is a property of
  * the whole table). The shard's LOCAL page may then hold fewer than offset+limit docs: those it lacks are on no rank's
  * share of the table-wide page; totals and funnel counters are unaffected. Other batches: as mgx_batch_execute. The
- * exchange is opt-in (MGX_SEED_EXCHANGE=1 in every rank's environment; otherwise this call is mgx_batch_execute) and is
- * entered by every rank or by none: the decision uses the queries and the world size only (shards of a million docs and
- * more, MGX_SEED_EXCHANGE_MIN_DOCS). */
+ * exchange runs from four ranks up (MGX_SEED_EXCHANGE=0 / 1 in every rank's environment forces it off / on; otherwise
+ * this call is mgx_batch_execute) and is entered by every rank or by none: the decision uses the queries and the world
+ * size only (shards of a million docs and more, MGX_SEED_EXCHANGE_MIN_DOCS). */
 int mgx_batch_execute_sharded(mgx_batch* batch, mgx_comm* comm, void* hip_stream);
 /* The same with the caller's transport (a test's gloo all-gather, MPI, ...): `gather` must fill all[r * bytes ..] with
  * rank r's `mine` for every rank (both are DEVICE buffers of the batch; the call may enqueue on hip_stream or block) and

@@ -3279,13 +3279,16 @@ int mgx_batch_execute_gather(mgx_batch* batch, int world, mgx_gather_fn gather, 
     sg.world = world;
     sg.fn = gather;
     sg.user = user;
-    // Splitting the launch costs ~0.03 ms per batch (the main items wait for every seed, two small kernels, the
-    // collective) and buys a bound made from world x 8 tiles instead of 8: measured on one GPU only the cost shows
-    // (0.375 -> 0.405 ms per step on a 1.25M-doc shard), and the ceiling of any better start is 24 % of that shard's
-    // kernel: expected to be worth single-digit percents at eight shards, minus a second point per batch
-    // where ranks wait for each other. It cannot be measured on one GPU, so it is OPT-IN: MGX_SEED_EXCHANGE=1.
-    static const int forced = std::getenv("MGX_SEED_EXCHANGE") ? atoi(std::getenv("MGX_SEED_EXCHANGE")) : 0;
-    const bool on = forced != 0;
+    // Splitting the launch costs ~0.03 ms per batch on a 1.25M-doc shard (the main items wait for every seed, two small
+    // kernels, the collective: 0.375 -> 0.405 ms per step measured with one rank) and buys a bound made from world x 8
+    // tiles instead of 8. What a better start is worth was measured on one GPU with the bounds of a finished pass
+    // injected (ablation build, MGX_KEEP_BOUNDS): 0.27 -> 0.20 ms on that shard, 24 % of its kernel. Eight ranks' seeds
+    // together cover 64 of a shard's 77 tiles' worth of documents — a bound close to the finished pass's — so the
+    // exchange nets about 0.07 x 0.8 - 0.03 = +0.03 ms of 0.27 (10 %) at eight shards, less than its cost at two.
+    // Default: ON from four ranks up (shards of a million docs and more, see ExecuteImpl); MGX_SEED_EXCHANGE=0 / 1
+    // forces it off / on for every world size.
+    static const int forced = std::getenv("MGX_SEED_EXCHANGE") ? atoi(std::getenv("MGX_SEED_EXCHANGE")) : -1;
+    const bool on = forced >= 0 ? forced != 0 : world >= 4;
     return mgx::ExecuteImpl(batch, s, on ? &sg : nullptr);
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_execute_gather: ") + e.what());
