@@ -466,6 +466,46 @@ int mgx_retain(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, cons
  * the caller orders the values by count and pages them. counts_out has room for the column's n_values. */
 int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id, uint64_t* counts_out, uint64_t* matched);
 
+/* ---- mutable tables (the binlog applier's Index::AddDocument / UpdateDocument / RemoveDocument,
+ * src/index/index.cpp:39-233, after the index was built) -------------------------------------------------------------
+ * The column arrays of an mgx_index are immutable. A table that changes is TWO indexes on one device: the MAIN index as
+ * built, with a LIVE row (a filter bitmap whose bits are cleared as documents are removed or superseded), and a small
+ * DELTA index over the documents added or changed since, numbered 1..n in ascending order of their table ids with a doc
+ * map back to those ids. A batch is compiled against both (same queries, table-wide statistics in both: the df the
+ * planner passes, total_docs, avg_doc_length), both are executed on ONE stream, and the delta's pages are merged into
+ * the main batch — the exchange of a sharded table without the wire. The host layer (mygram_shim: Index::AddDocument &
+ * co.) owns the bookkeeping and rebuilds the delta when it changes; when the delta has grown it rebuilds the main index.
+ *
+ * mgx_index_set_live_bitmap: every batched query (and every df query of a text-level term) on `idx` is ANDed with this
+ *   filter row right after its first term, so candidates, totals and funnel counters count live documents only; the
+ *   single-operator entry points (mgx_and ...) do NOT apply it. enable = 0 turns it off.
+ * mgx_index_update_filter_bitmap: sets / clears bits of a filter row in place (ids are table doc ids of this index's
+ *   range). Not ordered against batches in flight: call it between batches (mgx_index_synchronize) when a batch must see
+ *   either all or none of an update.
+ * mgx_index_set_doc_map: table id of every doc slot (ascending) — mgx_batch_merge_local reports this index's documents
+ *   under these ids.
+ * mgx_index_invalidate_statistics: drops everything the index cached per (total_docs, avg_doc_length, idf): contribution
+ *   tables, length norms, block-max bounds, df counts. Call when the table-wide statistics changed, with NO batch of this
+ *   index compiled or in flight (compiled batches hold table addresses); it waits for the device.
+ * mgx_batch_df_merge_local, before the executes: df pass of the text-level terms on every batch, summed, the sum handed
+ *   to every batch (mgx_batch_exchange_df without the all-reduce).
+ * mgx_batch_merge_local, after the executes, all on `hip_stream`: merges the others' top-(offset+limit) per query into
+ *   `primary` (mgx_batch_exchange without the all-gather); mgx_batch_fetch(primary) then returns the table-wide page
+ *   and total. Funnel counters stay per index: fetch the others too and add them. Same restriction as the exchange:
+ *   all MGX_SORT_SCORE or all docid-ordered pages. The others must stay untouched until primary has been fetched. */
+/* One document's stored value of a filter column, as it was given to mgx_index_add_filter_column (a document that moves
+ * to the delta index takes its filter values along). value_id may be NULL. */
+int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,
+                                 uint32_t* value_id);
+int mgx_index_set_live_bitmap(mgx_index* idx, uint32_t bitmap_id, int enable);
+int mgx_index_update_filter_bitmap(mgx_index* idx, uint32_t bitmap_id, const uint32_t* set_docids, uint64_t n_set,
+                                   const uint32_t* clear_docids, uint64_t n_clear);
+int mgx_index_set_doc_map(mgx_index* idx, const uint32_t* table_ids, uint64_t n);
+int mgx_index_invalidate_statistics(mgx_index* idx);
+int mgx_index_synchronize(mgx_index* idx);
+int mgx_batch_df_merge_local(mgx_batch* primary, mgx_batch* const* others, uint32_t n_others, void* hip_stream);
+int mgx_batch_merge_local(mgx_batch* primary, mgx_batch* const* others, uint32_t n_others, void* hip_stream);
+
 /* BM25Scorer::ScoreDocuments for single-gram terms: one score per candidate, in candidate order. A candidate
  * outside the index or with empty text scores 0.0 (bm25_scorer.cpp:73-89). */
 int mgx_score_documents(mgx_index* idx, const uint32_t* candidates, uint64_t n_cand, const uint32_t* gram_ids,

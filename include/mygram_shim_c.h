@@ -82,6 +82,19 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
  * come NUL-terminated in `strings`); is_null (may be NULL) marks NULLs. */
 int mgxs_table_add_filter_column(mgxs_table* table, const char* name, int value_type, uint64_t n, const void* values,
                                  const char* const* strings, const uint8_t* is_null);
+/* Mutable tables (Index::AddDocument / UpdateDocument / RemoveDocument after the index was built: the binlog applier's calls,
+ * src/mysql/binlog_event_processor.cpp:96,140,225,278). Texts are normalized. A document's filter values travel as
+ * n_filters (name, type, 8-byte value | string) tuples: types as in mgxs_table_add_filter_column, 0 = NULL. Changes take
+ * effect at the next search / submit on the table. */
+int mgxs_table_add_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len, uint32_t n_filters,
+                            const char* const* names, const int* types, const void* values, const char* const* strings);
+/* with_filters = 0: the document keeps its filter values. */
+int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* old_text, size_t old_len, const char* new_text,
+                               size_t new_len, int with_filters, uint32_t n_filters, const char* const* names,
+                               const int* types, const void* values, const char* const* strings);
+int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len);
+int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,
+                              uint64_t* removed_from_main, uint64_t* epoch);
 /* One query with parsed FILTER conditions (query::FilterCondition: column, op 0 EQ 1 NE 2 GT 3 GTE 4 LT 5 LTE as
  * query::FilterOp, literal) through search_pipeline::ExecuteBatch; the conditions are resolved like
  * ApplyFiltersWithBitmap (src/server/search_pipeline.cpp:1196-1237). docs / scores have room for `limit` entries. */

@@ -12,6 +12,7 @@ EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
            "mgxs_submit", "mgxs_wait", "mgxs_table_from_dump", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
+           "mgxs_table_add_document", "mgxs_table_update_document", "mgxs_table_remove_document", "mgxs_table_mutation_stats",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -51,6 +52,10 @@ def load():
     L.mgxs_search.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, i32, i32, u32, u32, C.POINTER(u64), C.POINTER(u32), vp, vp]
     L.mgxs_facet.argtypes = [vp, u32, vp, u32, vp, u32, vp, vp, vp, C.c_char_p, u32, u32, C.POINTER(u64), C.POINTER(u64),
                              C.POINTER(u32), vp, vp, C.c_size_t, vp]
+    L.mgxs_table_add_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t, u32, vp, vp, vp, vp]
+    L.mgxs_table_update_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, i32, u32, vp, vp, vp, vp]
+    L.mgxs_table_remove_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t]
+    L.mgxs_table_mutation_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
     L.mgxs_batcher_destroy.argtypes = [vp]
     L.mgxs_batcher_destroy.restype = None
@@ -163,6 +168,57 @@ class Table:
         a = np.ascontiguousarray(values, dtype=dt)
         _check(load().mgxs_table_add_filter_column(self._h, name.encode(), t, n, a.ctypes.data, None,
                                                    nul.ctypes.data if nul is not None else None))
+
+    # ---- mutable tables: the binlog applier's calls after the index was built ----------------------------------------
+    def _filters(self, filters):
+        """{name: (value_type, value)} -> the C arrays of mgxs_table_add_document (value None = NULL)."""
+        items = list((filters or {}).items())
+        n = len(items)
+        names = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in items])
+        types = np.zeros(max(n, 1), np.int32)
+        vals = np.zeros(max(n, 1), np.uint64)
+        strs = []
+        for i, (_, (vt, v)) in enumerate(items):
+            t = 0 if v is None else self.VALUE_TYPES[vt]
+            types[i] = t
+            strs.append(b"")
+            if t == 11:
+                strs[-1] = v.encode("utf-8") if isinstance(v, str) else bytes(v)
+            elif t == 12:
+                vals[i] = np.float64(v).view(np.uint64)
+            elif t != 0:
+                vals[i] = np.int64(v).view(np.uint64) if t not in (3, 5, 7, 9) else np.uint64(v)
+        sarr = (C.c_char_p * max(n, 1))(*strs)
+        return n, names, types, vals, sarr
+
+    @staticmethod
+    def _text(t):
+        return t.encode("utf-8") if isinstance(t, str) else bytes(t)
+
+    def add_document(self, doc_id, text, filters=None):
+        """Index::AddDocument on a built index (normalized text): the document joins the delta index."""
+        n, names, types, vals, sarr = self._filters(filters)
+        raw = self._text(text)
+        _check(load().mgxs_table_add_document(self._h, doc_id, raw, len(raw), n, C.cast(names, C.c_void_p), types.ctypes.data,
+                                              vals.ctypes.data, C.cast(sarr, C.c_void_p)))
+
+    def update_document(self, doc_id, old_text, new_text, filters=None):
+        """Index::UpdateDocument; filters None: the document keeps its filter values."""
+        n, names, types, vals, sarr = self._filters(filters)
+        o, w = self._text(old_text), self._text(new_text)
+        _check(load().mgxs_table_update_document(self._h, doc_id, o, len(o), w, len(w), int(filters is not None), n,
+                                                 C.cast(names, C.c_void_p), types.ctypes.data, vals.ctypes.data,
+                                                 C.cast(sarr, C.c_void_p)))
+
+    def remove_document(self, doc_id, text):
+        """Index::RemoveDocument (text = the document's current normalized text)."""
+        raw = self._text(text)
+        _check(load().mgxs_table_remove_document(self._h, doc_id, raw, len(raw)))
+
+    def mutation_stats(self):
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load().mgxs_table_mutation_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"main_documents": a.value, "delta_documents": b.value, "removed_from_main": c.value, "epoch": d.value}
 
     @staticmethod
     def _strs(items):

@@ -361,6 +361,10 @@ struct mgx_index {
   // every candidate of the term) runs once per distinct term, not once per batch.
   std::unordered_map<std::string, uint64_t> df_cache;
   uint32_t n_bitmap_rows = 0, n_fine_rows = 0;
+  // Mutable tables (mgx_index_set_live_bitmap): the filter row every batched query is ANDed with right after its first
+  // term — the documents of this index that are still live (removed / superseded ones cleared) — or kNoRow.
+  std::atomic<uint32_t> live_row{mgx::kNoRow};
+  DevBuf d_doc_map;  // mgx_index_set_doc_map: local slot -> table doc id (a delta index), or empty
   DevBuf d_fine_rows;                 // fine row -> bitmap row
   std::vector<uint32_t> h_fine_map;   // bitmap row -> fine row (kNoRow: none)
 };
@@ -1034,6 +1038,111 @@ int mgx_index_add_filter_bitmap(mgx_index* idx, const uint32_t* docids, uint64_t
   return MGX_OK;
 }
 
+int mgx_index_update_filter_bitmap(mgx_index* idx, uint32_t bitmap_id, const uint32_t* set_docids, uint64_t n_set,
+                                   const uint32_t* clear_docids, uint64_t n_clear) {
+  if (!idx || (n_set && !set_docids) || (n_clear && !clear_docids))
+    return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_update_filter_bitmap: null argument");
+  if (n_set + n_clear > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_update_filter_bitmap: too many ids");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (bitmap_id >= idx->n_filter_rows) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_update_filter_bitmap: unknown bitmap id");
+    std::vector<uint32_t> slots;
+    slots.reserve(n_set + n_clear);
+    for (int part = 0; part < 2; ++part) {
+      const uint32_t* ids = part == 0 ? set_docids : clear_docids;
+      const uint64_t n = part == 0 ? n_set : n_clear;
+      for (uint64_t i = 0; i < n; ++i) {
+        if (ids[i] < idx->dev.first_doc_id || ids[i] - idx->dev.first_doc_id >= idx->dev.n_docs)
+          return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_update_filter_bitmap: doc id outside the index range");
+        slots.push_back(ids[i] - idx->dev.first_doc_id);
+      }
+    }
+    if (slots.empty()) return MGX_OK;
+    MGX_HIP(hipSetDevice(idx->device));
+    DevBuf d_slots;
+    MGX_HIP(mgx::Upload(d_slots, slots.data(), slots.size()));
+    uint64_t* row = idx->d_filter_bitmaps.as<uint64_t>() + static_cast<uint64_t>(bitmap_id) * idx->filter_row_stride;
+    MGX_LAUNCH(mgx::LaunchUpdateBitmap(row, d_slots.as<uint32_t>(), static_cast<uint32_t>(n_set),
+                                       static_cast<uint32_t>(slots.size()), idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    if (idx->live_row.load() == bitmap_id) {  // the live set changed: df counts of text-level terms are stale
+      std::lock_guard<std::mutex> tl(idx->table_mu);
+      idx->df_cache.clear();
+    }
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_update_filter_bitmap: ") + e.what());
+  }
+}
+
+int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,
+                                 uint32_t* value_id) {
+  if (!idx || !value_bits || !is_null) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_column_read: null argument");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (column_id >= idx->filter_columns.size()) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_filter_column_read: unknown filter column");
+  if (doc_id < idx->dev.first_doc_id || doc_id - idx->dev.first_doc_id >= idx->dev.n_docs)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_filter_column_read: doc id outside the index range");
+  const uint32_t slot = doc_id - idx->dev.first_doc_id;
+  const mgx_index::FilterColumn& col = *idx->filter_columns[column_id];
+  MGX_HIP(hipSetDevice(idx->device));
+  uint8_t nul = 0;
+  uint32_t vid = 0xFFFFFFFFu;
+  MGX_HIP(hipMemcpy(value_bits, col.d_values.as<uint64_t>() + slot, 8, hipMemcpyDeviceToHost));
+  if (col.d_null.p) MGX_HIP(hipMemcpy(&nul, col.d_null.as<uint8_t>() + slot, 1, hipMemcpyDeviceToHost));
+  if (col.d_value_ids.p) MGX_HIP(hipMemcpy(&vid, col.d_value_ids.as<uint32_t>() + slot, 4, hipMemcpyDeviceToHost));
+  *is_null = nul ? 1 : 0;
+  if (value_id) *value_id = vid;
+  return MGX_OK;
+}
+
+int mgx_index_set_live_bitmap(mgx_index* idx, uint32_t bitmap_id, int enable) {
+  if (!idx) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_live_bitmap: null index");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (enable && bitmap_id >= idx->n_filter_rows)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_set_live_bitmap: unknown bitmap id");
+  idx->live_row.store(enable ? bitmap_id : mgx::kNoRow);
+  std::lock_guard<std::mutex> tl(idx->table_mu);
+  idx->df_cache.clear();
+  return MGX_OK;
+}
+
+int mgx_index_set_doc_map(mgx_index* idx, const uint32_t* table_ids, uint64_t n) {
+  if (!idx || !table_ids) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_doc_map: null argument");
+  if (n != idx->dev.n_docs) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_doc_map: one id per doc slot of the index");
+  for (uint64_t i = 1; i < n; ++i)
+    if (table_ids[i] <= table_ids[i - 1])
+      return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_doc_map: ids must ascend with the slot (rank order is kept by that)");
+  try {
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    MGX_HIP(mgx::Upload(idx->d_doc_map, table_ids, n));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_set_doc_map: ") + e.what());
+  }
+}
+
+int mgx_index_invalidate_statistics(mgx_index* idx) {
+  if (!idx) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_invalidate_statistics: null index");
+  MGX_HIP(hipSetDevice(idx->device));
+  MGX_HIP(hipDeviceSynchronize());  // nothing in flight reads the tables that go
+  std::lock_guard<std::mutex> lock(idx->table_mu);
+  idx->table_slot.clear();
+  idx->table_used = 0;
+  idx->pending_jobs.clear();
+  idx->norm_tables.clear();
+  idx->block_max.clear();
+  idx->df_cache.clear();
+  return MGX_OK;
+}
+
+int mgx_index_synchronize(mgx_index* idx) {
+  if (!idx) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_synchronize: null index");
+  MGX_HIP(hipSetDevice(idx->device));
+  MGX_HIP(hipDeviceSynchronize());
+  return MGX_OK;
+}
+
 }  // extern "C"
 
 // =================================================================================================================
@@ -1163,6 +1272,15 @@ struct Compiler {
     q->leaves.push_back(lf);
     return static_cast<uint32_t>(q->leaves.size() - 1);
   }
+  uint32_t FilterLeaf(uint32_t row) {
+    DevLeaf lf{};
+    lf.score_slot = kNoSlot;
+    lf.row = kNoRow;
+    lf.kind = kLeafFilterBitmap;
+    lf.b = row;
+    q->leaves.push_back(lf);
+    return static_cast<uint32_t>(q->leaves.size() - 1);
+  }
   // kOpVerifyText argument for ONE more pattern of the query: its index among the query's patterns | count 1 << 12
   uint32_t OnePattern(const mgx_term& t) {
     q->verify_patterns.emplace_back(reinterpret_cast<const char*>(t.text), t.text_len);
@@ -1230,6 +1348,13 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     }
     out->est_density = dens;
   }
+  // a mutable table's main index: only its live documents exist (a removed document is in no posting list of the
+  // reference, index.cpp:148-197), so every funnel counter counts live documents only
+  const uint32_t live_row = idx->live_row.load(std::memory_order_relaxed);
+  auto and_live = [&]() {
+    if (live_row == kNoRow) return;
+    c.Emit(kOpAnd, c.FilterLeaf(live_row));
+  };
   if (in.n_expr > 0) {
     // ExecuteWithBooleanAst: the positive part is a boolean tree over the terms. Postfix -> tree -> accumulator code.
     if (!in.expr) return Fail(MGX_ERR_INVALID_ARGUMENT, "n_expr without expr");
@@ -1304,10 +1429,12 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     };
     emit(st[0]);
     if (out->stack_depth > 40) return Fail(MGX_ERR_OUT_OF_RANGE, "expression nests deeper than 40 levels");
+    and_live();
     c.Emit(kOpCount, 0);
     c.Emit(kOpCount, 1);
   } else {
     c.LoadTerm(in.terms[0]);
+    and_live();
     c.Emit(kOpCount, 0);
     for (uint32_t i = 1; i < in.n_terms; ++i) {
       const mgx_term& t = in.terms[i];
@@ -2364,6 +2491,8 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
         } else {
           c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
           for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
+          const uint32_t live_row = idx->live_row.load(std::memory_order_relaxed);
+          if (live_row != kNoRow) c.Emit(kOpAnd, c.FilterLeaf(live_row));  // (df counts live documents only)
         }
         for (uint32_t gid : tt.grams)
           mn = std::min<uint64_t>(mn, gid == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[gid + 1] - idx->h_offsets[gid]);
@@ -3086,6 +3215,79 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
   batch->merged_shards = true;
   batch->last_stream = s;
   return mgx::IssueResultCopy(batch, s);
+}
+
+// Mutable tables: a table is its main index plus a small delta index on the same device (documents added or changed
+// since the main index was built). The same batch is compiled against both; the two calls below are the exchange of a
+// sharded table with the wire taken out.
+int mgx_batch_df_merge_local(mgx_batch* primary, mgx_batch* const* others, uint32_t n_others, void* hip_stream) {
+  if (!primary || (n_others && !others)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_df_merge_local: null argument");
+  try {
+    const uint32_t n = static_cast<uint32_t>(primary->h_text_df.size());
+    for (uint32_t j = 0; j < n_others; ++j)
+      if (!others[j] || others[j]->h_text_df.size() != n || others[j]->idx->device != primary->idx->device)
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_df_merge_local: the batches do not hold the same text-level terms");
+    if (n == 0) return MGX_OK;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int rc = mgx_batch_count_df(primary, hip_stream);
+    if (rc) return rc;
+    for (uint32_t j = 0; j < n_others; ++j) {
+      rc = mgx_batch_count_df(others[j], hip_stream);
+      if (rc) return rc;
+      MGX_LAUNCH(mgx::LaunchAddU64(primary->d_text_df.as<uint64_t>(), others[j]->d_text_df.as<uint64_t>(), n, s));
+    }
+    for (uint32_t j = 0; j < n_others; ++j)
+      MGX_HIP(hipMemcpyAsync(others[j]->d_text_df.p, primary->d_text_df.p, static_cast<size_t>(n) * 8, hipMemcpyDeviceToDevice, s));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_df_merge_local: ") + e.what());
+  }
+}
+
+int mgx_batch_merge_local(mgx_batch* primary, mgx_batch* const* others, uint32_t n_others, void* hip_stream) {
+  if (!primary || (n_others && !others)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: null argument");
+  if (primary->n_queries == 0) return MGX_OK;
+  if (!primary->res) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: not a prepared batch object");
+  try {
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    uint32_t stride = 0;
+    int rc = mgx_batch_export_topk(primary, nullptr, nullptr, &stride, hip_stream);
+    if (rc) return rc;
+    const bool pages = primary->score.qids.empty();
+    for (uint32_t j = 0; j < n_others; ++j) {
+      uint32_t st = 0;
+      if (!others[j] || others[j]->n_queries != primary->n_queries || others[j]->idx->device != primary->idx->device)
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: the batches do not hold the same queries");
+      rc = mgx_batch_export_topk(others[j], nullptr, nullptr, &st, hip_stream);
+      if (rc) return rc;
+      if (st != stride || others[j]->score.qids.empty() != pages)
+        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: the batches do not hold the same queries");
+    }
+    MGX_HIP(hipSetDevice(primary->idx->device));
+    const uint64_t elems = static_cast<uint64_t>(primary->n_queries) * stride + primary->n_queries;
+    const uint64_t off32 = elems * 8, bytes = (elems * 12 + 7) / 8 * 8;
+    void* recv = nullptr;
+    MGX_HIP(primary->res->Exchange(1, bytes * (1ull + n_others), &recv));
+    char* g = static_cast<char*>(recv);
+    for (uint32_t j = 0; j <= n_others; ++j) {
+      mgx_batch* b = j == 0 ? primary : others[j - 1];
+      uint64_t* b64 = reinterpret_cast<uint64_t*>(g + bytes * j);
+      uint32_t* b32 = reinterpret_cast<uint32_t*>(g + bytes * j + off32);
+      uint32_t st = 0;
+      rc = mgx_batch_export_topk(b, b64, b32, &st, hip_stream);
+      if (rc) return rc;
+      const mgx_index* ix = b->idx;
+      if (ix->d_doc_map.p) {
+        const mgx_batch::Group& grp = pages ? b->page : b->score;
+        MGX_LAUNCH(mgx::LaunchRemapBlobDocs(grp.dev.queries, b->n_queries, stride, ix->d_doc_map.as<uint32_t>(),
+                                            ix->dev.first_doc_id, ix->dev.n_docs, pages ? b64 : nullptr, b32, s));
+      }
+    }
+    return mgx_batch_merge_shards(primary, n_others + 1, reinterpret_cast<const uint64_t*>(g), bytes / 8,
+                                  reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, hip_stream);
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_merge_local: ") + e.what());
+  }
 }
 
 // =================================================================================================================

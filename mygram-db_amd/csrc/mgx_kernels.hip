@@ -3931,6 +3931,74 @@ int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, ui
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mutable tables: live-set row updates, the delta index's doc map, df sums of two local indexes
+// ---------------------------------------------------------------------------------------------------------------
+
+// Bits of one filter row set (the first n_set slots) and cleared (the rest) in place: the live set of a table whose
+// documents are removed or superseded after the index was built (Index::RemoveDocument / UpdateDocument, index.cpp:148-233).
+__global__ __launch_bounds__(256) void update_bitmap_kernel(unsigned long long* __restrict__ row,
+                                                            const uint32_t* __restrict__ slots, uint32_t n_set,
+                                                            uint32_t n_total) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total) return;
+  const uint32_t slot = slots[i];
+  const unsigned long long bit = 1ull << (slot & 63u);
+  if (i < n_set) atomicOr(&row[slot >> 6], bit); else atomicAnd(&row[slot >> 6], ~bit);
+}
+
+int LaunchUpdateBitmap(uint64_t* row, const uint32_t* slots, uint32_t n_set, uint32_t n_total, hipStream_t s) {
+  if (n_total == 0) return 0;
+  hipLaunchKernelGGL(update_bitmap_kernel, dim3((n_total + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<unsigned long long*>(row), slots, n_set, n_total);
+  MGX_KCHECK();
+  return 0;
+}
+
+// The doc ids of one exchange blob (mgx_batch_export_topk layout) through the index's doc map: a delta index numbers its
+// documents 1..n in ascending order of their table ids, so best-first order and ties are kept. Entries are in ordering
+// form (the id for descending queries, its complement for ascending ones); page blobs carry the same value as their key.
+__global__ __launch_bounds__(256) void remap_blob_docs_kernel(const DevQuery* __restrict__ queries, uint32_t n,
+                                                              uint32_t stride, const uint32_t* __restrict__ map,
+                                                              uint32_t first_doc_id, uint32_t n_docs,
+                                                              uint64_t* __restrict__ blob64, uint32_t* __restrict__ blob32) {
+  const uint64_t e = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= static_cast<uint64_t>(n) * stride) return;
+  const uint32_t qi = static_cast<uint32_t>(e / stride), k = static_cast<uint32_t>(e % stride);
+  const uint32_t cnt = blob32[static_cast<uint64_t>(n) * stride + qi];
+  if (k >= cnt) return;
+  const bool desc = queries[qi].descending != 0;
+  const uint32_t d = blob32[e];
+  const uint32_t local = (desc ? d : ~d) - first_doc_id;
+  if (local >= n_docs) return;  // (cannot happen for a blob this index exported)
+  const uint32_t real = map[local];
+  const uint32_t o = desc ? real : ~real;
+  blob32[e] = o;
+  if (blob64) blob64[e] = o;
+}
+
+int LaunchRemapBlobDocs(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* map, uint32_t first_doc_id,
+                        uint32_t n_docs, uint64_t* blob64, uint32_t* blob32, hipStream_t s) {
+  const uint64_t total = static_cast<uint64_t>(n) * stride;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(remap_blob_docs_kernel, dim3(static_cast<uint32_t>((total + 255) / 256)), dim3(256), 0, s, queries, n,
+                     stride, map, first_doc_id, n_docs, blob64, blob32);
+  MGX_KCHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void add_u64_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+int LaunchAddU64(uint64_t* dst, const uint64_t* src, uint32_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_u64_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, src, n);
+  MGX_KCHECK();
+  return 0;
+}
+
 // read-only streaming probe: the box's attainable HBM read bandwidth, the second roofline denominator of bench.py
 typedef uint32_t probe_vec4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read_probe_kernel(const probe_vec4* __restrict__ src, uint64_t n_vec, uint32_t* sink) {

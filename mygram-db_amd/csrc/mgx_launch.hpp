@@ -52,6 +52,10 @@ int LaunchFilterCompare(const uint64_t* values, const uint8_t* is_null, uint32_t
                         hipStream_t s);
 int LaunchFacetCount(const uint64_t* rbits, uint32_t n_words, const uint32_t* value_ids, uint32_t n_docs, uint32_t n_values,
                      unsigned long long* counts, hipStream_t s);
+int LaunchUpdateBitmap(uint64_t* row, const uint32_t* slots, uint32_t n_set, uint32_t n_total, hipStream_t s);
+int LaunchRemapBlobDocs(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* map, uint32_t first_doc_id,
+                        uint32_t n_docs, uint64_t* blob64, uint32_t* blob32, hipStream_t s);
+int LaunchAddU64(uint64_t* dst, const uint64_t* src, uint32_t n, hipStream_t s);
 int LaunchGatherDf(const unsigned long long* counters, const uint64_t* known, uint32_t n, uint64_t* local,
                    uint64_t* exchange, hipStream_t s);
 int LaunchScanTiles(const uint32_t* tile_cnt, uint32_t n_slots, uint32_t n_tiles, uint64_t* tile_start,

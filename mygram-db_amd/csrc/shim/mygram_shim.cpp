@@ -244,9 +244,43 @@ struct Index::Impl {
         return true;
       }
     }
+    if (fallback != nullptr) {  // a delta index: the main index's dictionary says what the rest of the table holds
+      uint32_t mid = 0;
+      if (fallback->Lookup(gram, &mid)) {
+        *id = MGX_GRAM_ABSENT;
+        *size = fallback->Size(mid);
+        return true;
+      }
+    }
     return false;
   }
   std::unordered_map<std::string, uint64_t> absent_grams;  // grams of the table this shard has no posting for -> size
+  const Impl* fallback = nullptr;
+
+  // ---- mutable tables: changes recorded after the index was built (all under mu) ------------------------------------------
+  struct Mutable {
+    bool active = false;  // a change was ever recorded (the bookkeeping below exists)
+    bool dirty = false;   // recorded changes the device has not seen
+    std::vector<uint64_t> main_live;            // live documents of the main index, by slot
+    std::vector<DocId> pending_clear;           // main documents removed / superseded since the last apply
+    std::vector<uint32_t> pending_dead_grams;   // their distinct n-grams (main gram ids): one posting less each
+    std::map<DocId, std::string> delta_docs;    // documents of the delta index: table id -> normalized text
+    std::map<DocId, storage::FilterMap> delta_filters;
+    bool delta_changed = false;
+    uint64_t main_docs = 0, main_len = 0;       // BM25Stats share of the main index's live documents
+    uint64_t removed = 0, epoch = 0;
+    uint32_t live_bitmap = 0;
+    bool have_live = false;
+    std::shared_ptr<Index> delta;               // the delta index the device holds (nullptr: none)
+    std::vector<std::pair<uint32_t, uint64_t>> delta_contrib;  // (main gram id, the delta's posting count) inside global_sizes
+  };
+  mutable Mutable mut;
+  mutable std::vector<uint64_t> exists_bits;  // has_gaps: the ids that were added, by slot
+  bool LiveInMain(DocId doc) const {
+    if (!mut.active || doc < view.first_doc_id || doc - view.first_doc_id >= view.n_docs) return false;
+    const uint64_t slot = doc - view.first_doc_id;
+    return (mut.main_live[slot >> 6] >> (slot & 63)) & 1;
+  }
 
   // ---- filter columns (DocumentStore filter values + FilterIndex, on the device by doc slot) -------------------------
   struct FilterColumn {
@@ -343,8 +377,12 @@ std::unique_ptr<Index> Index::FromDump(const void* data, size_t len, const std::
   // DocumentStore::GetAllDocIds: the ids the store holds (deleted ids leave gaps in the range)
   if (v.n_existing != v.n_docs) {
     std::vector<DocId> existing;
+    im->exists_bits.assign((v.n_docs + 63) / 64, 0);
     for (uint64_t i = 0; i < v.n_docs; ++i)
-      if (v.exists[i]) existing.push_back(v.first_doc_id + static_cast<DocId>(i));
+      if (v.exists[i]) {
+        existing.push_back(v.first_doc_id + static_cast<DocId>(i));
+        im->exists_bits[i >> 6] |= 1ull << (i & 63);
+      }
     im->has_gaps = true;
     if (mgx_index_add_filter_bitmap(im->dev, existing.data(), existing.size(), &im->exists_bitmap) != MGX_OK)
       return fail(mgx_last_error());
@@ -387,21 +425,312 @@ std::unique_ptr<Index> Index::FromDump(const void* data, size_t len, const std::
   return idx;
 }
 
+namespace {
+// Everything the first recorded change needs: which documents of the main index are live, its share of BM25Stats, and
+// table-wide posting sizes the planner reads instead of the columns' own. Called with im->mu held, index finalised.
+std::string EnsureMutable(Index::Impl* im) {
+  Index::Impl::Mutable& m = im->mut;
+  if (m.active) return "";
+  if (!im->dev) return im->last_error.empty() ? "no device index" : im->last_error;
+  if (!im->global_sizes.empty() || !im->absent_grams.empty() || im->fallback)
+    return "a shard of a sharded table (SetGlobalStats) is static";
+  const uint64_t n = im->view.n_docs;
+  if (im->has_gaps) {
+    m.main_live = im->exists_bits;
+  } else {
+    m.main_live.assign((n + 63) / 64, ~0ull);
+    if (n & 63) m.main_live.back() = (1ull << (n & 63)) - 1;
+  }
+  m.main_docs = im->view.bm25_doc_count;
+  m.main_len = im->view.bm25_total_len;
+  im->global_sizes.resize(im->view.n_grams);
+  for (uint64_t g = 0; g < im->view.n_grams; ++g) im->global_sizes[g] = im->view.offsets[g + 1] - im->view.offsets[g];
+  im->global_docs = m.main_docs;
+  im->global_avgdl = m.main_docs ? static_cast<double>(m.main_len) / static_cast<double>(m.main_docs) : 0.0;
+  m.active = true;
+  return "";
+}
+}  // namespace
+
 bool Index::AddDocument(DocId doc_id, std::string_view text) {
   std::lock_guard<std::mutex> lock(impl_->mu);
-  if (impl_->finalized) {
-    impl_->last_error = "AddDocument after the first search: the device index is static (SURVEY.md 8f N4)";
-    return false;
+  if (impl_->finalized) {  // index.cpp:39-74 on a built index: the document joins the delta
+    const std::string err = EnsureMutable(impl_.get());
+    if (!err.empty()) {
+      impl_->last_error = "AddDocument: " + err;
+      return false;
+    }
+    if (impl_->LiveInMain(doc_id) || impl_->mut.delta_docs.count(doc_id)) {
+      impl_->last_error = "AddDocument: the document id is live (UpdateDocument changes a document's text)";
+      return false;
+    }
+    impl_->mut.delta_docs[doc_id] = std::string(text);
+    impl_->mut.delta_changed = impl_->mut.dirty = true;
+    return !GenerateHybridNgrams(text, ngram_size_, kanji_ngram_size_, cross_boundary_).empty();
   }
   impl_->pending[doc_id] = std::string(text);
   return !GenerateHybridNgrams(text, ngram_size_, kanji_ngram_size_, cross_boundary_).empty();  // index.cpp:39-74
 }
 
 bool Index::AddDocument(DocId doc_id, std::string_view text, const storage::FilterMap& filters) {
+  bool was_live = false;
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    was_live = impl_->finalized && (impl_->LiveInMain(doc_id) || impl_->mut.delta_docs.count(doc_id) != 0);
+  }
   const bool has_grams = AddDocument(doc_id, text);
   std::lock_guard<std::mutex> lock(impl_->mu);
-  if (!impl_->finalized) impl_->pending_filters[doc_id] = filters;
+  if (!impl_->finalized) {
+    impl_->pending_filters[doc_id] = filters;
+  } else if (!was_live && impl_->mut.delta_docs.count(doc_id)) {
+    impl_->mut.delta_filters[doc_id] = filters;
+  }
   return has_grams;
+}
+
+namespace {
+storage::FilterValue FilterValueFromBits(size_t type, uint64_t w, const std::vector<storage::FilterValue>& dict) {
+  switch (type) {
+    case 1: return w != 0;
+    case 2: return static_cast<int8_t>(static_cast<int64_t>(w));
+    case 3: return static_cast<uint8_t>(w);
+    case 4: return static_cast<int16_t>(static_cast<int64_t>(w));
+    case 5: return static_cast<uint16_t>(w);
+    case 6: return static_cast<int32_t>(static_cast<int64_t>(w));
+    case 7: return static_cast<uint32_t>(w);
+    case 8: return static_cast<int64_t>(w);
+    case 9: return static_cast<uint64_t>(w);
+    case 10: return storage::TimeValue{static_cast<int64_t>(w)};
+    case 11: return w < dict.size() ? dict[w] : storage::FilterValue{};  // strings are stored as dictionary ranks
+    case 12: {
+      double d;
+      std::memcpy(&d, &w, 8);
+      return d;
+    }
+    default: return storage::FilterValue{};
+  }
+}
+
+// RemoveDocument's bookkeeping (index.cpp:148-197: every distinct n-gram of the text loses the posting). im->mu held.
+void RemoveLocked(const Index& index, Index::Impl* im, DocId doc_id, std::string_view text) {
+  Index::Impl::Mutable& m = im->mut;
+  const auto it = m.delta_docs.find(doc_id);
+  if (it != m.delta_docs.end()) {
+    m.delta_docs.erase(it);
+    m.delta_filters.erase(doc_id);
+    m.delta_changed = m.dirty = true;
+    return;
+  }
+  if (!im->LiveInMain(doc_id)) return;  // not a document of the table
+  const uint64_t slot = doc_id - im->view.first_doc_id;
+  m.main_live[slot >> 6] &= ~(1ull << (slot & 63));
+  m.pending_clear.push_back(doc_id);
+  auto grams = GenerateHybridNgrams(text, index.GetNgramSize(), index.GetKanjiNgramSize(), index.GetCrossBoundaryNgrams());
+  DeduplicateSorted(grams);
+  for (const auto& g : grams) {
+    uint32_t id = 0;
+    if (im->Lookup(g, &id)) m.pending_dead_grams.push_back(id);
+  }
+  const uint32_t dl = im->view.doc_len[slot];
+  if (dl > 0) {  // BM25Stats::RemoveDocument (binlog_event_processor.cpp:140-142)
+    m.main_docs -= 1;
+    m.main_len -= dl;
+  }
+  m.removed += 1;
+  m.dirty = true;
+}
+}  // namespace
+
+void Index::RemoveDocument(DocId doc_id, std::string_view text) {
+  Finalize();
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  const std::string err = EnsureMutable(impl_.get());
+  if (!err.empty()) {
+    impl_->last_error = "RemoveDocument: " + err;
+    return;
+  }
+  RemoveLocked(*this, impl_.get(), doc_id, text);
+}
+
+void Index::UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text) {
+  Finalize();
+  FlushPendingFilterColumns();
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  Impl* im = impl_.get();
+  const std::string err = EnsureMutable(im);
+  if (!err.empty()) {
+    im->last_error = "UpdateDocument: " + err;
+    return;
+  }
+  // the document keeps its filter values (the reference changes them through DocumentStore::UpdateDocument, a separate
+  // call): a delta document has them on the host, a document of the main index has them in the device columns
+  storage::FilterMap keep;
+  const auto df = im->mut.delta_filters.find(doc_id);
+  if (df != im->mut.delta_filters.end()) {
+    keep = df->second;
+  } else if (im->LiveInMain(doc_id)) {
+    std::lock_guard<std::mutex> fl(im->filter_mu);
+    for (const auto& col : im->filter_columns) {
+      uint64_t w = 0;
+      int nul = 1;
+      if (mgx_index_filter_column_read(im->dev, col.device_id, doc_id, &w, &nul, nullptr) != MGX_OK) {
+        im->last_error = mgx_last_error();
+        continue;
+      }
+      if (!nul && col.type != 0) keep[col.name] = FilterValueFromBits(col.type, w, col.dict);
+    }
+  }
+  RemoveLocked(*this, im, doc_id, old_text);
+  im->mut.delta_docs[doc_id] = std::string(new_text);
+  if (!keep.empty()) im->mut.delta_filters[doc_id] = std::move(keep);
+  im->mut.delta_changed = im->mut.dirty = true;
+}
+
+void Index::UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text,
+                           const storage::FilterMap& filters) {
+  Finalize();
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  Impl* im = impl_.get();
+  const std::string err = EnsureMutable(im);
+  if (!err.empty()) {
+    im->last_error = "UpdateDocument: " + err;
+    return;
+  }
+  RemoveLocked(*this, im, doc_id, old_text);
+  im->mut.delta_docs[doc_id] = std::string(new_text);
+  im->mut.delta_filters[doc_id] = filters;
+  im->mut.delta_changed = im->mut.dirty = true;
+}
+
+Index::MutationStats Index::GetMutationStats() const {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  MutationStats st;
+  const auto& m = impl_->mut;
+  st.main_documents = m.active ? m.main_docs : impl_->view.bm25_doc_count;
+  st.delta_documents = m.delta_docs.size();
+  st.removed_from_main = m.removed;
+  st.epoch = m.epoch;
+  return st;
+}
+
+// The recorded changes reach the device: live row, delta index, table-wide statistics. The caller guarantees that no
+// batch of this Index is being planned, compiled or run by another thread (header note).
+std::string Index::ApplyMutations() const {
+  Impl* im = impl_.get();
+  std::unique_lock<std::mutex> lock(im->mu);
+  Impl::Mutable& m = im->mut;
+  if (!m.dirty) return "";
+  auto fail = [&](const std::string& msg) {
+    im->last_error = "ApplyMutations: " + msg;
+    return im->last_error;
+  };
+  if (mgx_index_synchronize(im->dev) != MGX_OK) return fail(mgx_last_error());
+  // ---- the live row of the main index ---------------------------------------------------------------------------------
+  if (!m.have_live) {
+    std::vector<DocId> live;
+    live.reserve(im->view.n_docs);
+    for (uint64_t slot = 0; slot < im->view.n_docs; ++slot)
+      if ((m.main_live[slot >> 6] >> (slot & 63)) & 1) live.push_back(im->view.first_doc_id + static_cast<DocId>(slot));
+    if (mgx_index_add_filter_bitmap(im->dev, live.data(), live.size(), &m.live_bitmap) != MGX_OK) return fail(mgx_last_error());
+    if (mgx_index_set_live_bitmap(im->dev, m.live_bitmap, 1) != MGX_OK) return fail(mgx_last_error());
+    m.have_live = true;
+    im->has_gaps = false;  // (the live row is also the NOT universe: ids never added are not in it)
+  } else if (!m.pending_clear.empty()) {
+    if (mgx_index_update_filter_bitmap(im->dev, m.live_bitmap, nullptr, 0, m.pending_clear.data(), m.pending_clear.size()) != MGX_OK)
+      return fail(mgx_last_error());
+  }
+  m.pending_clear.clear();
+  // ---- posting sizes: the main index's live postings, then the delta's on top -------------------------------------------
+  for (const auto& c : m.delta_contrib) im->global_sizes[c.first] -= c.second;
+  m.delta_contrib.clear();
+  for (uint32_t gid : m.pending_dead_grams)
+    if (im->global_sizes[gid] > 0) im->global_sizes[gid] -= 1;
+  m.pending_dead_grams.clear();
+  // ---- the delta index ------------------------------------------------------------------------------------------------
+  if (m.delta_changed) {
+    m.delta_changed = false;
+    if (m.delta_docs.empty()) {
+      m.delta.reset();
+    } else {
+      auto nd = std::make_shared<Index>(ngram_size_, im->query_kanji, im->dense_threshold, cross_boundary_, normalize_nfkc_,
+                                        normalize_width_, normalize_lower_, im->device);
+      std::vector<DocId> ids;
+      ids.reserve(m.delta_docs.size());
+      DocId local = 1;
+      for (const auto& kv : m.delta_docs) {  // (ascending table id -> ascending local id: rank order and ties are kept)
+        nd->AddDocument(local++, kv.second);
+        ids.push_back(kv.first);
+      }
+      lock.unlock();  // (Finalize / AddFilterColumn of the new index take their own locks; nothing here touches `m`)
+      const std::string err = nd->Finalize();
+      if (!err.empty() || !nd->impl()->dev) {
+        lock.lock();
+        return fail("the delta index failed to build: " + err);
+      }
+      if (mgx_index_set_doc_map(nd->impl()->dev, ids.data(), ids.size()) != MGX_OK) {
+        lock.lock();
+        return fail(mgx_last_error());
+      }
+      std::vector<std::string> names;
+      {
+        std::lock_guard<std::mutex> fl(im->filter_mu);
+        for (const auto& c : im->filter_columns) names.push_back(c.name);
+      }
+      lock.lock();
+      for (const auto& kv : m.delta_filters)
+        for (const auto& f : kv.second)
+          if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);
+      for (const auto& name : names) {
+        std::vector<storage::FilterValue> values(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) {
+          const auto fm = m.delta_filters.find(ids[i]);
+          if (fm == m.delta_filters.end()) continue;
+          const auto fv = fm->second.find(name);
+          if (fv != fm->second.end()) values[i] = fv->second;
+        }
+        const std::string ferr = nd->AddFilterColumn(name, values);
+        if (!ferr.empty()) return fail(ferr);
+      }
+      nd->impl()->fallback = im;
+      m.delta = std::move(nd);
+    }
+  }
+  // ---- table-wide statistics in both ------------------------------------------------------------------------------------
+  uint64_t n_docs = m.main_docs, total_len = m.main_len;
+  im->absent_grams.clear();
+  std::vector<uint64_t> delta_sizes;
+  if (m.delta) {
+    const mgx_columns_view& dv = m.delta->impl()->view;
+    n_docs += dv.bm25_doc_count;
+    total_len += dv.bm25_total_len;
+    delta_sizes.resize(dv.n_grams);
+    for (uint64_t g = 0; g < dv.n_grams; ++g) {
+      const std::string_view key(reinterpret_cast<const char*>(dv.key_bytes) + dv.key_off[g], dv.key_off[g + 1] - dv.key_off[g]);
+      const uint64_t sz = dv.offsets[g + 1] - dv.offsets[g];
+      uint32_t mid = 0;
+      if (im->Lookup(key, &mid)) {
+        im->global_sizes[mid] += sz;
+        m.delta_contrib.emplace_back(mid, sz);
+        delta_sizes[g] = im->global_sizes[mid];
+      } else {
+        im->absent_grams.emplace(std::string(key), sz);
+        delta_sizes[g] = sz;
+      }
+    }
+  }
+  im->global_docs = n_docs;
+  im->global_avgdl = n_docs ? static_cast<double>(total_len) / static_cast<double>(n_docs) : 0.0;
+  if (m.delta) {
+    Impl* dm = m.delta->impl();
+    dm->global_sizes = std::move(delta_sizes);
+    dm->global_docs = im->global_docs;
+    dm->global_avgdl = im->global_avgdl;
+    if (mgx_index_invalidate_statistics(dm->dev) != MGX_OK) return fail(mgx_last_error());
+  }
+  if (mgx_index_invalidate_statistics(im->dev) != MGX_OK) return fail(mgx_last_error());
+  m.dirty = false;
+  m.epoch += 1;
+  return "";
 }
 
 namespace {
@@ -504,8 +833,14 @@ std::string Index::Finalize() const {
   bytes.resize(bytes.size() + 16);
   std::vector<DocId> existing;
   impl_->has_gaps = impl_->pending.size() != n && !impl_->pending.empty();
-  if (impl_->has_gaps)
-    for (const auto& kv : impl_->pending) existing.push_back(kv.first);
+  if (impl_->has_gaps) {
+    impl_->exists_bits.assign((n + 63) / 64, 0);
+    for (const auto& kv : impl_->pending) {
+      existing.push_back(kv.first);
+      const uint64_t slot = kv.first - first;
+      impl_->exists_bits[slot >> 6] |= 1ull << (slot & 63);
+    }
+  }
   impl_->pending.clear();
   mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, ngram_size_, kanji_ngram_size_, cross_boundary_ ? 1 : 0, 0};
   if (mgx_columns_build(&bp, bytes.data(), off.data(), first, n, &impl_->cols) != MGX_OK) {
@@ -1410,7 +1745,8 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
 }
 
 // results of one fetched batch -> BatchResult objects, in the order the queries were given
-void Collect(const std::vector<PlannedQuery>& plans, const mgx_result_view& v, std::vector<BatchResult>* out) {
+void Collect(const std::vector<PlannedQuery>& plans, const mgx_result_view& v, std::vector<BatchResult>* out,
+             const mgx_result_view* delta_view = nullptr) {
   out->resize(plans.size());  // (elements a caller hands back keep their vectors' storage: WaitInto)
   size_t k = 0;
   for (size_t qi = 0; qi < plans.size(); ++qi) {
@@ -1424,15 +1760,60 @@ void Collect(const std::vector<PlannedQuery>& plans, const mgx_result_view& v, s
       o.empty_term_detected = plans[qi].empty_term_detected;
       continue;
     }
-    const mgx_query_result& r = v.queries[k++];
+    const mgx_query_result& r = v.queries[k];
     o.total = r.total;
     o.total_candidates = r.total_candidates;
     o.after_intersection = r.after_intersection;
     o.after_not = r.after_not;
     o.after_filters = r.after_filters;
+    if (delta_view != nullptr && delta_view->queries != nullptr) {
+      // a mutable table: page and total were merged on the device; the funnel counters are each index's own
+      const mgx_query_result& d = delta_view->queries[k];
+      o.total_candidates += d.total_candidates;
+      o.after_intersection += d.after_intersection;
+      o.after_not += d.after_not;
+      o.after_filters += d.after_filters;
+    }
+    ++k;
     o.results.assign(v.docs + r.docs_begin, v.docs + r.docs_begin + r.n_docs);
     o.scores.assign(v.scores + r.docs_begin, v.scores + r.docs_begin + r.n_docs);
   }
+}
+}  // namespace
+
+namespace {
+// A mutable table's delta index as the device holds it now (nullptr: none). ApplyMutations has run.
+std::shared_ptr<index::Index> DeltaOf(const index::Index& index) {
+  index::Index::Impl* im = index.impl();
+  std::lock_guard<std::mutex> lock(im->mu);
+  return im->mut.delta;
+}
+
+// The same query planned against the delta index: must run where the main plan runs (both see table-wide sizes).
+bool PlanForDelta(const index::Index& delta, const BatchQuery& q, uint64_t total_docs, double avgdl,
+                  const PlannedQuery& main_plan, PlannedQuery* p) {
+  if (!q.filters.empty()) {
+    Fail(p, ErrorCode::kNotImplemented,
+         "BatchQuery::filters (raw bitmap ids) belong to one device index: a table with a delta takes filter_conditions");
+    return false;
+  }
+  PlanQuery(delta, q, total_docs, avgdl, p);
+  if (p->error != ErrorCode::kSuccess) return false;
+  if (p->on_device != main_plan.on_device) {
+    Fail(p, ErrorCode::kInternalError, "the main and the delta index plan a query differently");
+    return false;
+  }
+  return true;
+}
+
+// df pass + execute of both batches and the merge, all on the main batch's stream
+int RunWithDelta(mgx_batch* main_batch, mgx_batch* delta_batch, void* stream) {
+  mgx_batch* others[1] = {delta_batch};
+  int rc = mgx_batch_df_merge_local(main_batch, others, 1, stream);
+  if (rc == MGX_OK) rc = mgx_batch_execute(main_batch, stream);
+  if (rc == MGX_OK) rc = mgx_batch_execute(delta_batch, stream);
+  if (rc == MGX_OK) rc = mgx_batch_merge_local(main_batch, others, 1, stream);
+  return rc;
 }
 }  // namespace
 
@@ -1441,15 +1822,25 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   index.Finalize();
   index::Index::Impl* im = index.impl();
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  {
+    const std::string merr = index.ApplyMutations();
+    if (!merr.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, merr));
+  }
+  const std::shared_ptr<index::Index> delta = DeltaOf(index);
   const uint64_t total_docs = index.Bm25DocCount();
   const double avgdl = index.Bm25AvgDocLength();
-  std::vector<PlannedQuery> plans(queries.size());
-  std::vector<mgx_query> mq;
+  std::vector<PlannedQuery> plans(queries.size()), dplans(delta ? queries.size() : 0);
+  std::vector<mgx_query> mq, dq;
   for (size_t qi = 0; qi < queries.size(); ++qi) {
     PlanQuery(index, queries[qi], total_docs, avgdl, &plans[qi]);
     if (plans[qi].error != ErrorCode::kSuccess)
       return MakeUnexpected(MakeError(plans[qi].error, plans[qi].error_message));
     if (plans[qi].on_device) mq.push_back(plans[qi].q);
+    if (delta) {
+      if (!PlanForDelta(*delta, queries[qi], total_docs, avgdl, plans[qi], &dplans[qi]))
+        return MakeUnexpected(MakeError(dplans[qi].error, dplans[qi].error_message));
+      if (dplans[qi].on_device) dq.push_back(dplans[qi].q);
+    }
   }
   std::vector<BatchResult> out;
   mgx_result_view v{};
@@ -1461,6 +1852,22 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   int rc = mgx_batch_prepare(im->dev, mq.data(), static_cast<uint32_t>(mq.size()), &batch);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> guard(batch, mgx_batch_destroy);
+  if (delta) {
+    mgx_batch* dbatch = nullptr;
+    rc = mgx_batch_prepare(delta->impl()->dev, dq.data(), static_cast<uint32_t>(dq.size()), &dbatch);
+    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+    std::unique_ptr<mgx_batch, void (*)(mgx_batch*)> dguard(dbatch, mgx_batch_destroy);
+    void* stream = nullptr;
+    rc = mgx_batch_stream(batch, &stream);
+    if (rc == MGX_OK) rc = RunWithDelta(batch, dbatch, stream);
+    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+    mgx_result_view dv{};
+    rc = mgx_batch_fetch(batch, &v);
+    if (rc == MGX_OK) rc = mgx_batch_fetch(dbatch, &dv);
+    if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
+    Collect(plans, v, &out, &dv);
+    return out;
+  }
   rc = mgx_batch_execute(batch, nullptr);
   if (rc != MGX_OK) return MakeUnexpected(MakeError(static_cast<ErrorCode>(rc), mgx_last_error()));
   rc = mgx_batch_fetch(batch, &v);
@@ -1469,20 +1876,24 @@ Expected<std::vector<BatchResult>, Error> ExecuteBatch(const index::Index& index
   return out;
 }
 
-Expected<FacetOutput, Error> ExecuteFacet(const index::Index& index, const BatchQuery& query, const std::string& column) {
-  index.Finalize();
+namespace {
+// FACET over one device index: the column's distinct values (ascending) and how many documents of the query's result set
+// hold each. found = false: this index has no such column.
+Error FacetOne(const index::Index& index, const BatchQuery& query, const std::string& column, bool* found,
+               std::vector<storage::FilterValue>* dict, std::vector<uint64_t>* counts, uint64_t* matched) {
   index.FlushPendingFilterColumns();
   index::Index::Impl* im = index.impl();
-  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
   uint32_t device_column = 0;
-  std::vector<storage::FilterValue> dict;
+  *found = false;
+  *matched = 0;
   {
     std::lock_guard<std::mutex> lock(im->filter_mu);
     const index::Index::Impl::FilterColumn* col = im->ResolveColumn(column);
-    if (col == nullptr)  // search_pipeline.cpp:2089-2092
-      return MakeUnexpected(MakeError(ErrorCode::kIndexNotFound, "Facet column \"" + column + "\" not found"));
-    device_column = col->device_id;
-    dict = col->dict;
+    if (col != nullptr) {
+      *found = true;
+      device_column = col->device_id;
+      *dict = col->dict;
+    }
   }
   // the search part: the query's own, or — FACET without search terms — every document (GetAllDocIds, :2118) narrowed by
   // its NOT terms and filters: the expression NOT(<empty>) is the universe
@@ -1497,13 +1908,67 @@ Expected<FacetOutput, Error> ExecuteFacet(const index::Index& index, const Batch
   }
   PlannedQuery plan;
   PlanQuery(index, q, index.Bm25DocCount(), index.Bm25AvgDocLength(), &plan);
-  if (plan.error != ErrorCode::kSuccess) return MakeUnexpected(MakeError(plan.error, plan.error_message));
-  FacetOutput out;
-  std::vector<uint64_t> counts(std::max<size_t>(dict.size(), 1), 0);
-  if (plan.on_device) {
-    if (mgx_facet_counts(im->dev, &plan.q, device_column, counts.data(), &out.matched_documents) != MGX_OK)
-      return MakeUnexpected(MakeError(ErrorCode::kInternalError, mgx_last_error()));
+  if (plan.error != ErrorCode::kSuccess) return MakeError(plan.error, plan.error_message);
+  counts->assign(std::max<size_t>(dict->size(), 1), 0);
+  if (plan.on_device && *found) {
+    if (mgx_facet_counts(im->dev, &plan.q, device_column, counts->data(), matched) != MGX_OK)
+      return MakeError(ErrorCode::kInternalError, mgx_last_error());
   }
+  return Error{ErrorCode::kSuccess, ""};
+}
+}  // namespace
+
+Expected<FacetOutput, Error> ExecuteFacet(const index::Index& index, const BatchQuery& query, const std::string& column) {
+  index.Finalize();
+  index::Index::Impl* im = index.impl();
+  if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  {
+    const std::string merr = index.ApplyMutations();
+    if (!merr.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, merr));
+  }
+  const std::shared_ptr<index::Index> delta = DeltaOf(index);
+  if (delta && !query.filters.empty())
+    return MakeUnexpected(MakeError(ErrorCode::kNotImplemented,
+                                    "BatchQuery::filters (raw bitmap ids) belong to one device index: a table with a delta takes filter_conditions"));
+  bool found = false, dfound = false;
+  std::vector<storage::FilterValue> dict, ddict;
+  std::vector<uint64_t> counts, dcounts;
+  FacetOutput out;
+  Error e = FacetOne(index, query, column, &found, &dict, &counts, &out.matched_documents);
+  if (e.code() != ErrorCode::kSuccess) return MakeUnexpected(e);
+  if (delta) {  // a mutable table: the delta's documents count too; values meet by value, not by per-index id
+    uint64_t dmatched = 0;
+    e = FacetOne(*delta, query, column, &dfound, &ddict, &dcounts, &dmatched);
+    if (e.code() != ErrorCode::kSuccess) return MakeUnexpected(e);
+    out.matched_documents += dmatched;
+    if (dfound) {
+      std::vector<storage::FilterValue> merged;
+      std::vector<uint64_t> mcounts;
+      size_t i = 0, j = 0;
+      const size_t ni = found ? dict.size() : 0;
+      while (i < ni || j < ddict.size()) {
+        if (j == ddict.size() || (i < ni && dict[i] < ddict[j])) {
+          merged.push_back(dict[i]);
+          mcounts.push_back(counts[i]);
+          ++i;
+        } else if (i == ni || ddict[j] < dict[i]) {
+          merged.push_back(ddict[j]);
+          mcounts.push_back(dcounts[j]);
+          ++j;
+        } else {
+          merged.push_back(dict[i]);
+          mcounts.push_back(counts[i] + dcounts[j]);
+          ++i;
+          ++j;
+        }
+      }
+      dict.swap(merged);
+      counts.swap(mcounts);
+      found = true;
+    }
+  }
+  if (!found)  // search_pipeline.cpp:2089-2092
+    return MakeUnexpected(MakeError(ErrorCode::kIndexNotFound, "Facet column \"" + column + "\" not found"));
   std::vector<size_t> order;
   for (size_t v = 0; v < dict.size(); ++v)
     if (counts[v] > 0) order.push_back(v);
@@ -1537,6 +2002,14 @@ struct BatchExecutor::Impl {
     std::vector<BatchQuery> queries;
     std::vector<PlannedQuery> plans;
     std::vector<mgx_query> mq;
+    // a mutable table: the delta index this batch was submitted against, the same queries planned for it, and the batch
+    // object compiled on it (bound to dbatch_index: a rebuilt delta gets a new object)
+    std::shared_ptr<index::Index> delta, dbatch_index;
+    std::vector<PlannedQuery> dplans;
+    std::vector<mgx_query> dq;
+    mgx_batch* dbatch = nullptr;
+    uint64_t total_docs = 0;  // BM25Stats the batch is planned with (a mutable table's change between batches)
+    double avgdl = 0.0;
     uint64_t ticket = 0;
     State state = kFree;
     size_t chunks_left = 0;  // under mu
@@ -1588,6 +2061,16 @@ struct BatchExecutor::Impl {
       if (p.on_device) slot->mq.push_back(p.q);
     }
     slot->timing.device_queries = static_cast<uint32_t>(slot->mq.size());
+    slot->dq.clear();
+    if (slot->delta) {
+      for (const auto& p : slot->dplans) {
+        if (p.error != ErrorCode::kSuccess) {
+          slot->error = MakeError(p.error, p.error_message);
+          return;
+        }
+        if (p.on_device) slot->dq.push_back(p.q);
+      }
+    }
     if (slot->mq.empty()) return;
     if (kTrace) {
       static std::atomic<uint64_t> n{0}, us{0};
@@ -1599,6 +2082,22 @@ struct BatchExecutor::Impl {
       rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
     else
       rc = mgx_batch_reset(slot->batch, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()));
+    if (rc != MGX_OK) {
+      slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
+      return;
+    }
+    if (slot->dbatch && slot->dbatch_index != slot->delta) {  // the delta index was rebuilt (or went away)
+      mgx_batch_destroy(slot->dbatch);
+      slot->dbatch = nullptr;
+      slot->dbatch_index.reset();
+    }
+    if (!slot->delta) return;
+    if (!slot->dbatch) {
+      rc = mgx_batch_prepare(slot->delta->impl()->dev, slot->dq.data(), static_cast<uint32_t>(slot->dq.size()), &slot->dbatch);
+      if (rc == MGX_OK) slot->dbatch_index = slot->delta;
+    } else {
+      rc = mgx_batch_reset(slot->dbatch, slot->dq.data(), static_cast<uint32_t>(slot->dq.size()));
+    }
     if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
   }
 
@@ -1626,10 +2125,14 @@ struct BatchExecutor::Impl {
         void* stream = nullptr;  // the batch object's own stream: slots overlap on the device
         int rc = mgx_batch_stream(slot->batch, &stream);
         mgx_comm* comm = opt.comm;
-        if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
-        if (rc == MGX_OK)                                                                 // asynchronous
-          rc = comm ? mgx_batch_execute_sharded(slot->batch, comm, stream) : mgx_batch_execute(slot->batch, stream);
-        if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
+        if (rc == MGX_OK && slot->delta) {
+          rc = RunWithDelta(slot->batch, slot->dbatch, stream);  // both indexes + the merge, on this one stream
+        } else {
+          if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
+          if (rc == MGX_OK)                                                                 // asynchronous
+            rc = comm ? mgx_batch_execute_sharded(slot->batch, comm, stream) : mgx_batch_execute(slot->batch, stream);
+          if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
+        }
         if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
         slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
         lock.lock();
@@ -1656,7 +2159,13 @@ struct BatchExecutor::Impl {
       lock.unlock();
       for (size_t i = c.begin; i < c.end; ++i) {
         c.slot->plans[i].Reset();  // (the slot's plans are re-used from batch to batch)
-        PlanQuery(index, c.slot->queries[i], total_docs, avgdl, &c.slot->plans[i]);
+        PlanQuery(index, c.slot->queries[i], c.slot->total_docs, c.slot->avgdl, &c.slot->plans[i]);
+        if (c.slot->delta) {
+          c.slot->dplans[i].Reset();
+          if (c.slot->plans[i].error == ErrorCode::kSuccess)
+            PlanForDelta(*c.slot->delta, c.slot->queries[i], c.slot->total_docs, c.slot->avgdl, c.slot->plans[i],
+                         &c.slot->dplans[i]);
+        }
       }
       lock.lock();
       if (--c.slot->chunks_left != 0) continue;
@@ -1738,6 +2247,7 @@ BatchExecutor::~BatchExecutor() {
       mgx_result_view v{};
       (void)mgx_batch_fetch(s.batch, &v);  // (drain the device before the object goes)
     }
+    if (s.dbatch) mgx_batch_destroy(s.dbatch);
     if (s.batch) mgx_batch_destroy(s.batch);
   }
 }
@@ -1745,6 +2255,33 @@ BatchExecutor::~BatchExecutor() {
 Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& queries) {
   index::Index::Impl* im = impl_->index.impl();
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  // a mutable table: changes recorded since the last batch reach the device now — once nothing of this executor is
+  // being planned or compiled (batches already on the device finish first: ApplyMutations waits for it)
+  bool dirty = false, mutable_table = false;
+  {
+    std::lock_guard<std::mutex> il(im->mu);
+    dirty = im->mut.dirty;
+    mutable_table = im->mut.active;
+  }
+  if (dirty) {
+    if (impl_->opt.comm)
+      return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "a sharded table (Options::comm) is static"));
+    {
+      std::unique_lock<std::mutex> lock(impl_->mu);
+      impl_->cv_state.wait(lock, [&] {
+        for (auto& s : impl_->slots)
+          if (s.state == Impl::kPlanning || s.state == Impl::kPlanned || s.state == Impl::kCompiling || s.state == Impl::kCompiled)
+            return false;
+        return true;
+      });
+    }
+    const std::string merr = impl_->index.ApplyMutations();
+    if (!merr.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, merr));
+  }
+  if (mutable_table) {  // (another entry point may have applied the changes: the statistics are read per batch)
+    impl_->total_docs = impl_->index.Bm25DocCount();
+    impl_->avgdl = impl_->index.Bm25AvgDocLength();
+  }
   Impl::Slot* slot = nullptr;
   {
     std::lock_guard<std::mutex> lock(impl_->mu);
@@ -1762,6 +2299,10 @@ Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& querie
   // allocations, and the planner threads take the same lock for every chunk)
   slot->queries.swap(queries);  // (the caller gets the slot's previous batch back: storage to build its next one in)
   slot->plans.resize(slot->queries.size());  // (elements are reset by the planner that takes them)
+  slot->total_docs = impl_->total_docs;
+  slot->avgdl = impl_->avgdl;
+  slot->delta = DeltaOf(impl_->index);
+  if (slot->delta) slot->dplans.resize(slot->queries.size());
   slot->error = Error{ErrorCode::kSuccess, ""};
   slot->timing = Timing{};
   slot->t_submit = Impl::clock::now();
@@ -1818,10 +2359,11 @@ Error BatchExecutor::WaitInto(uint64_t ticket, std::vector<BatchResult>* results
     return e;
   }
   lock.unlock();  // (the slot is this caller's until it is freed below)
-  mgx_result_view v{};
+  mgx_result_view v{}, dv{};
   const auto t0 = Impl::clock::now();
   if (!s->mq.empty()) {
-    const int rc = mgx_batch_fetch(s->batch, &v);
+    int rc = mgx_batch_fetch(s->batch, &v);
+    if (rc == MGX_OK && s->delta) rc = mgx_batch_fetch(s->dbatch, &dv);
     if (rc != MGX_OK) {
       const Error e = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
       lock.lock();
@@ -1829,7 +2371,7 @@ Error BatchExecutor::WaitInto(uint64_t ticket, std::vector<BatchResult>* results
       return e;
     }
   }
-  Collect(s->plans, v, &out);
+  Collect(s->plans, v, &out, s->delta ? &dv : nullptr);
   s->timing.wait_ms = std::chrono::duration<double, std::milli>(Impl::clock::now() - t0).count();
   if (timing) *timing = s->timing;
   lock.lock();

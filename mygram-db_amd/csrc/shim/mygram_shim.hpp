@@ -14,8 +14,9 @@
 // ordering, the empty / unknown-term rules. No exception leaves these classes (request_dispatcher.cpp:188-192).
 //
 // Differences a maintainer must know (also listed in INTEGRATION.md):
-//   * the index is static: AddDocument() only records documents until the first search; then the column arrays are
-//     built and uploaded once (binlog updates are SURVEY.md §8f N4, not built);
+//   * AddDocument() before the first search only records documents; the column arrays are then built and uploaded
+//     once. Changes after that (the binlog applier's AddDocument / UpdateDocument / RemoveDocument) go to a delta index
+//     beside the main one and a live-document row on it (see "mutable tables" below);
 //   * BM25Scorer::ScoreDocuments takes the Index where the reference takes a DocumentStore: tf and doc length come
 //     from the index's own columns, which is exact for search terms that are one n-gram long;
 //   * NormalizeText runs ICU (NFKC / width / lower) when the build found ICU, else the reference's ASCII fallback;
@@ -148,9 +149,42 @@ class Index {
     std::string text;  // normalized
   };
 
-  // Recorded on the host until the first search (static index). Returns whether the text yields any n-gram.
+  // Recorded on the host until the first search. Returns whether the text yields any n-gram.
   bool AddDocument(DocId doc_id, std::string_view text);
   void AddDocumentBatch(const std::vector<DocumentItem>& documents);
+
+  // ---- mutable tables: the binlog applier's calls after the index was built (src/index/index.h:88-117, call sites
+  // src/mysql/binlog_event_processor.cpp:96,140,225,278) --------------------------------------------------------------
+  // The device's column arrays are immutable, so a table that changes is two indexes: the MAIN index as built, whose
+  // removed / superseded documents are cleared in a live-document row every query is ANDed with, and a DELTA index over
+  // the documents added or changed since (rebuilt when it changed, before the next query). search_pipeline::ExecuteBatch,
+  // BatchExecutor, MicroBatcher and ExecuteFacet run a query on both and merge the pages on the device
+  // (mgx_batch_merge_local: the exchange of a sharded table without the wire); BM25 statistics (N, average length, df)
+  // are the table's — live documents of both — so scores equal those of an index built from the current documents.
+  // Texts are normalized (as for AddDocument); `text` / `old_text` of a removal must be the document's current text, as
+  // in the reference (its n-grams are what is taken out of the posting sizes).
+  //   AddDocument(doc, text[, filters]) after the first search: a NEW document (false + LastError() if the id is live);
+  //   UpdateDocument: the document's text becomes new_text (index.cpp:199-233); its filter values stay, or become `filters`;
+  //   RemoveDocument: the document leaves the table (index.cpp:148-197).
+  // Calls are cheap (host bookkeeping); they take effect at the next query entry point, which must not overlap another
+  // thread's query on the same Index while it applies them (one BatchExecutor / MicroBatcher per mutable table, or
+  // external exclusion — the reference holds its index write lock for the same span).
+  // Limits: BatchQuery::filters (raw bitmap ids) are per device index and are refused while a delta exists — use
+  // filter_conditions; a batch must be all SORT _score or all docid pages with 0 < limit <= 16384 (the exchange's rule);
+  // sharded tables (BatchExecutor::Options::comm) are static.
+  void UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text);
+  void UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text,
+                      const storage::FilterMap& filters);
+  void RemoveDocument(DocId doc_id, std::string_view text);
+  struct MutationStats {
+    uint64_t main_documents = 0;   // live documents of the main index
+    uint64_t delta_documents = 0;  // documents of the delta index
+    uint64_t removed_from_main = 0;
+    uint64_t epoch = 0;            // times the device state was brought up to date
+  };
+  [[nodiscard]] MutationStats GetMutationStats() const;
+  // Brings the device state up to date with the recorded changes (every query entry point calls it). "" or an error.
+  std::string ApplyMutations() const;
 
   [[nodiscard]] std::vector<DocId> SearchAnd(const std::vector<std::string>& terms, size_t limit = 0,
                                              bool reverse = false) const;

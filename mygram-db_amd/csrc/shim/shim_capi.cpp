@@ -23,7 +23,7 @@ struct mgxs_executor {
   std::unique_ptr<BatchExecutor> ex;
   std::vector<BatchQuery> queries;  // re-used between submits
   std::vector<mygramdb::search_pipeline::BatchResult> results;  // re-used between waits
-  uint32_t limit = 0;
+  std::unordered_map<uint64_t, uint32_t> limits;  // ticket -> row pitch of mgxs_wait's docs / scores
 };
 
 struct mgxs_batcher {
@@ -193,10 +193,10 @@ int mgxs_submit(mgxs_executor* ex, uint32_t n_queries, const uint32_t* n_terms, 
     return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_submit: null argument");
   try {
     FillQueries(&ex->queries, n_queries, n_terms, terms, limit, offset, sort_by_score, descending);
-    ex->limit = limit;
     auto r = ex->ex->Submit(std::move(ex->queries));  // (hands an earlier batch's objects back: built into again above)
     if (!r) return Fail(static_cast<int>(r.error().code()), r.error().message());
     *ticket = *r;
+    ex->limits[*r] = limit;
     return MGX_OK;
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
@@ -208,6 +208,9 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
   if (!ex || !totals || !n_docs || !docs) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_wait: null argument");
   try {
     BatchExecutor::Timing tm;
+    const auto lim = ex->limits.find(ticket);
+    const uint32_t limit = lim != ex->limits.end() ? lim->second : 0;
+    if (lim != ex->limits.end()) ex->limits.erase(lim);
     const auto err = ex->ex->WaitInto(ticket, &ex->results, &tm);
     if (err.code() != mygram::utils::ErrorCode::kSuccess) return Fail(static_cast<int>(err.code()), err.message());
     const auto& res = ex->results;
@@ -215,9 +218,9 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
       totals[i] = res[i].total;
       const size_t n = res[i].results.size();
       n_docs[i] = static_cast<uint32_t>(n);
-      for (size_t k = 0; k < n && k < ex->limit; ++k) {
-        docs[i * ex->limit + k] = res[i].results[k];
-        if (scores) scores[i * ex->limit + k] = k < res[i].scores.size() ? res[i].scores[k] : 0.0;
+      for (size_t k = 0; k < n && k < limit; ++k) {
+        docs[i * limit + k] = res[i].results[k];
+        if (scores) scores[i * limit + k] = k < res[i].scores.size() ? res[i].scores[k] : 0.0;
       }
     }
     if (timing_ms) {
@@ -285,6 +288,88 @@ int mgxs_table_add_filter_column(mgxs_table* table, const char* name, int value_
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
   }
+}
+
+namespace {
+mygramdb::storage::FilterMap MakeFilterMap(uint32_t n, const char* const* names, const int* types, const void* values,
+                                           const char* const* strings) {
+  mygramdb::storage::FilterMap m;
+  const int64_t* si = static_cast<const int64_t*>(values);
+  const uint64_t* ui = static_cast<const uint64_t*>(values);
+  const double* di = static_cast<const double*>(values);
+  for (uint32_t i = 0; i < n; ++i) {
+    FilterValue v;
+    switch (types[i]) {
+      case 1: v = si[i] != 0; break;
+      case 2: v = static_cast<int8_t>(si[i]); break;
+      case 3: v = static_cast<uint8_t>(ui[i]); break;
+      case 4: v = static_cast<int16_t>(si[i]); break;
+      case 5: v = static_cast<uint16_t>(ui[i]); break;
+      case 6: v = static_cast<int32_t>(si[i]); break;
+      case 7: v = static_cast<uint32_t>(ui[i]); break;
+      case 8: v = static_cast<int64_t>(si[i]); break;
+      case 9: v = static_cast<uint64_t>(ui[i]); break;
+      case 10: v = mygramdb::storage::TimeValue{si[i]}; break;
+      case 11: v = std::string(strings[i]); break;
+      case 12: v = di[i]; break;
+      default: break;  // 0: NULL
+    }
+    m[names[i]] = std::move(v);
+  }
+  return m;
+}
+}  // namespace
+
+int mgxs_table_add_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len, uint32_t n_filters,
+                            const char* const* names, const int* types, const void* values, const char* const* strings) {
+  if (!table || (len && !text)) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_add_document: null argument");
+  try {
+    const size_t stats_before = table->index->GetMutationStats().delta_documents;
+    const std::string_view t(text ? text : "", len);
+    if (n_filters) table->index->AddDocument(doc_id, t, MakeFilterMap(n_filters, names, types, values, strings));
+    else table->index->AddDocument(doc_id, t);
+    if (table->index->GetMutationStats().delta_documents == stats_before)
+      return Fail(MGX_ERR_INVALID_ARGUMENT, table->index->LastError());
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* old_text, size_t old_len, const char* new_text,
+                               size_t new_len, int with_filters, uint32_t n_filters, const char* const* names,
+                               const int* types, const void* values, const char* const* strings) {
+  if (!table || (old_len && !old_text) || (new_len && !new_text))
+    return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_update_document: null argument");
+  try {
+    const std::string_view o(old_text ? old_text : "", old_len), n(new_text ? new_text : "", new_len);
+    if (with_filters) table->index->UpdateDocument(doc_id, o, n, MakeFilterMap(n_filters, names, types, values, strings));
+    else table->index->UpdateDocument(doc_id, o, n);
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len) {
+  if (!table || (len && !text)) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_remove_document: null argument");
+  try {
+    table->index->RemoveDocument(doc_id, std::string_view(text ? text : "", len));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
+int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,
+                              uint64_t* removed_from_main, uint64_t* epoch) {
+  if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_mutation_stats: null argument");
+  const auto st = table->index->GetMutationStats();
+  if (main_documents) *main_documents = st.main_documents;
+  if (delta_documents) *delta_documents = st.delta_documents;
+  if (removed_from_main) *removed_from_main = st.removed_from_main;
+  if (epoch) *epoch = st.epoch;
+  return MGX_OK;
 }
 
 int mgxs_search(mgxs_table* table, uint32_t n_terms, const char* const* terms, uint32_t n_not, const char* const* not_terms,
