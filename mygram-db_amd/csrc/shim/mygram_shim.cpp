@@ -272,6 +272,7 @@ struct Index::Impl {
     uint32_t live_bitmap = 0;
     bool have_live = false;
     std::shared_ptr<Index> delta;               // the delta index the device holds (nullptr: none)
+    std::shared_ptr<const std::vector<DocId>> delta_ids;  // its doc map: local id - 1 -> table id, ascending
     std::vector<std::pair<uint32_t, uint64_t>> delta_contrib;  // (main gram id, the delta's posting count) inside global_sizes
   };
   mutable Mutable mut;
@@ -651,6 +652,7 @@ std::string Index::ApplyMutations() const {
     m.delta_changed = false;
     if (m.delta_docs.empty()) {
       m.delta.reset();
+      m.delta_ids.reset();
     } else {
       auto nd = std::make_shared<Index>(ngram_size_, im->query_kanji, im->dense_threshold, cross_boundary_, normalize_nfkc_,
                                         normalize_width_, normalize_lower_, im->device);
@@ -693,6 +695,7 @@ std::string Index::ApplyMutations() const {
       }
       nd->impl()->fallback = im;
       m.delta = std::move(nd);
+      m.delta_ids = std::make_shared<const std::vector<DocId>>(std::move(ids));
     }
   }
   // ---- table-wide statistics in both ------------------------------------------------------------------------------------
@@ -904,8 +907,15 @@ void Index::SetNormalization(bool nfkc, const std::string& width, bool lower) {
 
 uint64_t Index::PostingSize(std::string_view term) const {  // index.cpp:580-584
   Finalize();
+  bool mutable_table = false;
+  {
+    std::lock_guard<std::mutex> lock(impl_->mu);
+    mutable_table = impl_->mut.active;
+  }
+  if (mutable_table) ApplyMutations();  // (the live postings of both indexes: what Count() is in the reference)
   uint32_t id = 0;
-  return impl_->Lookup(term, &id) ? impl_->Size(id) : 0;
+  uint64_t size = 0;
+  return impl_->Resolve(term, &id, &size) ? size : 0;
 }
 uint64_t Index::EstimatePostingSize(std::string_view term) const { return PostingSize(term); }  // index.cpp:756-759
 
@@ -941,6 +951,112 @@ Expected<uint32_t, Error> Index::AddFilterBitmap(const std::vector<DocId>& docs)
   return id;
 }
 
+// ---- single operators on a mutable table ---------------------------------------------------------------------------------
+// The operators below answer from the column arrays of ONE device index. A table with recorded changes answers with the
+// main index's result minus its dead documents plus the delta index's result under table ids — both ascending and
+// disjoint, so one std::merge; the set semantics are per document, so evaluating each index on its own is exact.
+namespace {
+thread_local bool tl_raw_operators = false;  // inside OverBoth: the operators answer from this index's arrays alone
+struct RawScope {
+  bool prev;
+  RawScope() : prev(tl_raw_operators) { tl_raw_operators = true; }
+  ~RawScope() { tl_raw_operators = prev; }
+};
+
+bool IsMutable(const Index& index) {
+  if (tl_raw_operators) return false;
+  Index::Impl* im = index.impl();
+  std::lock_guard<std::mutex> lock(im->mu);
+  return im->mut.active;
+}
+
+struct DeltaView {
+  std::shared_ptr<Index> delta;
+  std::shared_ptr<const std::vector<DocId>> ids;
+};
+DeltaView ViewOfDelta(const Index& index) {
+  Index::Impl* im = index.impl();
+  std::lock_guard<std::mutex> lock(im->mu);
+  return DeltaView{im->mut.delta, im->mut.delta_ids};
+}
+
+// op(index) -> ascending doc ids of that one index
+template <typename Op>
+std::vector<DocId> OverBoth(const Index& index, Op op) {
+  const std::string err = index.ApplyMutations();
+  if (!err.empty()) {
+    SetDeviceError(err);
+    return {};
+  }
+  RawScope raw;
+  std::vector<DocId> a = op(index);
+  if (!tl_device_error.empty()) return {};
+  Index::Impl* im = index.impl();
+  {
+    std::lock_guard<std::mutex> lock(im->mu);
+    a.erase(std::remove_if(a.begin(), a.end(), [&](DocId d) { return !im->LiveInMain(d); }), a.end());
+  }
+  const DeltaView dv = ViewOfDelta(index);
+  if (!dv.delta) return a;
+  std::vector<DocId> b = op(*dv.delta);
+  if (!tl_device_error.empty()) return {};
+  for (DocId& d : b) d = (*dv.ids)[d - 1];
+  std::vector<DocId> out(a.size() + b.size());
+  std::merge(a.begin(), a.end(), b.begin(), b.end(), out.begin());
+  return out;
+}
+
+// The candidates of a caller's list by the index that holds them: documents of the main index that are live, documents of
+// the delta index under its local ids; anything else is not a document of the table. ApplyMutations has run.
+struct SplitCandidates {
+  DeltaView view;
+  std::vector<DocId> main_docs, delta_docs;
+  std::vector<size_t> main_pos, delta_pos;  // positions in the caller's list
+  SplitCandidates(const Index& index, const std::vector<DocId>& candidates) : view(ViewOfDelta(index)) {
+    Index::Impl* im = index.impl();
+    std::lock_guard<std::mutex> lock(im->mu);
+    for (size_t i = 0; i < candidates.size(); ++i) {
+      const DocId c = candidates[i];
+      if (im->LiveInMain(c)) {
+        main_docs.push_back(c);
+        main_pos.push_back(i);
+      } else if (view.ids) {
+        const auto it = std::lower_bound(view.ids->begin(), view.ids->end(), c);
+        if (it != view.ids->end() && *it == c) {
+          delta_docs.push_back(static_cast<DocId>(it - view.ids->begin()) + 1);
+          delta_pos.push_back(i);
+        }
+      }
+    }
+  }
+  // `kept` is `given` with some documents taken out (every copy of a document, or none): mark what stayed
+  static void MarkKept(const std::vector<DocId>& given, const std::vector<size_t>& pos, const std::vector<DocId>& kept,
+                       std::vector<uint8_t>* keep) {
+    size_t k = 0;
+    for (size_t i = 0; i < given.size() && k < kept.size(); ++i)
+      if (given[i] == kept[k]) {
+        (*keep)[pos[i]] = 1;
+        ++k;
+      }
+  }
+};
+
+// PostingList::GetTopN / the tail of Index::SearchAnd (posting_list.cpp:476-514, index.cpp:352-366) over an ascending list
+std::vector<DocId> FinishTopN(std::vector<DocId> all, size_t limit, bool reverse) {
+  if (limit > 0 && all.size() > limit) {
+    if (reverse) {
+      all.erase(all.begin(), all.begin() + static_cast<std::ptrdiff_t>(all.size() - limit));
+      std::reverse(all.begin(), all.end());
+    } else {
+      all.resize(limit);
+    }
+  } else if (reverse) {
+    std::reverse(all.begin(), all.end());
+  }
+  return all;
+}
+}  // namespace
+
 std::vector<DocId> Index::SearchAnd(const std::vector<std::string>& terms, size_t limit, bool reverse) const {
   ClearDeviceError();
   if (terms.empty()) return {};  // index.cpp:203
@@ -949,6 +1065,8 @@ std::vector<DocId> Index::SearchAnd(const std::vector<std::string>& terms, size_
     SetDeviceError(impl_->last_error);
     return {};
   }
+  if (IsMutable(*this))
+    return FinishTopN(OverBoth(*this, [&](const Index& ix) { return ix.SearchAnd(terms, 0, false); }), limit, reverse);
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -973,6 +1091,7 @@ std::vector<DocId> Index::SearchOr(const std::vector<std::string>& terms) const 
     SetDeviceError(impl_->last_error);
     return {};
   }
+  if (IsMutable(*this)) return OverBoth(*this, [&](const Index& ix) { return ix.SearchOr(terms); });
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
     uint32_t id = 0;
@@ -998,6 +1117,13 @@ std::vector<DocId> Index::SearchNot(const std::vector<DocId>& all_docs, const st
   if (!impl_->dev) {
     SetDeviceError(impl_->last_error);
     return {};
+  }
+  if (IsMutable(*this)) {  // index.cpp:456-484 as written: the union of the terms' lists, then std::set_difference
+    const std::vector<DocId> uni = OverBoth(*this, [&](const Index& ix) { return ix.SearchOr(terms); });
+    if (!tl_device_error.empty()) return {};
+    std::vector<DocId> res;
+    std::set_difference(all_docs.begin(), all_docs.end(), uni.begin(), uni.end(), std::back_inserter(res));
+    return res;
   }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
@@ -1047,6 +1173,7 @@ std::vector<DocId> Index::SearchByThreshold(const std::vector<std::string>& term
     SetDeviceError(impl_->last_error);
     return {};
   }
+  if (IsMutable(*this)) return OverBoth(*this, [&](const Index& ix) { return ix.SearchByThreshold(terms, threshold); });
   std::vector<uint32_t> ids;
   for (const auto& t : uniq) {
     uint32_t id = 0;
@@ -1073,6 +1200,30 @@ std::vector<DocId> Index::FilterByNgrams(const std::vector<DocId>& candidates,
   if (!impl_->dev) {
     SetDeviceError(impl_->last_error);
     return {};
+  }
+  if (IsMutable(*this)) {
+    // every candidate belongs to one index (or to neither: not a live document); each index filters its own, and the
+    // caller's order — repeats included — is put back from the two answers, which are subsequences of what they were given
+    const std::string err = ApplyMutations();
+    if (!err.empty()) {
+      SetDeviceError(err);
+      return {};
+    }
+    RawScope raw;
+    SplitCandidates split(*this, candidates);
+    std::vector<uint8_t> keep(candidates.size(), 0);
+    const std::vector<DocId> km = split.main_docs.empty() ? std::vector<DocId>() : FilterByNgrams(split.main_docs, terms);
+    if (!tl_device_error.empty()) return {};
+    split.MarkKept(split.main_docs, split.main_pos, km, &keep);
+    if (split.view.delta && !split.delta_docs.empty()) {
+      const std::vector<DocId> kd = split.view.delta->FilterByNgrams(split.delta_docs, terms);
+      if (!tl_device_error.empty()) return {};
+      split.MarkKept(split.delta_docs, split.delta_pos, kd, &keep);
+    }
+    std::vector<DocId> out;
+    for (size_t i = 0; i < candidates.size(); ++i)
+      if (keep[i]) out.push_back(candidates[i]);
+    return out;
   }
   std::vector<uint32_t> ids;
   for (const auto& t : terms) {
@@ -1113,6 +1264,28 @@ Expected<std::vector<ScoredDoc>, Error> BM25Scorer::ScoreDocuments(const std::ve
   index.Finalize();
   Index::Impl* im = index.impl();
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
+  if (IsMutable(index)) {
+    // a document's score comes from its own text (tf, length) and the caller's statistics: each index scores its own
+    // candidates; an id that is no live document scores 0.0, like a document the store does not hold (bm25_scorer.cpp:73-76)
+    const std::string err = index.ApplyMutations();
+    if (!err.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, err));
+    RawScope raw;
+    SplitCandidates split(index, candidates);
+    std::vector<ScoredDoc> out;
+    out.reserve(candidates.size());
+    for (DocId c : candidates) out.push_back({c, 0.0});
+    if (!split.main_docs.empty()) {
+      auto r = ScoreDocuments(split.main_docs, search_terms, term_doc_freqs, index, total_docs, avg_doc_length, params);
+      if (!r) return r;
+      for (size_t i = 0; i < r->size(); ++i) out[split.main_pos[i]].score = (*r)[i].score;
+    }
+    if (split.view.delta && !split.delta_docs.empty()) {
+      auto r = ScoreDocuments(split.delta_docs, search_terms, term_doc_freqs, *split.view.delta, total_docs, avg_doc_length, params);
+      if (!r) return r;
+      for (size_t i = 0; i < r->size(); ++i) out[split.delta_pos[i]].score = (*r)[i].score;
+    }
+    return out;
+  }
   std::vector<uint32_t> ids;
   std::vector<double> idfs;
   bool all_single_gram = true;

@@ -132,6 +132,69 @@ int main() {
     EXPECT(index.FilterByNgrams({}, {"a"}).empty());
     EXPECT(index.FilterByNgrams({3, 3, 6000, 6001}, {"b"}) == (V{3, 3, 6000}));
   }
+  {  // tests/index/index_basic_test.cpp:103-121 RemoveDocument, :126-144 UpdateDocument (after the index was built: the
+     // live row + delta index of a mutable table)
+    Index index(1);
+    index.AddDocument(1, "abc");
+    index.AddDocument(2, "bcd");
+    EXPECT(index.Count("a") == 1 && index.Count("b") == 2 && index.Count("c") == 2);
+    index.RemoveDocument(1, "abc");
+    EXPECT(index.Count("a") == 0 && index.Count("b") == 1 && index.Count("c") == 1 && index.Count("d") == 1);
+    EXPECT(index.SearchAnd({"b"}) == (V{2}));
+    EXPECT(index.SearchOr({"a", "d"}) == (V{2}));
+    Index upd(1);
+    upd.AddDocument(1, "abc");
+    EXPECT(upd.Count("a") == 1 && upd.Count("d") == 0);
+    upd.UpdateDocument(1, "abc", "bcd");
+    EXPECT(upd.Count("a") == 0 && upd.Count("b") == 1 && upd.Count("c") == 1 && upd.Count("d") == 1);
+    EXPECT(upd.SearchAnd({"d"}) == (V{1}) && upd.SearchAnd({"a"}).empty());
+    // :256-339 updates that empty posting lists; repeated updates of one document
+    upd.UpdateDocument(1, "bcd", "xyz");
+    EXPECT(upd.Count("x") == 1 && upd.Count("y") == 1 && upd.Count("z") == 1);
+    EXPECT(upd.Count("b") == 0 && upd.Count("c") == 0 && upd.Count("d") == 0);
+    Index rep(1);
+    rep.AddDocument(1, "a");
+    EXPECT(rep.Count("a") == 1);
+    rep.UpdateDocument(1, "a", "b");
+    rep.UpdateDocument(1, "b", "c");
+    rep.UpdateDocument(1, "c", "d");
+    rep.UpdateDocument(1, "d", "e");
+    EXPECT(rep.Count("e") == 1 && rep.Count("a") == 0 && rep.Count("b") == 0 && rep.Count("c") == 0 && rep.Count("d") == 0);
+    EXPECT(rep.SearchAnd({"e"}) == (V{1}));
+  }
+  {  // tests/index/index_basic_test.cpp:149-184 UpdateDocumentMaintainsTopNOrdering
+    Index index(1);
+    const DocId kBase = 512;
+    for (DocId d = 1; d <= kBase; ++d) index.AddDocument(d, "aaaa");
+    index.AddDocument(kBase + 1, "zzzz");
+    EXPECT(index.SearchAnd({"a"}, 3, true) == (V{kBase, kBase - 1, kBase - 2}));
+    EXPECT(index.Count("a") == kBase);
+    index.UpdateDocument(kBase, "aaaa", "zzzz");
+    EXPECT(index.SearchAnd({"a"}, 3, true) == (V{kBase - 1, kBase - 2, kBase - 3}));
+    EXPECT(index.Count("a") == kBase - 1);
+    index.UpdateDocument(kBase + 1, "zzzz", "aaaa");
+    EXPECT(index.SearchAnd({"a"}, 3, true) == (V{kBase + 1, kBase - 1, kBase - 2}));
+    EXPECT(index.Count("a") == kBase);
+    // the other single operators over both indexes
+    EXPECT(index.SearchOr({"z"}) == (V{kBase}));
+    EXPECT(index.SearchNot({1, 2, kBase, kBase + 1}, {"z"}) == (V{1, 2, kBase + 1}));
+    EXPECT(index.SearchByThreshold({"a", "z"}, 1).size() == kBase + 1);
+    EXPECT(index.FilterByNgrams({kBase + 1, 5, kBase, 5, 9999}, {"a"}) == (V{kBase + 1, 5, 5}));
+    auto sc = BM25Scorer::ScoreDocuments({kBase, kBase + 1, 7, 9999}, {"a"}, {index.Count("a")}, index, kBase + 1, 4.0, BM25Params{});
+    EXPECT(sc.has_value() && sc->size() == 4);
+    if (sc.has_value() && sc->size() == 4) {
+      EXPECT((*sc)[0].score == 0.0);                       // "zzzz" now: no occurrence of the term
+      EXPECT((*sc)[1].score > 0.0 && (*sc)[1].score == (*sc)[2].score);  // "aaaa" in the delta = "aaaa" in the main index
+      EXPECT((*sc)[3].score == 0.0);                       // not a document
+    }
+    // and the batched pipeline: the page holds the delta's document under its table id
+    mygramdb::search_pipeline::BatchQuery q;
+    q.terms = {"a"};
+    q.limit = 3;
+    auto r = mygramdb::search_pipeline::ExecuteBatch(index, {q});
+    EXPECT(r.has_value() && (*r)[0].total == kBase && (*r)[0].results == (V{kBase + 1, kBase - 1, kBase - 2}));
+    if (r.has_value()) EXPECT((*r)[0].total_candidates == kBase && (*r)[0].after_filters == kBase);
+  }
   {  // tests/index/bm25_scorer_test.cpp:21-48
     EXPECT(std::fabs(BM25Scorer::ComputeIDF(100, 10) - std::log(90.5 / 10.5 + 1.0)) < 1e-10);
     EXPECT(BM25Scorer::ComputeIDF(0, 10) == 0.0);
