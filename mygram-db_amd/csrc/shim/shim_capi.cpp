@@ -343,8 +343,12 @@ int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* o
     return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_update_document: null argument");
   try {
     const std::string_view o(old_text ? old_text : "", old_len), n(new_text ? new_text : "", new_len);
+    const std::string before = table->index->LastError();
     if (with_filters) table->index->UpdateDocument(doc_id, o, n, MakeFilterMap(n_filters, names, types, values, strings));
     else table->index->UpdateDocument(doc_id, o, n);
+    // (the reference's signature returns nothing: a refused change shows in LastError())
+    if (table->index->LastError() != before && !table->index->LastError().empty())
+      return Fail(MGX_ERR_INVALID_ARGUMENT, table->index->LastError());
     return MGX_OK;
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
@@ -354,7 +358,10 @@ int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* o
 int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len) {
   if (!table || (len && !text)) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_remove_document: null argument");
   try {
+    const std::string before = table->index->LastError();
     table->index->RemoveDocument(doc_id, std::string_view(text ? text : "", len));
+    if (table->index->LastError() != before && !table->index->LastError().empty())
+      return Fail(MGX_ERR_INVALID_ARGUMENT, table->index->LastError());
     return MGX_OK;
   } catch (const std::exception& e) {
     return Fail(MGX_ERR_INTERNAL, e.what());
