@@ -83,7 +83,7 @@ int mgxs_wait(mgxs_executor* ex, uint64_t ticket, uint64_t* totals, uint32_t* n_
 int mgxs_table_add_filter_column(mgxs_table* table, const char* name, int value_type, uint64_t n, const void* values,
                                  const char* const* strings, const uint8_t* is_null);
 /* Mutable tables (Index::AddDocument / UpdateDocument / RemoveDocument after the index was built: the binlog applier's calls,
- * src/mysql/binlog_event_processor.cpp:96,140,225,278). Texts are normalized. A document's filter values travel as
+ * src/mysql/binlog_event_processor.cpp:96,138,184,234,283). Texts are normalized. A document's filter values travel as
  * n_filters (name, type, 8-byte value | string) tuples: types as in mgxs_table_add_filter_column, 0 = NULL. Changes take
  * effect at the next search / submit on the table. */
 int mgxs_table_add_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len, uint32_t n_filters,

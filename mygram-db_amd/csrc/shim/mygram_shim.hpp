@@ -154,7 +154,7 @@ class Index {
   void AddDocumentBatch(const std::vector<DocumentItem>& documents);
 
   // ---- mutable tables: the binlog applier's calls after the index was built (src/index/index.h:88-117, call sites
-  // src/mysql/binlog_event_processor.cpp:96,140,225,278) --------------------------------------------------------------
+  // src/mysql/binlog_event_processor.cpp:96,138,184,234,283) --------------------------------------------------------------
   // The device's column arrays are immutable, so a table that changes is two indexes: the MAIN index as built, whose
   // removed / superseded documents are cleared in a live-document row every query is ANDed with, and a DELTA index over
   // the documents added or changed since (rebuilt when it changed, before the next query). search_pipeline::ExecuteBatch,

@@ -1,5 +1,5 @@
 """-m gpu: a table that changes after its index was built — Index::AddDocument / UpdateDocument /
-RemoveDocument as the binlog applier calls them (src/mysql/binlog_event_processor.cpp:96,140,225,278; index.cpp:39-233)
+RemoveDocument as the binlog applier calls them (src/mysql/binlog_event_processor.cpp:96,138,184,234,283; index.cpp:39-233)
 through the C++ shim: a live-document row on the main index + a delta index, merged on the device. The bar: after any
 sequence of changes, pages, totals and BM25 scores equal those of an index BUILT from the table's current documents
 (what the reference's index holds after the same calls), bit for bit — checked against the oracle over such an index."""
