@@ -2301,10 +2301,23 @@ struct BatchExecutor::Impl {
         if (rc == MGX_OK && slot->delta) {
           rc = RunWithDelta(slot->batch, slot->dbatch, stream);  // both indexes + the merge, on this one stream
         } else {
+          static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
+          const auto e0 = clock::now();
           if (rc == MGX_OK && comm) rc = mgx_batch_exchange_df(slot->batch, comm, stream);  // table-wide df before idf
+          const auto e1 = clock::now();
           if (rc == MGX_OK)                                                                 // asynchronous
             rc = comm ? mgx_batch_execute_sharded(slot->batch, comm, stream) : mgx_batch_execute(slot->batch, stream);
+          const auto e2 = clock::now();
           if (rc == MGX_OK && comm) rc = mgx_batch_exchange(slot->batch, comm, stream);     // all-gather + merge
+          if (kTrace) {
+            static std::atomic<uint64_t> n{0}, a{0}, b{0}, c{0};
+            a += std::chrono::duration_cast<std::chrono::nanoseconds>(e1 - e0).count();
+            b += std::chrono::duration_cast<std::chrono::nanoseconds>(e2 - e1).count();
+            c += std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - e2).count();
+            if (++n % 64 == 0)
+              fprintf(stderr, "[shim] enqueue per batch: exchange_df %.1f us, execute %.1f us, exchange %.1f us\n",
+                      a.exchange(0) / 64e3, b.exchange(0) / 64e3, c.exchange(0) / 64e3);
+          }
         }
         if (rc != MGX_OK) slot->error = MakeError(static_cast<ErrorCode>(rc), mgx_last_error());
         slot->timing.enqueue_ms = std::chrono::duration<double, std::milli>(clock::now() - t0).count();
