@@ -1772,8 +1772,10 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
           leaves.push_back(nd.term);
           tis.push_back(MakeInfo(index, im, nd.term));
         }
-        // a term with an unknown gram (or none at all) is an empty doc set inside the tree
-        const bool empty = tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX;
+        // a term with an unknown gram is an empty doc set inside the tree; a term shorter than one n-gram is the documents
+        // whose text contains it (regular_term_search -> SearchTermDocuments, search_pipeline.cpp:1446-1455, :438-446)
+        const bool substring = tis[k].n_grams == 0 && !tis[k].normalized.empty();
+        const bool empty = !substring && (tis[k].estimated_size == 0 || tis[k].estimated_size == UINT64_MAX);
         p->expr.push_back(empty ? mgx_expr_token{MGX_EXPR_EMPTY, 0} : mgx_expr_token{MGX_EXPR_TERM, static_cast<uint32_t>(k)});
         // (a leaf with an unknown gram occurs in no text: tf = df = 0, it adds nothing to any score)
         if (q.sort_by_score && !under_not && !empty) p->score_list.push_back(static_cast<uint32_t>(k));
@@ -1794,6 +1796,13 @@ void PlanQuery(const index::Index& index, const BatchQuery& q, uint64_t total_do
       return Fail(p, ErrorCode::kInvalidArgument, "malformed expression tree");
     p->ids.reserve(leaves.size() + q.not_terms.size());
     for (auto& ti : tis) {
+      if (ti.n_grams == 0 && !ti.normalized.empty()) {  // substring leaf: a text scan on the device
+        p->ids.emplace_back();
+        p->texts.push_back(ti.normalized);
+        p->terms.push_back(mgx_term{nullptr, 0, 0, 0.0, reinterpret_cast<const uint8_t*>(p->texts.back().data()),
+                                    static_cast<uint32_t>(p->texts.back().size())});
+        continue;
+      }
       const bool empty_leaf = ti.gram_ids.empty() || ti.estimated_size == 0 || ti.estimated_size == UINT64_MAX;
       if (empty_leaf) ti.gram_ids.assign(1, 0u);  // placeholder of an EMPTY leaf
       p->ids.push_back(ti.gram_ids);

@@ -368,6 +368,31 @@ int main() {
     } else {
       std::printf("ExecuteBatch(ast) error: %s\n", r.error().message().c_str());
     }
+    // a leaf shorter than one n-gram is the documents whose text contains it (regular_term_search ->
+    // SearchTermDocuments -> SearchNormalizedSubstring, search_pipeline.cpp:1446-1455, :438-446), inside the tree too
+    Index sub(2, 0, 0.0, false);
+    sub.AddDocument(1, "hello world");
+    sub.AddDocument(2, "help a");
+    sub.AddDocument(3, "yellow");
+    sub.AddDocument(4, "a hello");
+    std::vector<BatchQuery> ss(4);
+    ss[0].ast = node(NodeType::AND, kids(term("hello"), term("a")));   // "a": docs 2, 4
+    ss[1].ast = node(NodeType::OR, kids(term("a"), term("yellow")));
+    ss[2].ast = node(NodeType::NOT, kids(term("a")));
+    ss[3].ast = node(NodeType::AND, kids(term("hello"), term("a")));
+    ss[3].sort_by_score = true;
+    for (auto& q : ss) q.order = SortOrder::ASC;
+    ss[3].order = SortOrder::DESC;
+    auto rs = ExecuteBatch(sub, ss);
+    EXPECT(rs.has_value());
+    if (rs) {
+      EXPECT((*rs)[0].results == (V{4}));
+      EXPECT((*rs)[1].results == (V{2, 3, 4}));
+      EXPECT((*rs)[2].results == (V{1, 3}));
+      EXPECT((*rs)[3].results == (V{4}) && (*rs)[3].scores.size() == 1 && (*rs)[3].scores[0] > 0.0);
+    } else {
+      std::printf("ExecuteBatch(ast, substring leaf) error: %s\n", rs.error().message().c_str());
+    }
   }
   {  // SORT _score over the boolean and FUZZY branches: the batch path must return what the reference's composition
      // returns — the branch's result set, BM25Scorer::ScoreDocuments over the POSITIVE terms (search_handler.cpp:428-456;
