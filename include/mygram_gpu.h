@@ -497,7 +497,15 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
  * to the delta index takes its filter values along). value_id may be NULL. */
 int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,
                                  uint32_t* value_id);
+/* enable: 0 off, 1 on, MGX_LIVE_BITMAPS_CLEAN: on, and the caller also takes every dead document out of the bitmap form of
+ * its dense grams (mgx_index_clear_postings with the document's distinct n-grams, BEFORE clearing its live bit): a query
+ * whose first term is made of bitmap-form grams only then holds live documents by construction and gets no live-row operand
+ * (the benchmark's 3-term AND keeps its three operands). */
+#define MGX_LIVE_BITMAPS_CLEAN 3
 int mgx_index_set_live_bitmap(mgx_index* idx, uint32_t bitmap_id, int enable);
+/* Clears posting (docids[i], gram_ids[i]) in the gram's bitmap form, if it has one (list-form grams are left alone: queries
+ * that read them keep the live-row operand). Same ordering rule as mgx_index_update_filter_bitmap. */
+int mgx_index_clear_postings(mgx_index* idx, const uint32_t* docids, const uint32_t* gram_ids, uint64_t n);
 int mgx_index_update_filter_bitmap(mgx_index* idx, uint32_t bitmap_id, const uint32_t* set_docids, uint64_t n_set,
                                    const uint32_t* clear_docids, uint64_t n_clear);
 int mgx_index_set_doc_map(mgx_index* idx, const uint32_t* table_ids, uint64_t n);

@@ -364,6 +364,9 @@ struct mgx_index {
   // Mutable tables (mgx_index_set_live_bitmap): the filter row every batched query is ANDed with right after its first
   // term — the documents of this index that are still live (removed / superseded ones cleared) — or kNoRow.
   std::atomic<uint32_t> live_row{mgx::kNoRow};
+  // the bitmap form of every dense gram excludes the dead documents too (mgx_index_clear_postings was called for each of
+  // them): a term whose grams are all bitmap-form is live by construction and takes no live-row operand
+  std::atomic<bool> bitmaps_clean{false};
   DevBuf d_doc_map;  // mgx_index_set_doc_map: local slot -> table doc id (a delta index), or empty
   DevBuf d_fine_rows;                 // fine row -> bitmap row
   std::vector<uint32_t> h_fine_map;   // bitmap row -> fine row (kNoRow: none)
@@ -1095,12 +1098,43 @@ int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t do
   return MGX_OK;
 }
 
+int mgx_index_clear_postings(mgx_index* idx, const uint32_t* docids, const uint32_t* gram_ids, uint64_t n) {
+  if (!idx || (n && (!docids || !gram_ids))) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_clear_postings: null argument");
+  if (n > 0xFFFFFFFFull) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_clear_postings: too many postings in one call");
+  try {
+    std::vector<uint32_t> slots, rows;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (docids[i] < idx->dev.first_doc_id || docids[i] - idx->dev.first_doc_id >= idx->dev.n_docs)
+        return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_clear_postings: doc id outside the index range");
+      if (gram_ids[i] >= idx->n_grams) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_clear_postings: unknown gram id");
+      const uint32_t row = idx->h_bm_row[gram_ids[i]];
+      if (row == mgx::kNoRow) continue;  // (a list-form gram: its queries keep the live-row operand)
+      slots.push_back(docids[i] - idx->dev.first_doc_id);
+      rows.push_back(row);
+    }
+    if (slots.empty()) return MGX_OK;
+    std::lock_guard<std::mutex> lock(idx->mu);
+    MGX_HIP(hipSetDevice(idx->device));
+    DevBuf d_slots, d_rows;
+    MGX_HIP(mgx::Upload(d_slots, slots.data(), slots.size()));
+    MGX_HIP(mgx::Upload(d_rows, rows.data(), rows.size()));
+    MGX_LAUNCH(mgx::LaunchClearGramBits(idx->d_gram_bitmaps.as<uint64_t>(), idx->dev.gb_tile_stride, idx->dev.gb_row_stride,
+                                        d_slots.as<uint32_t>(), d_rows.as<uint32_t>(), static_cast<uint32_t>(slots.size()),
+                                        idx->stream));
+    MGX_HIP(hipStreamSynchronize(idx->stream));
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_index_clear_postings: ") + e.what());
+  }
+}
+
 int mgx_index_set_live_bitmap(mgx_index* idx, uint32_t bitmap_id, int enable) {
   if (!idx) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_set_live_bitmap: null index");
   std::lock_guard<std::mutex> lock(idx->mu);
   if (enable && bitmap_id >= idx->n_filter_rows)
     return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_set_live_bitmap: unknown bitmap id");
   idx->live_row.store(enable ? bitmap_id : mgx::kNoRow);
+  idx->bitmaps_clean.store(enable == MGX_LIVE_BITMAPS_CLEAN);
   std::lock_guard<std::mutex> tl(idx->table_mu);
   idx->df_cache.clear();
   return MGX_OK;
@@ -1351,8 +1385,17 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
   // a mutable table's main index: only its live documents exist (a removed document is in no posting list of the
   // reference, index.cpp:148-197), so every funnel counter counts live documents only
   const uint32_t live_row = idx->live_row.load(std::memory_order_relaxed);
-  auto and_live = [&]() {
+  const bool bitmaps_clean = idx->bitmaps_clean.load(std::memory_order_relaxed);
+  // (a term that is an AND of bitmap-form grams holds live documents only when the index keeps its bitmaps clean)
+  auto live_by_construction = [&](const mgx_term& t) {
+    if (!bitmaps_clean || t.n_grams == 0 || (t.threshold != 0 && t.threshold < t.n_grams)) return false;
+    for (uint32_t g = 0; g < t.n_grams; ++g)
+      if (t.gram_ids[g] != MGX_GRAM_ABSENT && idx->h_bm_row[t.gram_ids[g]] == kNoRow) return false;
+    return true;
+  };
+  auto and_live = [&](const mgx_term* first_term = nullptr) {
     if (live_row == kNoRow) return;
+    if (first_term != nullptr && live_by_construction(*first_term)) return;
     c.Emit(kOpAnd, c.FilterLeaf(live_row));
   };
   if (in.n_expr > 0) {
@@ -1434,7 +1477,7 @@ static int CompileQuery(const mgx_index* idx, const mgx_query& in, QuerySpec* ou
     c.Emit(kOpCount, 1);
   } else {
     c.LoadTerm(in.terms[0]);
-    and_live();
+    and_live(&in.terms[0]);
     c.Emit(kOpCount, 0);
     for (uint32_t i = 1; i < in.n_terms; ++i) {
       const mgx_term& t = in.terms[i];
@@ -2492,7 +2535,9 @@ static int PrepareInto(mgx_batch* b, mgx_index* idx, std::vector<QuerySpec>&& sp
           c.Emit(kOpLoad, c.GramLeaf(tt.grams[0]));
           for (size_t k = 1; k < tt.grams.size(); ++k) c.Emit(kOpAnd, c.GramLeaf(tt.grams[k]));
           const uint32_t live_row = idx->live_row.load(std::memory_order_relaxed);
-          if (live_row != kNoRow) c.Emit(kOpAnd, c.FilterLeaf(live_row));  // (df counts live documents only)
+          bool all_bitmaps = idx->bitmaps_clean.load(std::memory_order_relaxed);
+          for (uint32_t gid : tt.grams) all_bitmaps = all_bitmaps && (gid == MGX_GRAM_ABSENT || idx->h_bm_row[gid] != kNoRow);
+          if (live_row != kNoRow && !all_bitmaps) c.Emit(kOpAnd, c.FilterLeaf(live_row));  // (df counts live documents only)
         }
         for (uint32_t gid : tt.grams)
           mn = std::min<uint64_t>(mn, gid == MGX_GRAM_ABSENT ? 0 : idx->h_offsets[gid + 1] - idx->h_offsets[gid]);

@@ -3955,6 +3955,27 @@ int LaunchUpdateBitmap(uint64_t* row, const uint32_t* slots, uint32_t n_set, uin
   return 0;
 }
 
+// Postings of dead documents taken out of the bitmap form of their dense grams: pair i = (doc slot, bitmap row). A query
+// whose operands are all bitmap-form then needs no live-row operand at all.
+__global__ __launch_bounds__(256) void clear_gram_bits_kernel(unsigned long long* __restrict__ bitmaps, uint64_t tile_stride,
+                                                              uint64_t row_stride, const uint32_t* __restrict__ slots,
+                                                              const uint32_t* __restrict__ rows, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t slot = slots[i];
+  const uint64_t tile = slot / kTileDocs, w = (slot % kTileDocs) >> 6;
+  atomicAnd(&bitmaps[tile * tile_stride + static_cast<uint64_t>(rows[i]) * row_stride + w], ~(1ull << (slot & 63u)));
+}
+
+int LaunchClearGramBits(uint64_t* bitmaps, uint64_t tile_stride, uint64_t row_stride, const uint32_t* slots,
+                        const uint32_t* rows, uint32_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(clear_gram_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<unsigned long long*>(bitmaps), tile_stride, row_stride, slots, rows, n);
+  MGX_KCHECK();
+  return 0;
+}
+
 // The doc ids of one exchange blob (mgx_batch_export_topk layout) through the index's doc map: a delta index numbers its
 // documents 1..n in ascending order of their table ids, so best-first order and ties are kept. Entries are in ordering
 // form (the id for descending queries, its complement for ascending ones); page blobs carry the same value as their key.

@@ -53,6 +53,8 @@ int LaunchFilterCompare(const uint64_t* values, const uint8_t* is_null, uint32_t
 int LaunchFacetCount(const uint64_t* rbits, uint32_t n_words, const uint32_t* value_ids, uint32_t n_docs, uint32_t n_values,
                      unsigned long long* counts, hipStream_t s);
 int LaunchUpdateBitmap(uint64_t* row, const uint32_t* slots, uint32_t n_set, uint32_t n_total, hipStream_t s);
+int LaunchClearGramBits(uint64_t* bitmaps, uint64_t tile_stride, uint64_t row_stride, const uint32_t* slots,
+                        const uint32_t* rows, uint32_t n, hipStream_t s);
 int LaunchRemapBlobDocs(const DevQuery* queries, uint32_t n, uint32_t stride, const uint32_t* map, uint32_t first_doc_id,
                         uint32_t n_docs, uint64_t* blob64, uint32_t* blob32, hipStream_t s);
 int LaunchAddU64(uint64_t* dst, const uint64_t* src, uint32_t n, hipStream_t s);

@@ -264,6 +264,7 @@ struct Index::Impl {
     std::vector<uint64_t> main_live;            // live documents of the main index, by slot
     std::vector<DocId> pending_clear;           // main documents removed / superseded since the last apply
     std::vector<uint32_t> pending_dead_grams;   // their distinct n-grams (main gram ids): one posting less each
+    std::vector<DocId> pending_dead_docs;       // parallel to pending_dead_grams: the document of each posting
     std::map<DocId, std::string> delta_docs;    // documents of the delta index: table id -> normalized text
     std::map<DocId, storage::FilterMap> delta_filters;
     bool delta_changed = false;
@@ -530,7 +531,10 @@ void RemoveLocked(const Index& index, Index::Impl* im, DocId doc_id, std::string
   DeduplicateSorted(grams);
   for (const auto& g : grams) {
     uint32_t id = 0;
-    if (im->Lookup(g, &id)) m.pending_dead_grams.push_back(id);
+    if (im->Lookup(g, &id)) {
+      m.pending_dead_grams.push_back(id);
+      m.pending_dead_docs.push_back(doc_id);
+    }
   }
   const uint32_t dl = im->view.doc_len[slot];
   if (dl > 0) {  // BM25Stats::RemoveDocument (binlog_event_processor.cpp:140-142)
@@ -626,6 +630,12 @@ std::string Index::ApplyMutations() const {
     return im->last_error;
   };
   if (mgx_index_synchronize(im->dev) != MGX_OK) return fail(mgx_last_error());
+  // ---- the dead documents' postings leave the bitmap form of their dense grams (a query over bitmap-form grams then
+  // needs no live-row operand), then their live bits go --------------------------------------------------------------
+  if (!m.pending_dead_grams.empty() &&
+      mgx_index_clear_postings(im->dev, m.pending_dead_docs.data(), m.pending_dead_grams.data(), m.pending_dead_grams.size()) != MGX_OK)
+    return fail(mgx_last_error());
+  m.pending_dead_docs.clear();
   // ---- the live row of the main index ---------------------------------------------------------------------------------
   if (!m.have_live) {
     std::vector<DocId> live;
@@ -633,7 +643,7 @@ std::string Index::ApplyMutations() const {
     for (uint64_t slot = 0; slot < im->view.n_docs; ++slot)
       if ((m.main_live[slot >> 6] >> (slot & 63)) & 1) live.push_back(im->view.first_doc_id + static_cast<DocId>(slot));
     if (mgx_index_add_filter_bitmap(im->dev, live.data(), live.size(), &m.live_bitmap) != MGX_OK) return fail(mgx_last_error());
-    if (mgx_index_set_live_bitmap(im->dev, m.live_bitmap, 1) != MGX_OK) return fail(mgx_last_error());
+    if (mgx_index_set_live_bitmap(im->dev, m.live_bitmap, MGX_LIVE_BITMAPS_CLEAN) != MGX_OK) return fail(mgx_last_error());
     m.have_live = true;
     im->has_gaps = false;  // (the live row is also the NOT universe: ids never added are not in it)
   } else if (!m.pending_clear.empty()) {
