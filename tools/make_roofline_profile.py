@@ -9,6 +9,8 @@ bench.py prints them only while the kernel sources still hash to the same value.
 --main:  tools/profile.sh <tag> bitmap_score_kernel                       (the benchmark's dominant kernel)
 --docid: tools/profile.sh <tag> wave_count_kernel MGX_BENCH_SORT=docid    (intersection only, bitmap-form lists)
 --lists: tools/profile.sh <tag> merge_score_kernel MGX_BENCH_DENSE=2      (index WITHOUT bitmaps: sorted posting arrays)
+--listsdoc: tools/profile.sh <tag> wave_count_kernel MGX_BENCH_SORT=docid MGX_BENCH_DENSE=2 MGX_CAND=0
+                                                                           (the same arrays, intersection only)
 The summaries (and the kernel-trace stats) are copied into profiles/ under the tag."""
 import argparse
 import json
@@ -63,6 +65,7 @@ def main():
     ap.add_argument("--main", required=True)
     ap.add_argument("--docid")
     ap.add_argument("--lists")
+    ap.add_argument("--listsdoc")
     ap.add_argument("--tag", default="r03_final")
     a = ap.parse_args()
     commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -102,6 +105,25 @@ def main():
             e["frac"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
             e["traffic_over_algorithmic"] = x["traffic_bytes_corrected"] / alg
         out["intersection"]["posting_arrays"] = e
+    if a.listsdoc:
+        d, f = take(a.listsdoc, a.tag, "listsdoc")
+        x = d["derived"]
+        ms, _ = stats_ms(a.listsdoc, "wave_count_kernel")
+        x["kernel_ms_mean"] = ms or x["kernel_ms_mean"]
+        bl = bench_line(a.listsdoc)
+        alg = bl["roofline"]["algorithmic_bytes_per_launch"] if bl else None
+        e = {"kernel": "mgx::wave_count_kernel<lists> (the benchmark batch WITHOUT scoring on an index WITHOUT bitmaps: "
+                       "MGX_BENCH_SORT=docid MGX_BENCH_DENSE=2 MGX_CAND=0 — intersection of sorted u32 posting arrays, "
+                       "exact totals, docid-DESC pages of 10)",
+             "kernel_ms": x["kernel_ms_mean"], "traffic_bytes_per_launch": x["traffic_bytes_corrected"],
+             "traffic_GBps": x["traffic_bytes_corrected"] / (x["kernel_ms_mean"] * 1e-3) / 1e9, "files": f}
+        e["traffic_frac"] = e["traffic_GBps"] / HBM_PEAK_GBS
+        if alg:
+            e["algorithmic_bytes_per_launch"] = alg
+            e["algorithmic_GBps"] = alg / (x["kernel_ms_mean"] * 1e-3) / 1e9
+            e["frac"] = e["algorithmic_GBps"] / HBM_PEAK_GBS
+            e["traffic_over_algorithmic"] = x["traffic_bytes_corrected"] / alg
+        out["intersection"]["posting_arrays_intersection_only"] = e
     json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_current.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
