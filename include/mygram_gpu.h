@@ -493,6 +493,12 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
  *   `primary` (mgx_batch_exchange without the all-gather); mgx_batch_fetch(primary) then returns the table-wide page
  *   and total. Funnel counters stay per index: fetch the others too and add them. Same restriction as the exchange:
  *   all MGX_SORT_SCORE or all docid-ordered pages. The others must stay untouched until primary has been fetched. */
+/* Compaction of a mutable table (the main index is rebuilt from the table's current documents): the texts the index holds
+ * (mgx_index_attach_text) and a filter column's arrays back on the host. mgx_index_copy_text with both buffers NULL only
+ * reports *total_bytes; text_off has room for n_docs + 1 entries (offsets start at 0). */
+int mgx_index_copy_text(mgx_index* idx, uint8_t* text_bytes, uint64_t capacity, uint64_t* text_off, uint64_t* total_bytes);
+int mgx_index_filter_column_export(mgx_index* idx, uint32_t column_id, uint64_t* values, uint8_t* is_null,
+                                   uint32_t* value_ids /* may be NULL */);
 /* One document's stored value of a filter column, as it was given to mgx_index_add_filter_column (a document that moves
  * to the delta index takes its filter values along). value_id may be NULL. */
 int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,

@@ -93,6 +93,8 @@ int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* o
                                size_t new_len, int with_filters, uint32_t n_filters, const char* const* names,
                                const int* types, const void* values, const char* const* strings);
 int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len);
+/* Index::Compact: the main index rebuilt from the table's current documents; the delta goes. */
+int mgxs_table_compact(mgxs_table* table);
 int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,
                               uint64_t* removed_from_main, uint64_t* epoch);
 /* One query with parsed FILTER conditions (query::FilterCondition: column, op 0 EQ 1 NE 2 GT 3 GTE 4 LT 5 LTE as

@@ -1078,6 +1078,41 @@ int mgx_index_update_filter_bitmap(mgx_index* idx, uint32_t bitmap_id, const uin
   }
 }
 
+int mgx_index_copy_text(mgx_index* idx, uint8_t* text_bytes, uint64_t capacity, uint64_t* text_off, uint64_t* total_bytes) {
+  if (!idx || !total_bytes) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_copy_text: null argument");
+  *total_bytes = 0;
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (!idx->d_text_off.p) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_copy_text: the index holds no texts (mgx_index_attach_text)");
+  MGX_HIP(hipSetDevice(idx->device));
+  const uint64_t n = idx->dev.n_docs;
+  uint64_t total = 0;
+  MGX_HIP(hipMemcpy(&total, idx->d_text_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost));
+  *total_bytes = total;
+  if (!text_off && !text_bytes) return MGX_OK;  // size query
+  if (!text_off || (total && !text_bytes)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_copy_text: null buffer");
+  if (capacity < total) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_copy_text: buffer too small (*total_bytes holds the size)");
+  MGX_HIP(hipMemcpy(text_off, idx->d_text_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+  if (total) MGX_HIP(hipMemcpy(text_bytes, idx->d_text.p, total, hipMemcpyDeviceToHost));
+  return MGX_OK;
+}
+
+int mgx_index_filter_column_export(mgx_index* idx, uint32_t column_id, uint64_t* values, uint8_t* is_null, uint32_t* value_ids) {
+  if (!idx || !values || !is_null) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_column_export: null argument");
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (column_id >= idx->filter_columns.size()) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_filter_column_export: unknown filter column");
+  const mgx_index::FilterColumn& col = *idx->filter_columns[column_id];
+  const uint64_t n = idx->dev.n_docs;
+  MGX_HIP(hipSetDevice(idx->device));
+  MGX_HIP(hipMemcpy(values, col.d_values.p, n * 8, hipMemcpyDeviceToHost));
+  if (col.d_null.p) MGX_HIP(hipMemcpy(is_null, col.d_null.p, n, hipMemcpyDeviceToHost));
+  else std::memset(is_null, 0, n);
+  if (value_ids) {
+    if (col.d_value_ids.p) MGX_HIP(hipMemcpy(value_ids, col.d_value_ids.p, n * 4, hipMemcpyDeviceToHost));
+    else std::memset(value_ids, 0xFF, n * 4);
+  }
+  return MGX_OK;
+}
+
 int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,
                                  uint32_t* value_id) {
   if (!idx || !value_bits || !is_null) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_column_read: null argument");

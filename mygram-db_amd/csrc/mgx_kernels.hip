@@ -550,6 +550,8 @@ __device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __rest
   return count;
 }
 
+__device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot);
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -952,10 +954,20 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
               tf = static_cast<double>(text_count_occurrences(ix.text, t0, t1, tpat[i], false));
               idf = bt.text_idf[st.text_term];
             } else {
-              const uint64_t wbits = bm64[leaf[st.leaf].lds * kBlock + word];
+              const DevLeaf slf = leaf[st.leaf];
+              const uint64_t wbits = bm64[slf.lds * kBlock + word];
               if ((wbits >> bit) & 1ull) {
-                const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
-                tf = static_cast<double>(posting_tf(ix, seg_lo[st.leaf] + rank));
+                if (slf.kind == kLeafGramBitmap && ix.tfnib != nullptr) {
+                  // by doc slot, not by posting rank: a mutable table clears dead documents' bits in the bitmap form
+                  // (mgx_index_clear_postings), after which the popcount below a bit is no longer the posting's rank
+                  const uint32_t nb = ix.tfnib[static_cast<uint64_t>(slf.b) * ix.nib_row_stride + (slot >> 1)];
+                  uint32_t tfv = (nb >> ((slot & 1u) * 4u)) & 15u;
+                  if (tfv == 15u) tfv = exact_tf(ix, slf.a, slf.row, slot);
+                  tf = static_cast<double>(tfv);
+                } else {
+                  const uint32_t rank = pref[(1 + i) * kBlock + word] + __popcll(wbits & below);
+                  tf = static_cast<double>(posting_tf(ix, seg_lo[st.leaf] + rank));
+                }
               }
             }
             if (tf > 0.0) {

@@ -209,13 +209,34 @@ struct Index::Impl {
   mutable bool has_gaps = false;       // ids inside [first, last] that were never added
   mutable uint32_t exists_bitmap = 0;  // filter bitmap of the ids that were (only when has_gaps)
 
-  bool owns_handles = true;  // false: adopted (Index::Adopt)
+  mutable bool owns_handles = true;  // false: adopted (Index::Adopt)
   // doc-range shards: table-wide statistics (empty / 0: this index is the whole table)
   std::vector<uint64_t> global_sizes;
   uint64_t global_docs = 0;
   double global_avgdl = 0.0;
 
+  // One generation of the main index. `cols` / `dev` above are the current generation's; a compaction publishes a new one,
+  // and whoever still holds batch objects compiled on the old device index (an executor's slots) keeps the old generation
+  // alive through its own reference until those objects are gone.
+  struct Handles {
+    mgx_columns* cols = nullptr;
+    mgx_index* dev = nullptr;
+    bool owns = true;
+    ~Handles() {
+      if (dev && owns) mgx_index_destroy(dev);
+      if (cols && owns) mgx_columns_destroy(cols);
+    }
+  };
+  mutable std::shared_ptr<Handles> handles;
+  void Publish() const {
+    auto h = std::make_shared<Handles>();
+    h->cols = cols;
+    h->dev = dev;
+    h->owns = owns_handles;
+    handles = std::move(h);
+  }
   ~Impl() {
+    if (handles) return;  // (the generation object destroys what it owns)
     if (dev && owns_handles) mgx_index_destroy(dev);
     if (cols && owns_handles) mgx_columns_destroy(cols);
   }
@@ -346,6 +367,7 @@ std::unique_ptr<Index> Index::Adopt(mgx_columns* columns, mgx_index* device_inde
   im->owns_handles = false;
   im->finalized = true;
   if (mgx_columns_view_get(columns, &im->view) != MGX_OK) im->last_error = mgx_last_error();
+  im->Publish();
   g_last_finalized.store(idx.get());
   return idx;
 }
@@ -375,6 +397,7 @@ std::unique_ptr<Index> Index::FromDump(const void* data, size_t len, const std::
                    cv.offsets,              cv.docids,       cv.tf,  cv.doc_len, 0.0,
                    cv.tf_overflow_pos,      cv.tf_overflow_val, cv.n_tf_overflow};
   if (mgx_index_create(&d, &im->dev) != MGX_OK) return fail(mgx_last_error());
+  im->Publish();
   if (v.has_texts && mgx_index_attach_text(im->dev, v.text_bytes, v.text_off) != MGX_OK) return fail(mgx_last_error());
   // DocumentStore::GetAllDocIds: the ids the store holds (deleted ids leave gaps in the range)
   if (v.n_existing != v.n_docs) {
@@ -746,6 +769,170 @@ std::string Index::ApplyMutations() const {
   return "";
 }
 
+// The main index rebuilt from the table's current documents: live documents of the old main index (their texts come back
+// from the device, where BM25 keeps them) + the delta's. Same quiescence contract as ApplyMutations. Batch objects an
+// executor compiled on the old device index stay valid until that executor lets go of them (Impl::Handles).
+std::string Index::Compact() const {
+  Finalize();
+  FlushPendingFilterColumns();
+  {
+    const std::string e = ApplyMutations();
+    if (!e.empty()) return e;
+  }
+  Impl* im = impl_.get();
+  std::unique_lock<std::mutex> lock(im->mu);
+  Impl::Mutable& m = im->mut;
+  if (!m.active) return "";  // the table never changed
+  auto fail = [&](const std::string& msg) {
+    im->last_error = "Compact: " + msg;
+    return im->last_error;
+  };
+  const uint64_t n_old = im->view.n_docs;
+  uint64_t total = 0;
+  if (mgx_index_copy_text(im->dev, nullptr, 0, nullptr, &total) != MGX_OK) return fail(mgx_last_error());
+  std::vector<uint8_t> old_bytes(total + 16);
+  std::vector<uint64_t> old_off(n_old + 1);
+  if (mgx_index_copy_text(im->dev, old_bytes.data(), total, old_off.data(), &total) != MGX_OK) return fail(mgx_last_error());
+  const DocId old_first = im->view.first_doc_id;
+  DocId first = old_first, last = old_first + static_cast<DocId>(n_old) - 1;
+  if (!m.delta_docs.empty()) {
+    first = std::min(first, m.delta_docs.begin()->first);
+    last = std::max(last, m.delta_docs.rbegin()->first);
+  }
+  const uint64_t n2 = static_cast<uint64_t>(last) - first + 1;
+  std::vector<uint8_t> bytes;
+  bytes.reserve(total + 1024);
+  std::vector<uint64_t> off(n2 + 1, 0);
+  std::vector<uint64_t> exists((n2 + 63) / 64, 0);
+  std::vector<DocId> existing;
+  {
+    auto dit = m.delta_docs.begin();
+    for (uint64_t i = 0; i < n2; ++i) {
+      const DocId doc = first + static_cast<DocId>(i);
+      while (dit != m.delta_docs.end() && dit->first < doc) ++dit;
+      bool here = false;
+      if (dit != m.delta_docs.end() && dit->first == doc) {
+        bytes.insert(bytes.end(), dit->second.begin(), dit->second.end());
+        here = true;
+      } else if (im->LiveInMain(doc)) {
+        const uint64_t slot = doc - old_first;
+        bytes.insert(bytes.end(), old_bytes.begin() + static_cast<std::ptrdiff_t>(old_off[slot]),
+                     old_bytes.begin() + static_cast<std::ptrdiff_t>(old_off[slot + 1]));
+        here = true;
+      }
+      if (here) {
+        exists[i >> 6] |= 1ull << (i & 63);
+        existing.push_back(doc);
+      }
+      off[i + 1] = bytes.size();
+    }
+  }
+  bytes.resize(bytes.size() + 16);
+  std::vector<uint8_t>().swap(old_bytes);
+  // ---- the old generation's filter columns, by doc slot ----------------------------------------------------------------
+  struct OldColumn {
+    Impl::FilterColumn meta;
+    std::vector<uint64_t> values;
+    std::vector<uint8_t> nul;
+  };
+  std::vector<OldColumn> old_cols;
+  {
+    std::lock_guard<std::mutex> fl(im->filter_mu);
+    for (const auto& c : im->filter_columns) {
+      OldColumn oc;
+      oc.meta = c;
+      oc.values.resize(n_old);
+      oc.nul.resize(n_old);
+      if (mgx_index_filter_column_export(im->dev, c.device_id, oc.values.data(), oc.nul.data(), nullptr) != MGX_OK)
+        return fail(mgx_last_error());
+      old_cols.push_back(std::move(oc));
+    }
+  }
+  // ---- the new generation ----------------------------------------------------------------------------------------------
+  mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, ngram_size_, kanji_ngram_size_, cross_boundary_ ? 1 : 0, 0};
+  mgx_columns* cols2 = nullptr;
+  if (mgx_columns_build(&bp, bytes.data(), off.data(), first, n2, &cols2) != MGX_OK) return fail(mgx_last_error());
+  mgx_columns_view view2{};
+  mgx_columns_view_get(cols2, &view2);
+  mgx_index_desc d{sizeof(mgx_index_desc), MGX_ABI_VERSION, im->device, 0, view2.first_doc_id, view2.n_docs, view2.n_grams,
+                   view2.offsets,            view2.docids,    view2.tf,   view2.doc_len, im->dense_threshold,
+                   view2.tf_overflow_pos,    view2.tf_overflow_val, view2.n_tf_overflow};
+  mgx_index* dev2 = nullptr;
+  if (mgx_index_create(&d, &dev2) != MGX_OK) {
+    mgx_columns_destroy(cols2);
+    return fail(mgx_last_error());
+  }
+  auto gen = std::make_shared<Impl::Handles>();
+  gen->cols = cols2;
+  gen->dev = dev2;
+  gen->owns = true;
+  if (mgx_index_attach_text(dev2, bytes.data(), off.data()) != MGX_OK) return fail(mgx_last_error());
+  const bool gaps = existing.size() != n2;
+  uint32_t exists_bitmap = 0;
+  if (gaps && mgx_index_add_filter_bitmap(dev2, existing.data(), existing.size(), &exists_bitmap) != MGX_OK)
+    return fail(mgx_last_error());
+  // what the re-added filter columns need of the old state
+  const std::vector<uint64_t> old_live = m.main_live;
+  const std::map<DocId, storage::FilterMap> delta_filters = m.delta_filters;
+  std::vector<DocId> delta_ids;
+  for (const auto& kv : m.delta_docs) delta_ids.push_back(kv.first);
+  // ---- swap ----------------------------------------------------------------------------------------------------------------
+  const std::shared_ptr<Impl::Handles> old_gen = im->handles;  // (let go at the end of this call, or by the last executor slot)
+  im->handles = gen;
+  im->cols = cols2;
+  im->dev = dev2;
+  im->view = view2;
+  im->owns_handles = true;
+  im->has_gaps = gaps;
+  im->exists_bitmap = exists_bitmap;
+  im->exists_bits = gaps ? exists : std::vector<uint64_t>();
+  im->global_sizes.clear();
+  im->absent_grams.clear();
+  im->global_docs = 0;
+  im->global_avgdl = 0.0;
+  const uint64_t epoch = m.epoch + 1;
+  m = Impl::Mutable{};
+  m.epoch = epoch;
+  {
+    std::lock_guard<std::mutex> fl(im->filter_mu);
+    im->filter_columns.clear();
+    im->condition_cache.clear();
+    im->have_empty_bitmap = false;
+  }
+  lock.unlock();
+  // ---- filter columns of the new generation: a live document of the old main index keeps its value, a document of the delta
+  // has the values recorded with it ----------------------------------------------------------------------------------------------
+  std::vector<std::string> names;
+  for (const auto& oc : old_cols) names.push_back(oc.meta.name);
+  for (const auto& kv : delta_filters)
+    for (const auto& f : kv.second)
+      if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);
+  for (const auto& name : names) {
+    std::vector<storage::FilterValue> values(n2);
+    const OldColumn* oc = nullptr;
+    for (const auto& c : old_cols)
+      if (c.meta.name == name) oc = &c;
+    if (oc != nullptr && oc->meta.type != 0) {
+      for (uint64_t slot = 0; slot < n_old; ++slot) {
+        if (!((old_live[slot >> 6] >> (slot & 63)) & 1) || oc->nul[slot]) continue;
+        values[static_cast<uint64_t>(old_first - first) + slot] = FilterValueFromBits(oc->meta.type, oc->values[slot], oc->meta.dict);
+      }
+    }
+    for (DocId doc : delta_ids) {
+      storage::FilterValue v;
+      const auto fm = delta_filters.find(doc);
+      if (fm != delta_filters.end()) {
+        const auto fv = fm->second.find(name);
+        if (fv != fm->second.end()) v = fv->second;
+      }
+      values[doc - first] = std::move(v);
+    }
+    const std::string ferr = AddFilterColumn(name, values);
+    if (!ferr.empty()) return "Compact: " + ferr;
+  }
+  return "";
+}
+
 namespace {
 // widened device value of a non-NULL FilterValue (strings: their dictionary rank, filled in by the caller)
 uint64_t WidenFilterValue(const storage::FilterValue& v) {
@@ -870,6 +1057,7 @@ std::string Index::Finalize() const {
     impl_->dev = nullptr;
     return impl_->last_error;
   }
+  impl_->Publish();
   // the shim's Index is also the DocumentStore of the texts it was given: BM25 terms longer than one n-gram are
   // counted in the text on the device
   if (mgx_index_attach_text(impl_->dev, bytes.data(), off.data()) != MGX_OK) impl_->last_error = mgx_last_error();
@@ -2196,6 +2384,7 @@ struct BatchExecutor::Impl {
     std::vector<mgx_query> mq;
     // a mutable table: the delta index this batch was submitted against, the same queries planned for it, and the batch
     // object compiled on it (bound to dbatch_index: a rebuilt delta gets a new object)
+    std::shared_ptr<index::Index::Impl::Handles> handles;  // the generation of the main index `batch` was compiled on
     std::shared_ptr<index::Index> delta, dbatch_index;
     std::vector<PlannedQuery> dplans;
     std::vector<mgx_query> dq;
@@ -2270,6 +2459,18 @@ struct BatchExecutor::Impl {
       if (++n % 64 == 0) fprintf(stderr, "[shim] gather of the planned queries: %.3f ms per batch\n", us.exchange(0) / 64e3);
     }
     int rc;
+    {
+      std::shared_ptr<index::Index::Impl::Handles> cur;
+      {
+        std::lock_guard<std::mutex> il(im->mu);
+        cur = im->handles;
+      }
+      if (slot->batch && slot->handles != cur) {  // the main index was compacted: the object belongs to the old generation
+        mgx_batch_destroy(slot->batch);
+        slot->batch = nullptr;
+      }
+      slot->handles = std::move(cur);
+    }
     if (!slot->batch)
       rc = mgx_batch_prepare(im->dev, slot->mq.data(), static_cast<uint32_t>(slot->mq.size()), &slot->batch);
     else

@@ -185,6 +185,11 @@ class Index {
   [[nodiscard]] MutationStats GetMutationStats() const;
   // Brings the device state up to date with the recorded changes (every query entry point calls it). "" or an error.
   std::string ApplyMutations() const;
+  // Folds the delta back: the main index is rebuilt from the table's current documents (the texts of its live documents come
+  // back from the device, where BM25 keeps them; filter values likewise) and the delta and the live row go. What the
+  // reference's Optimize / a dump-and-reload do for a grown index. Same exclusion rule as the mutation-applying entry
+  // points; an executor's batch objects move to the new device index by themselves. "" or an error.
+  std::string Compact() const;
 
   [[nodiscard]] std::vector<DocId> SearchAnd(const std::vector<std::string>& terms, size_t limit = 0,
                                              bool reverse = false) const;

@@ -368,6 +368,16 @@ int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* t
   }
 }
 
+int mgxs_table_compact(mgxs_table* table) {
+  if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_compact: null argument");
+  try {
+    const std::string err = table->index->Compact();
+    return err.empty() ? MGX_OK : Fail(MGX_ERR_INTERNAL, err);
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,
                               uint64_t* removed_from_main, uint64_t* epoch) {
   if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_mutation_stats: null argument");

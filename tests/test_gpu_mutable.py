@@ -30,6 +30,11 @@ class Mirror:
         return Pair(docs=sorted(self.docs.items()), ngram=2, kanji=0)
 
 
+def t_delta_docs(m, t):
+    """Some documents to remove at the end of the test: the newest ids (they sit in the delta, or did before a compaction)."""
+    return sorted(m.docs)[-120:]
+
+
 def _queries(rng, grams, n):
     qs = []
     for i in range(n):
@@ -128,8 +133,17 @@ def test_changes_after_the_build_equal_an_index_built_from_the_current_documents
     change(100, 100, 50, novel=2)
     want = m.rebuilt()
     _check(t, want, qs, ex)
+    # compaction: the main index is rebuilt from the current documents (texts back from the device), the delta and the live
+    # row go; the executor's batch objects move to the new device index; then the table changes again
+    t.compact()
+    st = t.mutation_stats()
+    assert st["delta_documents"] == 0 and st["main_documents"] == len([d for d in m.docs.values() if d]), st
+    _check(t, want, qs, ex)
+    change(60, 80, 40, novel=2)
+    want = m.rebuilt()
+    _check(t, want, qs, ex)
     # removals only: the delta goes away when its last document does
-    for d in [d for d in list(m.docs) if d > n]:
+    for d in t_delta_docs(m, t):
         t.remove_document(d, m.docs[d])
         del m.docs[d]
     want = m.rebuilt()
@@ -144,6 +158,7 @@ def test_filter_values_follow_a_changed_document_and_facets_count_both_indexes()
     n = 20_000
     corpus = mg.Corpus.synthetic(n, seed=51)
     p = Pair(corpus=corpus)
+    p.dev.ensure_text()  # (compaction reads the main index's texts back from the device)
     t = S.Table(p.dev)
     rng = np.random.default_rng(52)
     status = rng.integers(0, 6, n)
@@ -196,3 +211,23 @@ def test_filter_values_follow_a_changed_document_and_facets_count_both_indexes()
                 v = vals[d]["category"]
                 counts[v[1].encode()] = counts.get(v[1].encode(), 0) + 1
             assert matched == len(exp) and dict(page) == counts, (terms, conds)
+        if i == len(conds_list):  # the rest of the loop runs on the compacted table: filter values moved with the documents
+            t.compact()
+            assert t.mutation_stats()["delta_documents"] == 0
+
+
+def test_the_general_kernels_score_a_changed_table_too():
+    """The same scenario with every query forced onto the general workgroup kernel and without the fast scoring path: after
+    dead documents' bits left the bitmap form of their grams, tf must come by doc slot, not by popcount rank."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MGX_FORCE_BLOCK_KERNEL="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for extra in ({}, {"MGX_FORCE_BLOCK_KERNEL": "0", "MGX_FAST_PATH": "0"}):
+        e = dict(env, **extra)
+        if e["MGX_FORCE_BLOCK_KERNEL"] == "0":
+            del e["MGX_FORCE_BLOCK_KERNEL"]
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_mutable.py"),
+                            "-k", "changes_after_the_build"], env=e, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
