@@ -499,6 +499,8 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
 int mgx_index_copy_text(mgx_index* idx, uint8_t* text_bytes, uint64_t capacity, uint64_t* text_off, uint64_t* total_bytes);
 int mgx_index_filter_column_export(mgx_index* idx, uint32_t column_id, uint64_t* values, uint8_t* is_null,
                                    uint32_t* value_ids /* may be NULL */);
+/* One document's text (text NULL: only *len). */
+int mgx_index_read_text(mgx_index* idx, uint32_t doc_id, uint8_t* text, uint64_t capacity, uint64_t* len);
 /* One document's stored value of a filter column, as it was given to mgx_index_add_filter_column (a document that moves
  * to the delta index takes its filter values along). value_id may be NULL. */
 int mgx_index_filter_column_read(mgx_index* idx, uint32_t column_id, uint32_t doc_id, uint64_t* value_bits, int* is_null,

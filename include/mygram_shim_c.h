@@ -93,6 +93,9 @@ int mgxs_table_update_document(mgxs_table* table, uint32_t doc_id, const char* o
                                size_t new_len, int with_filters, uint32_t n_filters, const char* const* names,
                                const int* types, const void* values, const char* const* strings);
 int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* text, size_t len);
+/* Index::UpdateFilters (DocumentStore::UpdateDocument(doc_id, filters)): the document's filter values change, its text stays. */
+int mgxs_table_update_filters(mgxs_table* table, uint32_t doc_id, uint32_t n_filters, const char* const* names,
+                              const int* types, const void* values, const char* const* strings);
 /* Index::Compact: the main index rebuilt from the table's current documents; the delta goes. */
 int mgxs_table_compact(mgxs_table* table);
 int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,

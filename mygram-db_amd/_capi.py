@@ -24,7 +24,7 @@ EXPORTS = [
     "mgx_dump_take_columns", "mgx_dump_destroy", "mgx_columns_view_get", "mgx_columns_lookup", "mgx_columns_destroy",
     "mgx_index_create", "mgx_index_destroy", "mgx_posting_size", "mgx_index_memory_bytes",
     "mgx_index_add_filter_bitmap", "mgx_index_add_filter_column", "mgx_index_filter_compare", "mgx_facet_counts",
-    "mgx_index_filter_column_read", "mgx_index_copy_text", "mgx_index_filter_column_export", "mgx_index_set_live_bitmap", "mgx_index_clear_postings", "mgx_index_update_filter_bitmap", "mgx_index_set_doc_map",
+    "mgx_index_filter_column_read", "mgx_index_copy_text", "mgx_index_read_text", "mgx_index_filter_column_export", "mgx_index_set_live_bitmap", "mgx_index_clear_postings", "mgx_index_update_filter_bitmap", "mgx_index_set_doc_map",
     "mgx_index_invalidate_statistics", "mgx_index_synchronize", "mgx_batch_df_merge_local", "mgx_batch_merge_local",
     "mgx_index_set_batch_order", "mgx_index_attach_text", "mgx_batch_count_df", "mgx_batch_df_buffer", "mgx_score_documents_text",
     "mgx_batch_prepare", "mgx_batch_reset", "mgx_batch_stream", "mgx_batch_execute", "mgx_batch_fetch", "mgx_batch_export_topk",

@@ -12,7 +12,7 @@ EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
            "mgxs_submit", "mgxs_wait", "mgxs_table_from_dump", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
-           "mgxs_table_add_document", "mgxs_table_update_document", "mgxs_table_remove_document", "mgxs_table_mutation_stats", "mgxs_table_compact",
+           "mgxs_table_add_document", "mgxs_table_update_document", "mgxs_table_remove_document", "mgxs_table_mutation_stats", "mgxs_table_compact", "mgxs_table_update_filters",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -56,6 +56,7 @@ def load():
     L.mgxs_table_update_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, i32, u32, vp, vp, vp, vp]
     L.mgxs_table_remove_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t]
     L.mgxs_table_compact.argtypes = [vp]
+    L.mgxs_table_update_filters.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.mgxs_table_mutation_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
     L.mgxs_batcher_destroy.argtypes = [vp]
@@ -210,6 +211,12 @@ class Table:
         _check(load().mgxs_table_update_document(self._h, doc_id, o, len(o), w, len(w), int(filters is not None), n,
                                                  C.cast(names, C.c_void_p), types.ctypes.data, vals.ctypes.data,
                                                  C.cast(sarr, C.c_void_p)))
+
+    def update_filters(self, doc_id, filters):
+        """Index::UpdateFilters: new filter values for a document whose text stays."""
+        n, names, types, vals, sarr = self._filters(filters)
+        _check(load().mgxs_table_update_filters(self._h, doc_id, n, C.cast(names, C.c_void_p), types.ctypes.data,
+                                                vals.ctypes.data, C.cast(sarr, C.c_void_p)))
 
     def remove_document(self, doc_id, text):
         """Index::RemoveDocument (text = the document's current normalized text)."""

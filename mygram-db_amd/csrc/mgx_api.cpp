@@ -1096,6 +1096,24 @@ int mgx_index_copy_text(mgx_index* idx, uint8_t* text_bytes, uint64_t capacity, 
   return MGX_OK;
 }
 
+int mgx_index_read_text(mgx_index* idx, uint32_t doc_id, uint8_t* text, uint64_t capacity, uint64_t* len) {
+  if (!idx || !len) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_read_text: null argument");
+  *len = 0;
+  std::lock_guard<std::mutex> lock(idx->mu);
+  if (!idx->d_text_off.p) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_read_text: the index holds no texts (mgx_index_attach_text)");
+  if (doc_id < idx->dev.first_doc_id || doc_id - idx->dev.first_doc_id >= idx->dev.n_docs)
+    return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_read_text: doc id outside the index range");
+  MGX_HIP(hipSetDevice(idx->device));
+  const uint32_t slot = doc_id - idx->dev.first_doc_id;
+  uint64_t off[2] = {0, 0};
+  MGX_HIP(hipMemcpy(off, idx->d_text_off.as<uint64_t>() + slot, 16, hipMemcpyDeviceToHost));
+  *len = off[1] - off[0];
+  if (*len == 0 || !text) return MGX_OK;
+  if (capacity < *len) return mgx::Fail(MGX_ERR_OUT_OF_RANGE, "mgx_index_read_text: buffer too small (*len holds the size)");
+  MGX_HIP(hipMemcpy(text, idx->d_text.as<uint8_t>() + off[0], *len, hipMemcpyDeviceToHost));
+  return MGX_OK;
+}
+
 int mgx_index_filter_column_export(mgx_index* idx, uint32_t column_id, uint64_t* values, uint8_t* is_null, uint32_t* value_ids) {
   if (!idx || !values || !is_null) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_index_filter_column_export: null argument");
   std::lock_guard<std::mutex> lock(idx->mu);

@@ -630,6 +630,41 @@ void Index::UpdateDocument(DocId doc_id, std::string_view old_text, std::string_
   im->mut.delta_changed = im->mut.dirty = true;
 }
 
+bool Index::UpdateFilters(DocId doc_id, const storage::FilterMap& filters) {
+  Finalize();
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  Impl* im = impl_.get();
+  const std::string err = EnsureMutable(im);
+  if (!err.empty()) {
+    im->last_error = "UpdateFilters: " + err;
+    return false;
+  }
+  if (im->mut.delta_docs.count(doc_id)) {
+    im->mut.delta_filters[doc_id] = filters;
+    im->mut.delta_changed = im->mut.dirty = true;
+    return true;
+  }
+  if (!im->LiveInMain(doc_id)) {
+    im->last_error = "UpdateFilters: not a live document";
+    return false;
+  }
+  uint64_t len = 0;
+  if (mgx_index_read_text(im->dev, doc_id, nullptr, 0, &len) != MGX_OK) {
+    im->last_error = std::string("UpdateFilters: ") + mgx_last_error();
+    return false;
+  }
+  std::string text(len, '\0');
+  if (len && mgx_index_read_text(im->dev, doc_id, reinterpret_cast<uint8_t*>(text.data()), len, &len) != MGX_OK) {
+    im->last_error = std::string("UpdateFilters: ") + mgx_last_error();
+    return false;
+  }
+  RemoveLocked(*this, im, doc_id, text);
+  im->mut.delta_docs[doc_id] = std::move(text);
+  im->mut.delta_filters[doc_id] = filters;
+  im->mut.delta_changed = im->mut.dirty = true;
+  return true;
+}
+
 Index::MutationStats Index::GetMutationStats() const {
   std::lock_guard<std::mutex> lock(impl_->mu);
   MutationStats st;

@@ -176,6 +176,10 @@ class Index {
   void UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text,
                       const storage::FilterMap& filters);
   void RemoveDocument(DocId doc_id, std::string_view text);
+  // DocumentStore::UpdateDocument(doc_id, filters) (src/storage/document_store.h; binlog_event_processor.cpp:217): the
+  // document's filter values become `filters`, its text stays. The typed device columns are immutable, so a document of
+  // the main index moves to the delta with its text (read back from the device). False if the id is no live document.
+  bool UpdateFilters(DocId doc_id, const storage::FilterMap& filters);
   struct MutationStats {
     uint64_t main_documents = 0;   // live documents of the main index
     uint64_t delta_documents = 0;  // documents of the delta index

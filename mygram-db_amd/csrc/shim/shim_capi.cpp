@@ -368,6 +368,18 @@ int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* t
   }
 }
 
+int mgxs_table_update_filters(mgxs_table* table, uint32_t doc_id, uint32_t n_filters, const char* const* names,
+                              const int* types, const void* values, const char* const* strings) {
+  if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_update_filters: null argument");
+  try {
+    if (!table->index->UpdateFilters(doc_id, MakeFilterMap(n_filters, names, types, values, strings)))
+      return Fail(MGX_ERR_INVALID_ARGUMENT, table->index->LastError());
+    return MGX_OK;
+  } catch (const std::exception& e) {
+    return Fail(MGX_ERR_INTERNAL, e.what());
+  }
+}
+
 int mgxs_table_compact(mgxs_table* table) {
   if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_compact: null argument");
   try {

@@ -194,10 +194,21 @@ def test_filter_values_follow_a_changed_document_and_facets_count_both_indexes()
         t.add_document(d, new, filters=f)
         m.docs[d] = new
         vals[d] = f
+    # filter values alone change (DocumentStore::UpdateDocument(doc_id, filters)): a document of the main index, and one of
+    # the delta
+    still_main = [x for x in live if x in m.docs and x not in upd][:40]
+    for d in still_main + [n + 1, n + 2]:
+        f = {"status": ("int32", 9), "category": ("string", "moved")}
+        t.update_filters(d, f)
+        vals[d] = f
+    with pytest.raises(S.ShimError):
+        t.update_filters(10 * n, {"status": ("int32", 1)})
+    conds_extra = [[("status", "=", "9")], [("category", "=", "moved")]]
     want = m.rebuilt()
     columns = {name: (lambda doc, name=name: vals.get(doc, {}).get(name)) for name in ("status", "category")}
     conds_list = [[("status", "=", "7")], [("status", "!=", "2")], [("category", "=", "fresh")], [("status", ">=", "3")],
                   [("category", "=", "cat6")], [("status", "<", "2"), ("category", "!=", "cat1")]]
+    conds_list = conds_list + conds_extra
     for i, conds in enumerate(conds_list * 3):
         terms = [grams[int(rng.integers(0, len(grams)))]]
         base = want.oracle_query(Query(terms, limit=0, descending=False))[1].tolist()
