@@ -491,8 +491,9 @@ int mgx_facet_counts(mgx_index* idx, const mgx_query* query, uint32_t column_id,
  *   to every batch (mgx_batch_exchange_df without the all-reduce).
  * mgx_batch_merge_local, after the executes, all on `hip_stream`: merges the others' top-(offset+limit) per query into
  *   `primary` (mgx_batch_exchange without the all-gather); mgx_batch_fetch(primary) then returns the table-wide page
- *   and total. Funnel counters stay per index: fetch the others too and add them. Same restriction as the exchange:
- *   all MGX_SORT_SCORE or all docid-ordered pages. The others must stay untouched until primary has been fetched. */
+ *   and total. Funnel counters stay per index: fetch the others too and add them. Every query needs a page
+ *   bound (MGX_SORT_SCORE, or a docid-ordered page); unlike the exchange, a batch may mix the two (each group is merged
+ *   on its own). The others must stay untouched until primary has been fetched. */
 /* Compaction of a mutable table (the main index is rebuilt from the table's current documents): the texts the index holds
  * (mgx_index_attach_text) and a filter column's arrays back on the host. mgx_index_copy_text with both buffers NULL only
  * reports *total_bytes; text_off has room for n_docs + 1 entries (offsets start at 0). */

@@ -3219,6 +3219,13 @@ int mgx_batch_df_buffer(mgx_batch* batch, uint64_t** device_counts, uint32_t* n)
   return MGX_OK;
 }
 
+// One group of a batch (its SORT _score queries, or its docid-ordered pages) in the exchange layout. The public entry
+// points below take uniform batches (one all-gather moves one blob); the local merge of a mutable table takes each group
+// of a mixed batch in turn.
+static int ExportGroup(mgx_batch* batch, bool pages, uint64_t* blob64, uint32_t* blob32, uint32_t* stride, void* hip_stream);
+static int MergeGroup(mgx_batch* batch, bool pages, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
+                      const uint32_t* blob32, uint64_t pitch32, void* hip_stream);
+
 int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, uint32_t* stride,
                           void* hip_stream) {
   if (!batch || !stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null argument");
@@ -3227,6 +3234,10 @@ int mgx_batch_export_topk(mgx_batch* batch, uint64_t* blob64, uint32_t* blob32, 
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
                      "mgx_batch_export_topk: the batch must be all MGX_SORT_SCORE or all docid-ordered pages "
                      "(0 < limit <= 16384)");
+  return ExportGroup(batch, pages, blob64, blob32, stride, hip_stream);
+}
+
+static int ExportGroup(mgx_batch* batch, bool pages, uint64_t* blob64, uint32_t* blob32, uint32_t* stride, void* hip_stream) {
   *stride = pages ? batch->doc_page_stride : batch->top_stride;
   if (!blob64 && !blob32) return MGX_OK;  // size query
   if (!blob64 || !blob32) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_export_topk: null blob");
@@ -3272,6 +3283,11 @@ int mgx_batch_merge_shards(mgx_batch* batch, uint32_t n_shards, const uint64_t* 
   if (!pages && (!batch->bitmap.qids.empty() || !batch->page.qids.empty() || batch->score.qids.empty()))
     return mgx::Fail(MGX_ERR_INVALID_ARGUMENT,
                      "mgx_batch_merge_shards: the batch must be all MGX_SORT_SCORE or all docid-ordered pages");
+  return MergeGroup(batch, pages, n_shards, blob64, pitch64, blob32, pitch32, hip_stream);
+}
+
+static int MergeGroup(mgx_batch* batch, bool pages, uint32_t n_shards, const uint64_t* blob64, uint64_t pitch64,
+                      const uint32_t* blob32, uint64_t pitch32, void* hip_stream) {
   hipStream_t s = nullptr;
   {
     int rc_s = mgx::BatchStream(batch, hip_stream, &s);
@@ -3346,43 +3362,63 @@ int mgx_batch_merge_local(mgx_batch* primary, mgx_batch* const* others, uint32_t
   if (!primary || (n_others && !others)) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: null argument");
   if (primary->n_queries == 0) return MGX_OK;
   if (!primary->res) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: not a prepared batch object");
+  if (!primary->bitmap.qids.empty())
+    return mgx::Fail(MGX_ERR_NOT_IMPLEMENTED,
+                     "mgx_batch_merge_local: a query without a page bound (limit 0 or > 16384, not SORT _score) cannot be merged");
   try {
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    uint32_t stride = 0;
-    int rc = mgx_batch_export_topk(primary, nullptr, nullptr, &stride, hip_stream);
-    if (rc) return rc;
-    const bool pages = primary->score.qids.empty();
-    for (uint32_t j = 0; j < n_others; ++j) {
-      uint32_t st = 0;
-      if (!others[j] || others[j]->n_queries != primary->n_queries || others[j]->idx->device != primary->idx->device)
+    for (uint32_t j = 0; j < n_others; ++j)
+      if (!others[j] || others[j]->n_queries != primary->n_queries || others[j]->idx->device != primary->idx->device ||
+          others[j]->score.qids.size() != primary->score.qids.size() || others[j]->page.qids.size() != primary->page.qids.size())
         return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: the batches do not hold the same queries");
-      rc = mgx_batch_export_topk(others[j], nullptr, nullptr, &st, hip_stream);
-      if (rc) return rc;
-      if (st != stride || others[j]->score.qids.empty() != pages)
-        return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: the batches do not hold the same queries");
-    }
     MGX_HIP(hipSetDevice(primary->idx->device));
-    const uint64_t elems = static_cast<uint64_t>(primary->n_queries) * stride + primary->n_queries;
-    const uint64_t off32 = elems * 8, bytes = (elems * 12 + 7) / 8 * 8;
-    void* recv = nullptr;
-    MGX_HIP(primary->res->Exchange(1, bytes * (1ull + n_others), &recv));
-    char* g = static_cast<char*>(recv);
-    for (uint32_t j = 0; j <= n_others; ++j) {
-      mgx_batch* b = j == 0 ? primary : others[j - 1];
-      uint64_t* b64 = reinterpret_cast<uint64_t*>(g + bytes * j);
-      uint32_t* b32 = reinterpret_cast<uint32_t*>(g + bytes * j + off32);
-      uint32_t st = 0;
-      rc = mgx_batch_export_topk(b, b64, b32, &st, hip_stream);
-      if (rc) return rc;
-      const mgx_index* ix = b->idx;
-      if (ix->d_doc_map.p) {
-        const mgx_batch::Group& grp = pages ? b->page : b->score;
-        MGX_LAUNCH(mgx::LaunchRemapBlobDocs(grp.dev.queries, b->n_queries, stride, ix->d_doc_map.as<uint32_t>(),
-                                            ix->dev.first_doc_id, ix->dev.n_docs, pages ? b64 : nullptr, b32, s));
-      }
+    // a mixed batch has two groups (SORT _score queries, docid-ordered pages): each is exported, remapped and merged on its own
+    uint64_t need = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool pages = pass == 1;
+      const uint64_t n = pages ? primary->page.qids.size() : primary->score.qids.size();
+      if (n == 0) continue;
+      const uint64_t stride = pages ? primary->doc_page_stride : primary->top_stride;
+      need += ((n * stride + n) * 12 + 7) / 8 * 8 * (1ull + n_others);
     }
-    return mgx_batch_merge_shards(primary, n_others + 1, reinterpret_cast<const uint64_t*>(g), bytes / 8,
-                                  reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, hip_stream);
+    void* recv = nullptr;
+    MGX_HIP(primary->res->Exchange(1, need, &recv));
+    char* g = static_cast<char*>(recv);
+    for (int pass = 0; pass < 2; ++pass) {
+      const bool pages = pass == 1;
+      const uint32_t n = static_cast<uint32_t>(pages ? primary->page.qids.size() : primary->score.qids.size());
+      if (n == 0) continue;
+      uint32_t stride = 0;
+      int rc = ExportGroup(primary, pages, nullptr, nullptr, &stride, hip_stream);
+      if (rc) return rc;
+      for (uint32_t j = 0; j < n_others; ++j) {
+        uint32_t st = 0;
+        rc = ExportGroup(others[j], pages, nullptr, nullptr, &st, hip_stream);
+        if (rc) return rc;
+        if (st != stride) return mgx::Fail(MGX_ERR_INVALID_ARGUMENT, "mgx_batch_merge_local: the batches do not hold the same queries");
+      }
+      const uint64_t elems = static_cast<uint64_t>(n) * stride + n;
+      const uint64_t off32 = elems * 8, bytes = (elems * 12 + 7) / 8 * 8;
+      for (uint32_t j = 0; j <= n_others; ++j) {
+        mgx_batch* b = j == 0 ? primary : others[j - 1];
+        uint64_t* b64 = reinterpret_cast<uint64_t*>(g + bytes * j);
+        uint32_t* b32 = reinterpret_cast<uint32_t*>(g + bytes * j + off32);
+        uint32_t st = 0;
+        rc = ExportGroup(b, pages, b64, b32, &st, hip_stream);
+        if (rc) return rc;
+        const mgx_index* ix = b->idx;
+        if (ix->d_doc_map.p) {
+          const mgx_batch::Group& grp = pages ? b->page : b->score;
+          MGX_LAUNCH(mgx::LaunchRemapBlobDocs(grp.dev.queries, n, stride, ix->d_doc_map.as<uint32_t>(), ix->dev.first_doc_id,
+                                              ix->dev.n_docs, pages ? b64 : nullptr, b32, s));
+        }
+      }
+      rc = MergeGroup(primary, pages, n_others + 1, reinterpret_cast<const uint64_t*>(g), bytes / 8,
+                      reinterpret_cast<const uint32_t*>(g + off32), bytes / 4, hip_stream);
+      if (rc) return rc;
+      g += bytes * (1ull + n_others);
+    }
+    return MGX_OK;
   } catch (const std::exception& e) {
     return mgx::Fail(MGX_ERR_INTERNAL, std::string("mgx_batch_merge_local: ") + e.what());
   }

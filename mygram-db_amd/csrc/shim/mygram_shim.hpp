@@ -170,8 +170,9 @@ class Index {
   // thread's query on the same Index while it applies them (one BatchExecutor / MicroBatcher per mutable table, or
   // external exclusion — the reference holds its index write lock for the same span).
   // Limits: BatchQuery::filters (raw bitmap ids) are per device index and are refused while a delta exists — use
-  // filter_conditions; a batch must be all SORT _score or all docid pages with 0 < limit <= 16384 (the exchange's rule);
-  // sharded tables (BatchExecutor::Options::comm) are static.
+  // filter_conditions; every query of a batch needs a page bound (SORT _score, or a docid page with 0 < limit <= 16384:
+  // what the device merge takes; score and page queries may share a batch); sharded tables (BatchExecutor::Options::comm)
+  // are static.
   void UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text);
   void UpdateDocument(DocId doc_id, std::string_view old_text, std::string_view new_text,
                       const storage::FilterMap& filters);

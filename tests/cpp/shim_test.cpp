@@ -194,6 +194,19 @@ int main() {
     auto r = mygramdb::search_pipeline::ExecuteBatch(index, {q});
     EXPECT(r.has_value() && (*r)[0].total == kBase && (*r)[0].results == (V{kBase + 1, kBase - 1, kBase - 2}));
     if (r.has_value()) EXPECT((*r)[0].total_candidates == kBase && (*r)[0].after_filters == kBase);
+    // a mixed batch (a docid page and a SORT _score query) on a table with a delta: each group is merged on its own
+    mygramdb::search_pipeline::BatchQuery qs2 = q;
+    qs2.sort_by_score = true;
+    qs2.limit = 2;
+    auto r2 = mygramdb::search_pipeline::ExecuteBatch(index, {q, qs2, q});
+    EXPECT(r2.has_value());
+    if (r2.has_value()) {
+      EXPECT((*r2)[0].results == (V{kBase + 1, kBase - 1, kBase - 2}) && (*r2)[2].results == (*r2)[0].results);
+      EXPECT((*r2)[1].total == kBase && (*r2)[1].results.size() == 2 && (*r2)[1].scores.size() == 2 &&
+             (*r2)[1].scores[0] == (*r2)[1].scores[1] && (*r2)[1].scores[0] > 0.0);
+    } else {
+      std::printf("mixed batch on a mutable table: %s\n", r2.error().message().c_str());
+    }
   }
   {  // tests/index/bm25_scorer_test.cpp:21-48
     EXPECT(std::fabs(BM25Scorer::ComputeIDF(100, 10) - std::log(90.5 / 10.5 + 1.0)) < 1e-10);
