@@ -162,6 +162,42 @@ int main() {
     EXPECT(rep.Count("e") == 1 && rep.Count("a") == 0 && rep.Count("b") == 0 && rep.Count("c") == 0 && rep.Count("d") == 0);
     EXPECT(rep.SearchAnd({"e"}) == (V{1}));
   }
+  {  // a table with gaps in its id range that changes: the NOT universe is the ids that exist NOW
+     // (DocumentStore::GetAllDocIds), whichever index holds them
+    using namespace mygramdb::search_pipeline;
+    using mygramdb::query::NodeType;
+    using mygramdb::query::QueryNode;
+    Index index(2, 0, 0.0, false);
+    index.AddDocument(1, "machine learning");
+    index.AddDocument(2, "deep learning");
+    index.AddDocument(5, "old cats");  // ids 3, 4 do not exist
+    auto not_of = [](const char* t) {
+      auto n = std::make_unique<QueryNode>(NodeType::NOT);
+      n->children.push_back(std::make_unique<QueryNode>(std::string(t)));
+      return n;
+    };
+    BatchQuery q;
+    q.ast = not_of("machine");
+    q.order = SortOrder::ASC;
+    auto r0 = ExecuteBatch(index, {q});
+    EXPECT(r0.has_value() && (*r0)[0].results == (V{2, 5}));
+    index.RemoveDocument(2, "deep learning");
+    EXPECT(index.AddDocument(4, "new cats"));          // an id inside the old range that never existed
+    EXPECT(index.AddDocument(9, "machine cats"));      // and one beyond it
+    EXPECT(!index.AddDocument(5, "again"));            // a live id is refused
+    auto r1 = ExecuteBatch(index, {q});
+    EXPECT(r1.has_value() && (*r1)[0].results == (V{4, 5}) && (*r1)[0].total == 2);
+    BatchQuery c;
+    c.terms = {"cats"};
+    c.order = SortOrder::ASC;
+    auto r2 = ExecuteBatch(index, {c});
+    EXPECT(r2.has_value() && (*r2)[0].results == (V{4, 5, 9}));
+    EXPECT(index.Compact().empty());
+    auto r3 = ExecuteBatch(index, {q, c});
+    EXPECT(r3.has_value() && (*r3)[0].results == (V{4, 5}) && (*r3)[1].results == (V{4, 5, 9}));
+    EXPECT(index.SearchOr({"ca", "ma"}) == (V{1, 4, 5, 9}));
+    EXPECT(index.GetMutationStats().delta_documents == 0);
+  }
   {  // tests/index/index_basic_test.cpp:149-184 UpdateDocumentMaintainsTopNOrdering
     Index index(1);
     const DocId kBase = 512;
