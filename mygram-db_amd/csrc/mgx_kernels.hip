@@ -129,7 +129,7 @@ __host__ __device__ inline LdsOffsets carve(const LdsPlan& p, bool score_mode) {
   o.leaf = at;      at += align8(p.max_leaves * static_cast<uint32_t>(sizeof(DevLeaf)));
   o.prog = at;      at += align8(p.max_instr * 4);
   o.scan_tot = at;  at += 4 * 16 * 4;  // 4 waves x up to 16 packed scan lanes
-  o.misc = at;      at += 64;
+  o.misc = at;      at += 128;  // page-pass masks (32 B), operand-presence mask (32 B), jump targets (8 B)
   o.pref = at;
   o.match = at;
   o.tk_keys = at;
@@ -552,6 +552,39 @@ __device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __rest
 
 __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot);
 
+// Can the query's program reach its first COUNT with a non-empty accumulator in a tile where only the operands marked in
+// `ne` (bit l = leaf l has a posting / a set range in this tile; bitmap-form operands always count as present) hold
+// anything? Evaluated on one boolean per operand: AND needs both sides, OR either, AND-NOT leaves the left side, a
+// threshold term needs that many present operands. Everything after the first COUNT only narrows the accumulator, so a
+// tile that fails here contributes zero to every counter, to the result and to the page: it is skipped before any
+// posting is scattered. (A sparse-gram index — CJK trigrams: a handful of postings per gram — fails in almost every
+// tile; the general kernel used to stage and evaluate all of them: 8.4 ms of a 9.4 ms batch of BASELINE configs[2].)
+__device__ __forceinline__ bool tile_may_match(const uint32_t* prog, uint32_t n_instr, const uint64_t* ne) {
+  bool acc = false;
+  uint64_t stk = 0;
+  uint32_t sp = 0, cnt = 0;
+  auto NE = [&](uint32_t l) -> bool { return (ne[l >> 6] >> (l & 63u)) & 1ull; };
+  for (uint32_t pc = 0; pc < n_instr; ++pc) {
+    const uint32_t ins = prog[pc];
+    const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+    switch (op) {
+      case kOpLoad: acc = NE(arg); break;
+      case kOpAnd: acc = acc && NE(arg); break;
+      case kOpOr: acc = acc || NE(arg); break;
+      case kOpPush: stk = (stk & ~(1ull << sp)) | (static_cast<uint64_t>(acc) << sp); ++sp; break;
+      case kOpPopAnd: --sp; acc = ((stk >> sp) & 1ull) && acc; break;
+      case kOpPopOr: --sp; acc = ((stk >> sp) & 1ull) || acc; break;
+      case kOpPopAndNot: --sp; acc = (stk >> sp) & 1ull; break;
+      case kOpThreshBegin: cnt = 0; break;
+      case kOpThreshAdd: cnt += NE(arg) ? 1u : 0u; break;
+      case kOpThreshEnd: acc = cnt >= arg; break;
+      case kOpCount: return acc;
+      default: break;  // AND-NOT, text verification: the accumulator can only shrink
+    }
+  }
+  return acc;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -667,6 +700,12 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   // per-tile offset row (three dependent loads in front of a barrier, per tile, became two independent ones).
   uint64_t my_l0 = 0, my_l1 = 0;
   const uint32_t* my_tile_off = nullptr;
+  // A list without a per-tile offset row (short) and an explicit id list are WALKED: `my_cur` is the first entry not before
+  // the tile being visited — one load tells that a tile holds none of them (two binary searches of the whole list per
+  // tile before).
+  const uint32_t* my_ids = nullptr;
+  uint64_t my_cur = 0;
+  uint64_t* const ne_mask = reinterpret_cast<uint64_t*>(misc) + 4;  // 4 words: operands present in the tile (above)
   if (tid < n_leaves) {
     const DevLeaf lf = leaf[tid];
     if (lf.kind == kLeafList || lf.kind == kLeafGramBitmap) {
@@ -674,9 +713,135 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       my_l1 = ix.offsets[lf.a + 1];
       const uint32_t row = ix.skip_row[lf.a];
       if (row != kNoRow) my_tile_off = ix.tile_off + static_cast<uint64_t>(row) * (ix.n_tiles + 1);
+      else if (lf.kind == kLeafList) my_ids = ix.docids;
+    } else if (lf.kind == kLeafExplicit) {
+      my_ids = bt.explicit_pool;
+      my_l0 = lf.a;
+      my_l1 = static_cast<uint64_t>(lf.a) + lf.b;
     }
+    if (my_ids) my_cur = my_l0;
   }
-  for (uint32_t tile = next_tile(tile_begin); tile < tile_end; tile = next_tile(tile + 1)) {
+  // JUMPING. When every operand the program reads before its first COUNT is a sorted list (no bitmap-form operand, no
+  // slot range: nothing that is present in every tile), a tile can only matter if one of those lists has a posting in it:
+  // the workgroup goes from one such tile straight to the next (each list's thread knows its next posting's tile; one LDS
+  // min per step) instead of testing every tile of its item.
+  // A second, usually tighter bound: a list the accumulator cannot be non-empty without (an AND operand: REQUIRED) must have
+  // a posting in the tile, so the next tile is not before the latest of the required lists' next tiles — and that holds
+  // whatever else the program reads (a dense gram's bitmap beside a rare one).
+  uint32_t* const jump_word = reinterpret_cast<uint32_t*>(misc) + 16;  // [2][2]: min of the referenced, max of the required
+  uint64_t* const req_mask = reinterpret_cast<uint64_t*>(misc) + 10;   // 4 words: operands the first COUNT requires
+  bool my_ref = false, my_req = false, jumping = false, union_bound = false;
+  if (MODE != kModeDocPage) {
+    if (tid == 0) {
+      // required operands: Load l -> {l}; AND adds, OR intersects, AND-NOT keeps the left side; a threshold term requires
+      // its operands only when it asks for all of them. Sets are 4-word masks; the PUSH stack lives in the (still unused)
+      // operand stack region of LDS.
+      uint64_t acc[4] = {0, 0, 0, 0}, ts[4] = {0, 0, 0, 0};
+      uint32_t sp = 0, tcount = 0;
+      uint64_t* const rs = stack;
+      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+        const uint32_t ins = prog[pc];
+        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+        if (op == kOpCount) break;
+        const uint32_t w = (arg >> 6) & 3u;
+        const uint64_t bit = 1ull << (arg & 63u);
+        switch (op) {
+          case kOpLoad: acc[0] = acc[1] = acc[2] = acc[3] = 0; acc[w] = bit; break;
+          case kOpAnd: acc[w] |= bit; break;
+          case kOpOr: {
+            const bool had = acc[w] & bit;
+            acc[0] = acc[1] = acc[2] = acc[3] = 0;
+            if (had) acc[w] = bit;
+            break;
+          }
+          case kOpPush:
+            for (int k = 0; k < 4; ++k) rs[sp * 4 + k] = acc[k];
+            ++sp;
+            break;
+          case kOpPopAnd: --sp; for (int k = 0; k < 4; ++k) acc[k] |= rs[sp * 4 + k]; break;
+          case kOpPopOr: --sp; for (int k = 0; k < 4; ++k) acc[k] &= rs[sp * 4 + k]; break;
+          case kOpPopAndNot: --sp; for (int k = 0; k < 4; ++k) acc[k] = rs[sp * 4 + k]; break;
+          case kOpThreshBegin: ts[0] = ts[1] = ts[2] = ts[3] = 0; tcount = 0; break;
+          case kOpThreshAdd: ts[w] |= bit; ++tcount; break;
+          case kOpThreshEnd:
+            for (int k = 0; k < 4; ++k) acc[k] = arg >= tcount ? ts[k] : 0;
+            break;
+          default: break;
+        }
+      }
+      for (int k = 0; k < 4; ++k) req_mask[k] = acc[k];
+      for (int k = 0; k < 4; ++k) jump_word[k] = (k & 1) ? 0u : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    bool blocks = false, req_list = false;
+    if (tid < n_leaves) {
+      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
+        const uint32_t ins = prog[pc];
+        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+        if (op == kOpCount) break;
+        if ((op == kOpLoad || op == kOpAnd || op == kOpOr || op == kOpAndNot || op == kOpThreshAdd) && arg == tid) my_ref = true;
+      }
+      const DevLeaf lf = leaf[tid];
+      blocks = my_ref && (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap || (lf.kind == kLeafRange && lf.b > lf.a));
+      my_req = ((req_mask[tid >> 6] >> (tid & 63u)) & 1ull) && (my_ids != nullptr || (lf.kind == kLeafList && my_tile_off != nullptr));
+      req_list = my_req;
+    }
+    union_bound = __syncthreads_or(blocks ? 1 : 0) == 0;
+    jumping = union_bound || __syncthreads_or(req_list ? 1 : 0) != 0;
+  }
+  uint32_t jump_calls = 0;
+  // a lower bound (< tile_end, or tile_end: nothing left) of the first tile >= from that can matter; workgroup-uniform
+  auto next_candidate = [&](uint32_t from) -> uint32_t {
+    uint32_t mine = 0xFFFFFFFFu;  // the first tile >= from in which this thread's list has a posting
+    if ((my_ref || my_req) && from < tile_end) {
+      if (my_ids) {
+        uint64_t a = my_cur;
+        const uint64_t from_doc = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(from) * kTileDocs;
+        if (a < my_l1 && my_ids[a] < from_doc) {
+          a = lower_bound_u32(my_ids, a, my_l1, from_doc);
+          my_cur = a;
+        }
+        if (a < my_l1) mine = (my_ids[a] - ix.first_doc_id) >> kTileShift;
+      } else if (my_tile_off) {
+        uint32_t t = from;
+        while (t < tile_end && my_tile_off[t + 1] == my_tile_off[t]) ++t;
+        mine = t;
+      }
+      if (mine > tile_end) mine = tile_end;
+    }
+    uint32_t* const w = jump_word + 2u * (jump_calls & 1u);
+    if (union_bound && my_ref && mine < tile_end) atomicMin(w, mine);
+    if (my_req) atomicMax(w + 1, mine);  // (tile_end: this required list has nothing left — nor has the query)
+    __syncthreads();
+    uint32_t r = union_bound ? w[0] : from;
+    if (w[1] > r) r = w[1];
+    if (tid == 0) {  // (the other pair is next call's: nobody touches it before a barrier)
+      jump_word[2u * ((jump_calls + 1u) & 1u)] = 0xFFFFFFFFu;
+      jump_word[2u * ((jump_calls + 1u) & 1u) + 1] = 0u;
+    }
+    ++jump_calls;
+    return r < tile_end ? r : tile_end;
+  };
+  // tiles [from, to) are not visited: their outputs are zero
+  auto zero_skipped = [&](uint32_t from, uint32_t to) {
+    if (MODE == kModeBitmap)
+      for (uint32_t t = from; t < to; ++t)
+        bt.rbits[(static_cast<uint64_t>(q.out_slot) * ix.n_tiles + t) * kWordsPerTile + tid] = 0;
+    if (MODE == kModeBitmap || MODE == kModeDocCount)
+      for (uint32_t t = from + tid; t < to; t += kBlock) bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + t] = 0;
+  };
+  auto advance = [&](uint32_t done) -> uint32_t {  // the tile to visit after `done`
+    if (!jumping) return next_tile(done + 1);
+    const uint32_t nt = next_candidate(done + 1);
+    zero_skipped(done + 1, nt);
+    return nt;
+  };
+  uint32_t first_tile = next_tile(tile_begin);
+  if (jumping) {
+    first_tile = next_candidate(tile_begin);
+    zero_skipped(tile_begin, first_tile);
+  }
+  for (uint32_t tile = first_tile; tile < tile_end; tile = advance(tile)) {
     const uint64_t tile_first = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(tile) * kTileDocs;
     if (MODE == kModeScore) wave_topk_refresh_gbound(tk);
     // page pass: ranks [page_lo, page_hi) of the query's matches in doc order are wanted (ascending: the first `limit`,
@@ -693,26 +858,44 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     }
 
     // ---- A. operand setup: segment bounds, and bitmaps that need no scatter -----------------------------------
+    bool present = false;
     if (tid < n_leaves) {
       const DevLeaf lf = leaf[tid];
       uint64_t a = 0, b = 0;
-      if (lf.kind == kLeafList) {
-        if (my_tile_off) {
-          a = my_l0 + my_tile_off[tile];
-          b = my_l0 + my_tile_off[tile + 1];
-        } else {
-          a = lower_bound_u32(ix.docids, my_l0, my_l1, tile_first);
-          b = lower_bound_u32(ix.docids, a, my_l1, tile_first + kTileDocs);
-        }
-      } else if (lf.kind == kLeafExplicit) {
-        a = lower_bound_u32(bt.explicit_pool, lf.a, static_cast<uint64_t>(lf.a) + lf.b, tile_first);
-        b = lower_bound_u32(bt.explicit_pool, a, static_cast<uint64_t>(lf.a) + lf.b, tile_first + kTileDocs);
+      present = true;  // (bitmap-form operands: a dense gram, a filter row)
+      if (my_ids) {    // walked list: entries of this tile are [a, b), the pointer moves on to b
+        a = my_cur;
+        if (a < my_l1 && my_ids[a] < tile_first) a = lower_bound_u32(my_ids, a, my_l1, tile_first);  // (tiles were skipped)
+        b = a;
+        if (a < my_l1 && my_ids[a] < tile_first + kTileDocs) b = lower_bound_u32(my_ids, a + 1, my_l1, tile_first + kTileDocs);
+        my_cur = b;
+        present = b > a;
+      } else if (lf.kind == kLeafList) {
+        a = my_l0 + my_tile_off[tile];
+        b = my_l0 + my_tile_off[tile + 1];
+        present = b > a;
       } else if (lf.kind == kLeafGramBitmap) {
         // rank base for tf lookups: postings of the gram before this tile
         a = my_l0 + (my_tile_off ? my_tile_off[tile] : 0u);
+      } else if (lf.kind == kLeafRange) {
+        const uint64_t s0 = static_cast<uint64_t>(tile) * kTileDocs;
+        present = lf.b > lf.a && lf.b > s0 && lf.a < s0 + kTileDocs;
       }
       seg_lo[tid] = a;
       seg_hi[tid] = b;
+    }
+    {
+      const uint64_t m = __ballot(present);
+      if (lane_id() == 0) ne_mask[wave_id()] = m;
+    }
+    __syncthreads();
+    if (!tile_may_match(prog, q.n_instr, ne_mask)) {  // workgroup-uniform
+      if (MODE == kModeBitmap)
+        bt.rbits[(static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile) * kWordsPerTile + tid] = 0;
+      if ((MODE == kModeBitmap || MODE == kModeDocCount) && tid == 0)
+        bt.tile_cnt[static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile] = 0;
+      __syncthreads();  // (the next tile rewrites the mask)
+      continue;
     }
     // this thread's 64-bit word of a bitmap-form operand (dense gram, filter, slot range), straight from HBM
     auto direct_word = [&](const DevLeaf lf) -> uint64_t {
