@@ -1715,6 +1715,7 @@ struct mgx_batch {
     DevBuf d_pq_wave, d_pq_block;
     DevBuf d_queries, d_leaves, d_prog, d_score, d_explicit, d_counters, d_ident, d_items, d_list_begin;
     uint32_t n_items = 0;
+    uint32_t n_items_plain = 0;  // block-kernel items [0, n_items_plain): queries of bitmap-form operands only (LaunchTileEval)
     std::vector<unsigned long long> h_counters;
   };
   Group score, bitmap;
@@ -2315,6 +2316,17 @@ static int UploadGroup(mgx_batch* b, mgx_batch::Group& g, uint32_t mode, const s
     for (uint32_t i = 0; i < n; ++i) skip[i] = on_wave[i] == 4 ? 1 : 0;
     MGX_HIP(Upload(g.d_cand_skip, skip.data(), skip.size()));
   }
+  {
+    // block-kernel items: queries whose operands are all bitmap-form first (plain instantiation), then the queries with a
+    // sorted list, an explicit id list or a slot range among their operands (the instantiation that skips / jumps over tiles)
+    std::vector<uint8_t> listlike(n, 0);
+    for (uint32_t i = 0; i < n; ++i)
+      for (const DevLeaf& lf : specs[g.qids[i]].leaves)
+        if (lf.kind == kLeafList || lf.kind == kLeafExplicit || lf.kind == kLeafRange) listlike[i] = 1;
+    std::stable_partition(items_block.begin(), items_block.end(), [&](const DevItem& it) { return listlike[it.query] == 0; });
+    g.n_items_plain = 0;
+    for (const DevItem& it : items_block) g.n_items_plain += listlike[it.query] == 0 ? 1u : 0u;
+  }
   g.n_items = static_cast<uint32_t>(items_block.size());
   g.n_items_wave = static_cast<uint32_t>(items_wave.size());
   MGX_HIP(Upload(g.d_items, items_block.data(), items_block.size()));
@@ -2710,7 +2722,7 @@ static int CountDfImpl(mgx_batch* b, hipStream_t s) {
   }
   MGX_HIP(hipMemsetAsync(g.d_counters.p, 0, g.d_counters.bytes, s));
   MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, true, s));
-  MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s));
+  MGX_LAUNCH(LaunchTileEval(kModeTextDf, idx->dev, g.dev, g.plan, s, g.n_items_plain));
   // counter slot 5 of every df query (or the cached local count) -> the local array and the buffer ranks all-reduce
   MGX_LAUNCH(LaunchGatherDf(g.d_counters.as<unsigned long long>(), b->d_text_df_known.as<uint64_t>(),
                             static_cast<uint32_t>(g.qids.size()), b->d_text_df_local.as<uint64_t>(),
@@ -2813,7 +2825,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     }
     MGX_LAUNCH(LaunchCand(kModeScore, idx->dev, g.dev_cand, g.cand_leaves, g.cand_instr, g.cand_cap, side));
     MGX_LAUNCH(LaunchWaveScore(idx->dev, g.dev_wave_lists, g.wplan_lists, side));
-    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side));
+    MGX_LAUNCH(LaunchTileEval(kModeScore, idx->dev, g.dev, g.plan, side, g.n_items_plain));
     // (both conditions are the same on every rank: the collective is entered by all or by none)
     static const uint64_t kMinShardDocs = std::getenv("MGX_SEED_EXCHANGE_MIN_DOCS") ? static_cast<uint64_t>(atoll(std::getenv("MGX_SEED_EXCHANGE_MIN_DOCS"))) : 1000000ull;
     if (sg && sg->fn && g.seed_k != 0 && g.seed_table_docs / static_cast<uint64_t>(sg->world) >= kMinShardDocs) {
@@ -2867,7 +2879,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev0, s));
     }
-    MGX_LAUNCH(LaunchTileEval(kModeBitmap, idx->dev, g.dev, g.plan, s));
+    MGX_LAUNCH(LaunchTileEval(kModeBitmap, idx->dev, g.dev, g.plan, s, g.n_items_plain));
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev1, s));
       timed = true;
@@ -2896,7 +2908,7 @@ static int ExecuteImpl(mgx_batch* b, hipStream_t s, const SeedGather* sg = nullp
       MGX_HIP(hipEventRecord(b->res->join_ev, idx->side_stream));
     }
     MGX_LAUNCH(LaunchWaveCount(idx->dev, g.dev_wave, g.wplan, false, s));
-    MGX_LAUNCH(LaunchTileEval(kModeDocCount, idx->dev, g.dev, g.plan, s));
+    MGX_LAUNCH(LaunchTileEval(kModeDocCount, idx->dev, g.dev, g.plan, s, g.n_items_plain));
     if (b->timing && !timed) {
       MGX_HIP(hipEventRecord(ev1, s));
       timed = true;

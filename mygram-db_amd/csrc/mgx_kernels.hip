@@ -552,6 +552,123 @@ __device__ __forceinline__ uint32_t text_count_occurrences(const uint8_t* __rest
 
 __device__ __forceinline__ uint32_t exact_tf(const DevIndex& ix, uint32_t g, uint32_t row, uint32_t slot);
 
+// ---- jumping over tiles that cannot matter (general kernel) ------------------------------------------------------------
+// When every operand the program reads before its first COUNT is a sorted list (no bitmap-form operand, no slot range:
+// nothing that is present in every tile), a tile can only matter if one of those lists has a posting in it: the workgroup
+// goes from one such tile straight to the next (each list's thread knows its next posting's tile; one LDS min per step)
+// instead of testing every tile of its item — the UNION bound. A second, usually tighter one: a list the accumulator cannot
+// be non-empty without (an AND operand: REQUIRED) must have a posting in the tile, so the next tile is not before the
+// latest of the required lists' next tiles — and that holds whatever else the program reads (a dense gram's bitmap beside a
+// rare one).
+constexpr uint32_t kJumpRef = 1u, kJumpReq = 2u, kJumpJumping = 4u, kJumpUnion = 8u, kJumpCheck = 16u;
+
+// misc words: [16..19] jump words, u64 [10..13] required-operand mask. `stack` is the (still unused) operand stack region.
+__device__ __noinline__ uint32_t tile_jump_setup(const uint32_t* prog, uint32_t n_instr, const DevLeaf* leaf, uint32_t n_leaves,
+                                                 uint32_t* misc, uint64_t* stack, bool walked, bool has_off_row) {
+  const uint32_t tid = threadIdx.x;
+  bool listlike = false;
+  if (tid < n_leaves) {
+    const uint32_t kind = leaf[tid].kind;
+    listlike = kind == kLeafList || kind == kLeafExplicit || kind == kLeafRange;
+  }
+  // (a query of bitmap-form operands only — the common text-level shape — pays this one barrier)
+  if (__syncthreads_or(listlike ? 1 : 0) == 0) return 0;
+  uint32_t* const jump_word = misc + 16;
+  uint64_t* const req_mask = reinterpret_cast<uint64_t*>(misc) + 10;
+  if (tid == 0) {
+    // required operands: Load l -> {l}; AND adds, OR intersects, AND-NOT keeps the left side; a threshold term requires
+    // its operands only when it asks for all of them. Sets are 4-word masks.
+    uint64_t acc[4] = {0, 0, 0, 0}, ts[4] = {0, 0, 0, 0};
+    uint32_t sp = 0, tcount = 0;
+    for (uint32_t pc = 0; pc < n_instr; ++pc) {
+      const uint32_t ins = prog[pc];
+      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+      if (op == kOpCount) break;
+      const uint32_t w = (arg >> 6) & 3u;
+      const uint64_t bit = 1ull << (arg & 63u);
+      switch (op) {
+        case kOpLoad: acc[0] = acc[1] = acc[2] = acc[3] = 0; acc[w] = bit; break;
+        case kOpAnd: acc[w] |= bit; break;
+        case kOpOr: {
+          const bool had = acc[w] & bit;
+          acc[0] = acc[1] = acc[2] = acc[3] = 0;
+          if (had) acc[w] = bit;
+          break;
+        }
+        case kOpPush:
+          for (int k = 0; k < 4; ++k) stack[sp * 4 + k] = acc[k];
+          ++sp;
+          break;
+        case kOpPopAnd: --sp; for (int k = 0; k < 4; ++k) acc[k] |= stack[sp * 4 + k]; break;
+        case kOpPopOr: --sp; for (int k = 0; k < 4; ++k) acc[k] &= stack[sp * 4 + k]; break;
+        case kOpPopAndNot: --sp; for (int k = 0; k < 4; ++k) acc[k] = stack[sp * 4 + k]; break;
+        case kOpThreshBegin: ts[0] = ts[1] = ts[2] = ts[3] = 0; tcount = 0; break;
+        case kOpThreshAdd: ts[w] |= bit; ++tcount; break;
+        case kOpThreshEnd:
+          for (int k = 0; k < 4; ++k) acc[k] = arg >= tcount ? ts[k] : 0;
+          break;
+        default: break;
+      }
+    }
+    for (int k = 0; k < 4; ++k) req_mask[k] = acc[k];
+    for (int k = 0; k < 4; ++k) jump_word[k] = (k & 1) ? 0u : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  bool my_ref = false, my_req = false, blocks = false, absent_possible = false;
+  if (tid < n_leaves) {
+    for (uint32_t pc = 0; pc < n_instr; ++pc) {
+      const uint32_t ins = prog[pc];
+      const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
+      if (op == kOpCount) break;
+      if ((op == kOpLoad || op == kOpAnd || op == kOpOr || op == kOpAndNot || op == kOpThreshAdd) && arg == tid) my_ref = true;
+    }
+    const DevLeaf lf = leaf[tid];
+    blocks = my_ref && (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap || (lf.kind == kLeafRange && lf.b > lf.a));
+    my_req = ((req_mask[tid >> 6] >> (tid & 63u)) & 1ull) && (walked || (lf.kind == kLeafList && has_off_row));
+    absent_possible = my_ref && (lf.kind == kLeafList || lf.kind == kLeafExplicit || lf.kind == kLeafRange);
+  }
+  const bool union_bound = __syncthreads_or(blocks ? 1 : 0) == 0;
+  const bool jumping = union_bound || __syncthreads_or(my_req ? 1 : 0) != 0;
+  const bool check = __syncthreads_or(absent_possible ? 1 : 0) != 0;
+  return (my_ref ? kJumpRef : 0u) | (my_req ? kJumpReq : 0u) | (jumping ? kJumpJumping : 0u) | (union_bound ? kJumpUnion : 0u) |
+         (check ? kJumpCheck : 0u);
+}
+
+// a lower bound (< tile_end, or tile_end: nothing left) of the first tile >= from that can matter; workgroup-uniform.
+// `cur` is this thread's walked pointer (LDS), `ids` its id array (walked lists), `tile_off` its offset row (long lists).
+__device__ __noinline__ uint32_t tile_jump_next(uint32_t flags, uint32_t from, uint32_t tile_end, const uint32_t* ids,
+                                                uint64_t* cur, uint64_t l1, const uint32_t* tile_off, uint32_t first_doc_id,
+                                                uint32_t* jump_word, uint32_t calls) {
+  uint32_t mine = 0xFFFFFFFFu;  // the first tile >= from in which this thread's list has a posting
+  if ((flags & (kJumpRef | kJumpReq)) && from < tile_end) {
+    if (ids) {
+      uint64_t a = *cur;
+      const uint64_t from_doc = static_cast<uint64_t>(first_doc_id) + static_cast<uint64_t>(from) * kTileDocs;
+      if (a < l1 && ids[a] < from_doc) {
+        a = lower_bound_u32(ids, a, l1, from_doc);
+        *cur = a;
+      }
+      if (a < l1) mine = (ids[a] - first_doc_id) >> kTileShift;
+    } else if (tile_off) {
+      uint32_t t = from;
+      while (t < tile_end && tile_off[t + 1] == tile_off[t]) ++t;
+      mine = t;
+    }
+    if (mine > tile_end) mine = tile_end;
+  }
+  uint32_t* const w = jump_word + 2u * (calls & 1u);
+  if ((flags & kJumpUnion) && (flags & kJumpRef) && mine < tile_end) atomicMin(w, mine);
+  if (flags & kJumpReq) atomicMax(w + 1, mine);  // (tile_end: this required list has nothing left — nor has the query)
+  __syncthreads();
+  uint32_t r = (flags & kJumpUnion) ? w[0] : from;
+  if (w[1] > r) r = w[1];
+  if (threadIdx.x == 0) {  // (the other pair is next call's: nobody touches it before a barrier)
+    jump_word[2u * ((calls + 1u) & 1u)] = 0xFFFFFFFFu;
+    jump_word[2u * ((calls + 1u) & 1u) + 1] = 0u;
+  }
+  return r < tile_end ? r : tile_end;
+}
+
 // Can the query's program reach its first COUNT with a non-empty accumulator in a tile where only the operands marked in
 // `ne` (bit l = leaf l has a posting / a set range in this tile; bitmap-form operands always count as present) hold
 // anything? Evaluated on one boolean per operand: AND needs both sides, OR either, AND-NOT leaves the left side, a
@@ -585,8 +702,11 @@ __device__ __forceinline__ bool tile_may_match(const uint32_t* prog, uint32_t n_
   return acc;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan) {
+// JUMP: the query has an operand that can be absent from a tile (a sorted list, an explicit id list, a slot range): tiles
+// are tested / jumped over as described above. Queries of bitmap-form operands only run the plain instantiation — the
+// same tile loop without that machinery (its registers cost the text-level scoring path 6 % when they shared one kernel).
+template <int MODE, bool JUMP>
+__device__ __forceinline__ void tile_eval_body(const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LdsOffsets lo_ = carve(plan, MODE == kModeScore || MODE == kModeTextDf);
   uint64_t* const bm64 = reinterpret_cast<uint64_t*>(smem + lo_.bm);
@@ -703,8 +823,9 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
   // A list without a per-tile offset row (short) and an explicit id list are WALKED: `my_cur` is the first entry not before
   // the tile being visited — one load tells that a tile holds none of them (two binary searches of the whole list per
   // tile before).
+  // (the pointer lives in seg_hi[tid] — step A leaves the tile's end there anyway —, the id array follows from the kind:
+  //  registers are what keeps four waves per SIMD resident here)
   const uint32_t* my_ids = nullptr;
-  uint64_t my_cur = 0;
   uint64_t* const ne_mask = reinterpret_cast<uint64_t*>(misc) + 4;  // 4 words: operands present in the tile (above)
   if (tid < n_leaves) {
     const DevLeaf lf = leaf[tid];
@@ -719,108 +840,20 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       my_l0 = lf.a;
       my_l1 = static_cast<uint64_t>(lf.a) + lf.b;
     }
-    if (my_ids) my_cur = my_l0;
+    seg_hi[tid] = my_l0;
   }
-  // JUMPING. When every operand the program reads before its first COUNT is a sorted list (no bitmap-form operand, no
-  // slot range: nothing that is present in every tile), a tile can only matter if one of those lists has a posting in it:
-  // the workgroup goes from one such tile straight to the next (each list's thread knows its next posting's tile; one LDS
-  // min per step) instead of testing every tile of its item.
-  // A second, usually tighter bound: a list the accumulator cannot be non-empty without (an AND operand: REQUIRED) must have
-  // a posting in the tile, so the next tile is not before the latest of the required lists' next tiles — and that holds
-  // whatever else the program reads (a dense gram's bitmap beside a rare one).
+  // JUMPING (tile_jump_setup / tile_jump_next above the kernel; out of line, so that the queries that never jump keep the
+  // register budget of the tile loop).
   uint32_t* const jump_word = reinterpret_cast<uint32_t*>(misc) + 16;  // [2][2]: min of the referenced, max of the required
-  uint64_t* const req_mask = reinterpret_cast<uint64_t*>(misc) + 10;   // 4 words: operands the first COUNT requires
-  bool my_ref = false, my_req = false, jumping = false, union_bound = false;
-  if (MODE != kModeDocPage) {
-    if (tid == 0) {
-      // required operands: Load l -> {l}; AND adds, OR intersects, AND-NOT keeps the left side; a threshold term requires
-      // its operands only when it asks for all of them. Sets are 4-word masks; the PUSH stack lives in the (still unused)
-      // operand stack region of LDS.
-      uint64_t acc[4] = {0, 0, 0, 0}, ts[4] = {0, 0, 0, 0};
-      uint32_t sp = 0, tcount = 0;
-      uint64_t* const rs = stack;
-      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
-        const uint32_t ins = prog[pc];
-        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
-        if (op == kOpCount) break;
-        const uint32_t w = (arg >> 6) & 3u;
-        const uint64_t bit = 1ull << (arg & 63u);
-        switch (op) {
-          case kOpLoad: acc[0] = acc[1] = acc[2] = acc[3] = 0; acc[w] = bit; break;
-          case kOpAnd: acc[w] |= bit; break;
-          case kOpOr: {
-            const bool had = acc[w] & bit;
-            acc[0] = acc[1] = acc[2] = acc[3] = 0;
-            if (had) acc[w] = bit;
-            break;
-          }
-          case kOpPush:
-            for (int k = 0; k < 4; ++k) rs[sp * 4 + k] = acc[k];
-            ++sp;
-            break;
-          case kOpPopAnd: --sp; for (int k = 0; k < 4; ++k) acc[k] |= rs[sp * 4 + k]; break;
-          case kOpPopOr: --sp; for (int k = 0; k < 4; ++k) acc[k] &= rs[sp * 4 + k]; break;
-          case kOpPopAndNot: --sp; for (int k = 0; k < 4; ++k) acc[k] = rs[sp * 4 + k]; break;
-          case kOpThreshBegin: ts[0] = ts[1] = ts[2] = ts[3] = 0; tcount = 0; break;
-          case kOpThreshAdd: ts[w] |= bit; ++tcount; break;
-          case kOpThreshEnd:
-            for (int k = 0; k < 4; ++k) acc[k] = arg >= tcount ? ts[k] : 0;
-            break;
-          default: break;
-        }
-      }
-      for (int k = 0; k < 4; ++k) req_mask[k] = acc[k];
-      for (int k = 0; k < 4; ++k) jump_word[k] = (k & 1) ? 0u : 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    bool blocks = false, req_list = false;
-    if (tid < n_leaves) {
-      for (uint32_t pc = 0; pc < q.n_instr; ++pc) {
-        const uint32_t ins = prog[pc];
-        const uint32_t op = ins >> 24, arg = ins & 0xFFFFFFu;
-        if (op == kOpCount) break;
-        if ((op == kOpLoad || op == kOpAnd || op == kOpOr || op == kOpAndNot || op == kOpThreshAdd) && arg == tid) my_ref = true;
-      }
-      const DevLeaf lf = leaf[tid];
-      blocks = my_ref && (lf.kind == kLeafGramBitmap || lf.kind == kLeafFilterBitmap || (lf.kind == kLeafRange && lf.b > lf.a));
-      my_req = ((req_mask[tid >> 6] >> (tid & 63u)) & 1ull) && (my_ids != nullptr || (lf.kind == kLeafList && my_tile_off != nullptr));
-      req_list = my_req;
-    }
-    union_bound = __syncthreads_or(blocks ? 1 : 0) == 0;
-    jumping = union_bound || __syncthreads_or(req_list ? 1 : 0) != 0;
-  }
-  uint32_t jump_calls = 0;
-  // a lower bound (< tile_end, or tile_end: nothing left) of the first tile >= from that can matter; workgroup-uniform
+  uint32_t jflags = 0, jump_calls = 0;
+  if (JUMP && MODE != kModeDocPage)
+    jflags = tile_jump_setup(prog, q.n_instr, leaf, n_leaves, misc, stack, my_ids != nullptr, my_tile_off != nullptr);
+  const bool jumping = JUMP && (jflags & kJumpJumping) != 0, check_tiles = JUMP && (jflags & kJumpCheck) != 0;
   auto next_candidate = [&](uint32_t from) -> uint32_t {
-    uint32_t mine = 0xFFFFFFFFu;  // the first tile >= from in which this thread's list has a posting
-    if ((my_ref || my_req) && from < tile_end) {
-      if (my_ids) {
-        uint64_t a = my_cur;
-        const uint64_t from_doc = static_cast<uint64_t>(ix.first_doc_id) + static_cast<uint64_t>(from) * kTileDocs;
-        if (a < my_l1 && my_ids[a] < from_doc) {
-          a = lower_bound_u32(my_ids, a, my_l1, from_doc);
-          my_cur = a;
-        }
-        if (a < my_l1) mine = (my_ids[a] - ix.first_doc_id) >> kTileShift;
-      } else if (my_tile_off) {
-        uint32_t t = from;
-        while (t < tile_end && my_tile_off[t + 1] == my_tile_off[t]) ++t;
-        mine = t;
-      }
-      if (mine > tile_end) mine = tile_end;
-    }
-    uint32_t* const w = jump_word + 2u * (jump_calls & 1u);
-    if (union_bound && my_ref && mine < tile_end) atomicMin(w, mine);
-    if (my_req) atomicMax(w + 1, mine);  // (tile_end: this required list has nothing left — nor has the query)
-    __syncthreads();
-    uint32_t r = union_bound ? w[0] : from;
-    if (w[1] > r) r = w[1];
-    if (tid == 0) {  // (the other pair is next call's: nobody touches it before a barrier)
-      jump_word[2u * ((jump_calls + 1u) & 1u)] = 0xFFFFFFFFu;
-      jump_word[2u * ((jump_calls + 1u) & 1u) + 1] = 0u;
-    }
+    const uint32_t r = tile_jump_next(jflags, from, tile_end, my_ids, seg_hi + tid, my_l1, my_tile_off, ix.first_doc_id,
+                                      jump_word, jump_calls);
     ++jump_calls;
-    return r < tile_end ? r : tile_end;
+    return r;
   };
   // tiles [from, to) are not visited: their outputs are zero
   auto zero_skipped = [&](uint32_t from, uint32_t to) {
@@ -863,12 +896,11 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       const DevLeaf lf = leaf[tid];
       uint64_t a = 0, b = 0;
       present = true;  // (bitmap-form operands: a dense gram, a filter row)
-      if (my_ids) {    // walked list: entries of this tile are [a, b), the pointer moves on to b
-        a = my_cur;
+      if (my_ids) {    // walked list: entries of this tile are [a, b), the pointer (seg_hi[tid]) moves on to b
+        a = seg_hi[tid];
         if (a < my_l1 && my_ids[a] < tile_first) a = lower_bound_u32(my_ids, a, my_l1, tile_first);  // (tiles were skipped)
         b = a;
         if (a < my_l1 && my_ids[a] < tile_first + kTileDocs) b = lower_bound_u32(my_ids, a + 1, my_l1, tile_first + kTileDocs);
-        my_cur = b;
         present = b > a;
       } else if (lf.kind == kLeafList) {
         a = my_l0 + my_tile_off[tile];
@@ -884,12 +916,12 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
       seg_lo[tid] = a;
       seg_hi[tid] = b;
     }
-    {
+    if (check_tiles) {
       const uint64_t m = __ballot(present);
       if (lane_id() == 0) ne_mask[wave_id()] = m;
+      __syncthreads();
     }
-    __syncthreads();
-    if (!tile_may_match(prog, q.n_instr, ne_mask)) {  // workgroup-uniform
+    if (check_tiles && !tile_may_match(prog, q.n_instr, ne_mask)) {  // workgroup-uniform
       if (MODE == kModeBitmap)
         bt.rbits[(static_cast<uint64_t>(q.out_slot) * ix.n_tiles + tile) * kWordsPerTile + tid] = 0;
       if ((MODE == kModeBitmap || MODE == kModeDocCount) && tid == 0)
@@ -1221,6 +1253,15 @@ __global__ __launch_bounds__(kBlock) void tile_eval_kernel(DevIndex ix, DevBatch
     }
     if (tid == 0) bt.cand_n[it.list] = min(total, q.needed);
   }
+}
+
+// One launch for both kinds of item (two launches meant two tails): the host puts the plain items first, the workgroup
+// picks its instantiation by its index. The two bodies share no registers in flight; the kernel's budget is the larger one's.
+template <int MODE>
+__global__ __launch_bounds__(kBlock, (MODE == kModeScore ? 3 : 4)) void tile_eval_kernel(DevIndex ix, DevBatch bt, LdsPlan plan,
+                                                                                         uint32_t n_plain) {
+  if (blockIdx.x < n_plain) tile_eval_body<MODE, false>(ix, bt, plan);
+  else tile_eval_body<MODE, true>(ix, bt, plan);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -3774,7 +3815,9 @@ int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uin
   return 0;
 }
 
-int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s) {
+// Items [0, n_plain) belong to queries of bitmap-form operands only (plain instantiation), the rest to queries with an
+// operand that can be absent from a tile (jumping instantiation); n_plain >= n_items: everything plain.
+int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s, uint32_t n_plain) {
   const uint64_t grid = bt.n_items;
   if (grid == 0) return 0;
   if (grid > 0x7FFFFFFFull) return static_cast<int>(hipErrorInvalidValue);
@@ -3788,7 +3831,7 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan);
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan, n_plain);
   MGX_KCHECK();
   return 0;
 }

@@ -16,7 +16,8 @@ int LaunchBuildTfNib(const uint32_t* docids, const uint8_t* tf, const uint64_t* 
 int LaunchBuildBitmaps(const uint32_t* docids, const uint64_t* row_lo, const uint64_t* row_hi, uint32_t n_rows,
                        uint32_t first_doc_id, uint32_t first_row, uint64_t tile_stride, uint64_t row_stride,
                        uint64_t* bitmaps, hipStream_t s);
-int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s);
+int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPlan& plan, hipStream_t s,
+                   uint32_t n_plain = 0xFFFFFFFFu);
 int LaunchWaveScore(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
 int LaunchBitmapScore(uint32_t n_score, const DevIndex& ix, const DevBatch& bt, const FastPlan& plan, hipStream_t s);
 int LaunchWavePage(const DevIndex& ix, const DevBatch& bt, const WavePlan& plan, hipStream_t s);
