@@ -1381,7 +1381,12 @@ struct Compiler {
       Emit(kOpVerifyText, OnePattern(t));
       return;
     }
-    if (t.threshold != 0 && t.threshold < t.n_grams) {
+    if (t.threshold == 1 && t.n_grams > 1) {
+      // "at least one of its n-grams" is their union (FUZZY on a short term: theta = max(1, n - d * n_eff),
+      // search_pipeline.cpp:1700-1703): a flat program, which the wave kernels take
+      Emit(kOpLoad, GramLeaf(t.gram_ids[0]));
+      for (uint32_t i = 1; i < t.n_grams; ++i) Emit(kOpOr, GramLeaf(t.gram_ids[i]));
+    } else if (t.threshold != 0 && t.threshold < t.n_grams) {
       Emit(kOpThreshBegin);
       for (uint32_t i = 0; i < t.n_grams; ++i) Emit(kOpThreshAdd, GramLeaf(t.gram_ids[i]));
       Emit(kOpThreshEnd, t.threshold);
