@@ -731,22 +731,16 @@ std::string Index::ApplyMutations() const {
         nd->AddDocument(local++, kv.second);
         ids.push_back(kv.first);
       }
-      lock.unlock();  // (Finalize / AddFilterColumn of the new index take their own locks; nothing here touches `m`)
+      // (this Index's lock stays held: a writer thread recording a change meanwhile would otherwise see it marked applied;
+      //  Finalize / AddFilterColumn of the NEW index take that index's own locks)
       const std::string err = nd->Finalize();
-      if (!err.empty() || !nd->impl()->dev) {
-        lock.lock();
-        return fail("the delta index failed to build: " + err);
-      }
-      if (mgx_index_set_doc_map(nd->impl()->dev, ids.data(), ids.size()) != MGX_OK) {
-        lock.lock();
-        return fail(mgx_last_error());
-      }
+      if (!err.empty() || !nd->impl()->dev) return fail("the delta index failed to build: " + err);
+      if (mgx_index_set_doc_map(nd->impl()->dev, ids.data(), ids.size()) != MGX_OK) return fail(mgx_last_error());
       std::vector<std::string> names;
       {
         std::lock_guard<std::mutex> fl(im->filter_mu);
         for (const auto& c : im->filter_columns) names.push_back(c.name);
       }
-      lock.lock();
       for (const auto& kv : m.delta_filters)
         for (const auto& f : kv.second)
           if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);

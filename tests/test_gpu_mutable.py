@@ -242,3 +242,71 @@ def test_the_general_kernels_score_a_changed_table_too():
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_mutable.py"),
                             "-k", "changes_after_the_build"], env=e, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_a_table_changes_while_a_micro_batcher_serves_it():
+    """search_pipeline::MicroBatcher over a table that a writer thread keeps changing: the mutation calls only record (any
+    thread), the batcher's submitting thread applies them between batches; searches never fail, and once the writer is done
+    the answers are those of an index built from the final documents."""
+    import threading
+    S = _shim()
+    n = 30_000
+    corpus = mg.Corpus.synthetic(n, seed=61)
+    p = Pair(corpus=corpus)
+    p.dev.ensure_text()
+    t = S.Table(p.dev)
+    m = Mirror(corpus)
+    c = p.dev.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    grams = [c.gram(g).decode() for g in np.argsort(-sizes)[:40] if b" " not in c.gram(g)]
+    b = S.Batcher(t, max_batch=64, max_delay_us=200, depth=2, planner_threads=2)
+    errors, done = [], threading.Event()
+
+    def searcher(seed):
+        r = np.random.default_rng(seed)
+        try:
+            while not done.is_set():
+                terms = [grams[int(r.integers(0, len(grams)))] for _ in range(int(r.integers(1, 4)))]
+                total, docs, scores = b.search(terms, limit=10, sort_by_score=bool(r.integers(0, 2)))
+                assert len(docs) <= 10 and total >= len(docs)
+        except BaseException as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=searcher, args=(100 + k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    rng = np.random.default_rng(62)
+    try:
+        for step in range(300):
+            live = sorted(m.docs)
+            d = int(live[int(rng.integers(0, len(live)))])
+            kind = step % 3
+            if kind == 0:
+                t.remove_document(d, m.docs[d])
+                del m.docs[d]
+            elif kind == 1:
+                new = corpus.text(int(rng.integers(0, n)))
+                t.update_document(d, m.docs[d], new)
+                m.docs[d] = new
+            else:
+                new_id = max(max(m.docs), n) + 1
+                new = corpus.text(int(rng.integers(0, n)))
+                t.add_document(new_id, new)
+                m.docs[new_id] = new
+            if step == 150:
+                b.search([grams[0]], limit=5)  # (a search from the writer's thread too)
+    finally:
+        done.set()
+        for th in threads:
+            th.join()
+    assert not errors, errors[:1]
+    want = m.rebuilt()
+    for terms in ([grams[0]], [grams[1], grams[2]], [grams[3], grams[4], grams[5]]):
+        for by_score in (True, False):
+            total, docs, scores = b.search(terms, limit=10, sort_by_score=by_score)
+            wt, wp, ws, _ = want.oracle_query(Query(terms, sort_score=by_score, limit=10))
+            assert total == wt and docs.tolist() == wp.tolist(), (terms, by_score)
+            if by_score:
+                assert np.array_equal(scores, ws), terms
+    st = b.stats()
+    assert st["queries"] >= 20 and st["batches"] >= 5, st  # (every batch formed while the writer ran applied changes first)
