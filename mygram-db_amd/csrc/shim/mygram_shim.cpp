@@ -291,6 +291,8 @@ struct Index::Impl {
     bool delta_changed = false;
     uint64_t main_docs = 0, main_len = 0;       // BM25Stats share of the main index's live documents
     uint64_t removed = 0, epoch = 0;
+    std::chrono::microseconds staleness{0};                 // SetMutationStaleness
+    std::chrono::steady_clock::time_point last_apply{};     // when the device state was last brought up to date
     uint32_t live_bitmap = 0;
     bool have_live = false;
     std::shared_ptr<Index> delta;               // the delta index the device holds (nullptr: none)
@@ -678,11 +680,19 @@ Index::MutationStats Index::GetMutationStats() const {
 
 // The recorded changes reach the device: live row, delta index, table-wide statistics. The caller guarantees that no
 // batch of this Index is being planned, compiled or run by another thread (header note).
-std::string Index::ApplyMutations() const {
+void Index::SetMutationStaleness(std::chrono::microseconds max_staleness) {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  impl_->mut.staleness = max_staleness;
+}
+
+std::string Index::ApplyMutations(bool force) const {
   Impl* im = impl_.get();
   std::unique_lock<std::mutex> lock(im->mu);
   Impl::Mutable& m = im->mut;
   if (!m.dirty) return "";
+  const auto now = std::chrono::steady_clock::now();
+  if (!force && m.staleness.count() > 0 && m.epoch > 0 && now - m.last_apply < m.staleness) return "";
+  m.last_apply = now;
   auto fail = [&](const std::string& msg) {
     im->last_error = "ApplyMutations: " + msg;
     return im->last_error;
@@ -805,7 +815,7 @@ std::string Index::Compact() const {
   Finalize();
   FlushPendingFilterColumns();
   {
-    const std::string e = ApplyMutations();
+    const std::string e = ApplyMutations(/*force=*/true);
     if (!e.empty()) return e;
   }
   Impl* im = impl_.get();
@@ -920,8 +930,10 @@ std::string Index::Compact() const {
   im->global_docs = 0;
   im->global_avgdl = 0.0;
   const uint64_t epoch = m.epoch + 1;
+  const auto staleness = m.staleness;
   m = Impl::Mutable{};
   m.epoch = epoch;
+  m.staleness = staleness;
   {
     std::lock_guard<std::mutex> fl(im->filter_mu);
     im->filter_columns.clear();
@@ -2695,8 +2707,11 @@ Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& querie
   bool dirty = false, mutable_table = false;
   {
     std::lock_guard<std::mutex> il(im->mu);
-    dirty = im->mut.dirty;
-    mutable_table = im->mut.active;
+    const auto& mm = im->mut;
+    // (with a staleness bound, recorded changes wait — and the pipeline is not drained — until the bound has passed)
+    dirty = mm.dirty && (mm.staleness.count() == 0 || mm.epoch == 0 ||
+                         std::chrono::steady_clock::now() - mm.last_apply >= mm.staleness);
+    mutable_table = mm.active;
   }
   if (dirty) {
     if (impl_->opt.comm)

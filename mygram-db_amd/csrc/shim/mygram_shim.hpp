@@ -189,7 +189,14 @@ class Index {
   };
   [[nodiscard]] MutationStats GetMutationStats() const;
   // Brings the device state up to date with the recorded changes (every query entry point calls it). "" or an error.
-  std::string ApplyMutations() const;
+  // With a staleness bound set (below) the entry points' calls do nothing until the bound has passed since the last
+  // application; force = true applies now.
+  std::string ApplyMutations(bool force = false) const;
+  // A table under a steady stream of changes would rebuild its delta index for every batch (0.07-0.2 s each). With a
+  // staleness bound, recorded changes become visible to queries at most that long after they were made (they are applied
+  // by the first query entry point after the bound has passed): the reference's binlog applier is asynchronous to
+  // queries in the same way. 0 (default): every query sees every change recorded before it.
+  void SetMutationStaleness(std::chrono::microseconds max_staleness);
   // Folds the delta back: the main index is rebuilt from the table's current documents (the texts of its live documents come
   // back from the device, where BM25 keeps them; filter values likewise) and the delta and the live row go. What the
   // reference's Optimize / a dump-and-reload do for a grown index. Same exclusion rule as the mutation-applying entry

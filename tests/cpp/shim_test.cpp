@@ -192,6 +192,16 @@ int main() {
     c.order = SortOrder::ASC;
     auto r2 = ExecuteBatch(index, {c});
     EXPECT(r2.has_value() && (*r2)[0].results == (V{4, 5, 9}));
+    // a staleness bound: changes recorded inside the bound wait for it (or for a forced application)
+    index.SetMutationStaleness(std::chrono::seconds(3600));
+    index.RemoveDocument(9, "machine cats");
+    auto rs = ExecuteBatch(index, {c});
+    EXPECT(rs.has_value() && (*rs)[0].results == (V{4, 5, 9}));  // not yet
+    EXPECT(index.ApplyMutations(/*force=*/true).empty());
+    rs = ExecuteBatch(index, {c});
+    EXPECT(rs.has_value() && (*rs)[0].results == (V{4, 5}));
+    EXPECT(index.AddDocument(9, "machine cats"));
+    index.SetMutationStaleness(std::chrono::microseconds(0));
     EXPECT(index.Compact().empty());
     auto r3 = ExecuteBatch(index, {q, c});
     EXPECT(r3.has_value() && (*r3)[0].results == (V{4, 5}) && (*r3)[1].results == (V{4, 5, 9}));
