@@ -96,6 +96,8 @@ int mgxs_table_remove_document(mgxs_table* table, uint32_t doc_id, const char* t
 /* Index::UpdateFilters (DocumentStore::UpdateDocument(doc_id, filters)): the document's filter values change, its text stays. */
 int mgxs_table_update_filters(mgxs_table* table, uint32_t doc_id, uint32_t n_filters, const char* const* names,
                               const int* types, const void* values, const char* const* strings);
+/* Index::SetMutationStaleness: recorded changes become visible at most this long after they were made (0: at once). */
+int mgxs_table_set_mutation_staleness(mgxs_table* table, uint64_t microseconds);
 /* Index::Compact: the main index rebuilt from the table's current documents; the delta goes. */
 int mgxs_table_compact(mgxs_table* table);
 int mgxs_table_mutation_stats(mgxs_table* table, uint64_t* main_documents, uint64_t* delta_documents,

@@ -12,7 +12,7 @@ EXPORTS = ["mgxs_last_error", "mgxs_table_adopt", "mgxs_table_set_global_stats",
            "mgxs_table_set_normalization", "mgxs_table_set_absent_grams", "mgxs_normalize_uses_icu", "mgxs_normalize_text",
            "mgxs_executor_create", "mgxs_executor_create_sharded", "mgxs_executor_destroy", "mgxs_executor_warm",
            "mgxs_submit", "mgxs_wait", "mgxs_table_from_dump", "mgxs_table_add_filter_column", "mgxs_search", "mgxs_facet",
-           "mgxs_table_add_document", "mgxs_table_update_document", "mgxs_table_remove_document", "mgxs_table_mutation_stats", "mgxs_table_compact", "mgxs_table_update_filters",
+           "mgxs_table_add_document", "mgxs_table_update_document", "mgxs_table_remove_document", "mgxs_table_mutation_stats", "mgxs_table_compact", "mgxs_table_set_mutation_staleness", "mgxs_table_update_filters",
            "mgxs_batcher_create", "mgxs_batcher_destroy", "mgxs_batcher_search", "mgxs_batcher_stats"]
 _lib = None
 
@@ -56,6 +56,7 @@ def load():
     L.mgxs_table_update_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, i32, u32, vp, vp, vp, vp]
     L.mgxs_table_remove_document.argtypes = [vp, u32, C.c_char_p, C.c_size_t]
     L.mgxs_table_compact.argtypes = [vp]
+    L.mgxs_table_set_mutation_staleness.argtypes = [vp, u64]
     L.mgxs_table_update_filters.argtypes = [vp, u32, u32, vp, vp, vp, vp]
     L.mgxs_table_mutation_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.mgxs_batcher_create.argtypes = [vp, u32, u32, i32, i32, C.POINTER(vp)]
@@ -222,6 +223,10 @@ class Table:
         """Index::RemoveDocument (text = the document's current normalized text)."""
         raw = self._text(text)
         _check(load().mgxs_table_remove_document(self._h, doc_id, raw, len(raw)))
+
+    def set_mutation_staleness(self, seconds):
+        """Index::SetMutationStaleness: how long recorded changes may wait before queries see them (0: not at all)."""
+        _check(load().mgxs_table_set_mutation_staleness(self._h, int(seconds * 1e6)))
 
     def compact(self):
         """Index::Compact: the main index rebuilt from the current documents (delta and live row go)."""

@@ -159,16 +159,18 @@ static int BuildColumnsSorted(const mgx_build_params& bp, const uint8_t* text_by
   std::atomic<int> failed{0};
   auto parallel = [&](uint64_t n_jobs, auto&& fn) {
     next = 0;
+    const unsigned workers = static_cast<unsigned>(std::min<uint64_t>(n_threads, n_jobs));
+    auto body = [&]() {
+      DocScratch s;
+      for (;;) {
+        const uint64_t c = next.fetch_add(1);
+        if (c >= n_jobs || failed.load()) break;
+        fn(c, s);
+      }
+    };
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < n_threads; ++t)
-      th.emplace_back([&]() {
-        DocScratch s;
-        for (;;) {
-          const uint64_t c = next.fetch_add(1);
-          if (c >= n_jobs || failed.load()) break;
-          fn(c, s);
-        }
-      });
+    for (unsigned t = 1; t < workers; ++t) th.emplace_back(body);
+    body();
     for (auto& t : th) t.join();
   };
   // ---- A: records of every chunk, sorted by key (docs ascend inside equal keys: the sort is stable) -------------------
@@ -322,7 +324,8 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
   const bool cross = bp.cross_boundary_ngrams != 0;
   unsigned hw = std::thread::hardware_concurrency();
   const unsigned n_threads = bp.n_threads > 0 ? static_cast<unsigned>(bp.n_threads) : (hw ? hw : 4);
-  const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>((n_docs + 4095) / 4096, n_threads * 8ull));
+  // (512 documents per chunk at least: a delta index of a few thousand documents still spreads over the cores)
+  const uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>((n_docs + 511) / 512, n_threads * 8ull));
   const uint64_t chunk_docs = (n_docs + n_chunks - 1) / n_chunks;
 
   auto cols = std::make_unique<Columns>();
@@ -335,17 +338,20 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
   std::atomic<int> failed{0};
   auto run_chunks = [&](auto&& fn) {
     next = 0;
+    // (no more threads than chunks: a delta index of a few thousand documents is one or two chunks, and spawning one
+    //  thread per hardware thread of a 256-way host for each of the three passes was 75 of its 80 ms; the caller works too)
+    const unsigned workers = static_cast<unsigned>(std::min<uint64_t>(n_threads, n_chunks));
+    auto body = [&]() {
+      DocScratch s;
+      for (;;) {
+        uint64_t c = next.fetch_add(1);
+        if (c >= n_chunks || failed.load()) break;
+        fn(c, s);
+      }
+    };
     std::vector<std::thread> th;
-    for (unsigned t = 0; t < n_threads; ++t) {
-      th.emplace_back([&]() {
-        DocScratch s;
-        for (;;) {
-          uint64_t c = next.fetch_add(1);
-          if (c >= n_chunks || failed.load()) break;
-          fn(c, s);
-        }
-      });
-    }
+    for (unsigned t = 1; t < workers; ++t) th.emplace_back(body);
+    body();
     for (auto& t : th) t.join();
   };
 

@@ -693,6 +693,14 @@ std::string Index::ApplyMutations(bool force) const {
   const auto now = std::chrono::steady_clock::now();
   if (!force && m.staleness.count() > 0 && m.epoch > 0 && now - m.last_apply < m.staleness) return "";
   m.last_apply = now;
+  static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
+  auto t_prev = now;
+  auto lap = [&](const char* what) {
+    if (!kTrace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[shim] ApplyMutations %s: %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   auto fail = [&](const std::string& msg) {
     im->last_error = "ApplyMutations: " + msg;
     return im->last_error;
@@ -719,6 +727,7 @@ std::string Index::ApplyMutations(bool force) const {
       return fail(mgx_last_error());
   }
   m.pending_clear.clear();
+  lap("sync + live row + cleaned bitmaps");
   // ---- posting sizes: the main index's live postings, then the delta's on top -------------------------------------------
   for (const auto& c : m.delta_contrib) im->global_sizes[c.first] -= c.second;
   m.delta_contrib.clear();
@@ -770,6 +779,7 @@ std::string Index::ApplyMutations(bool force) const {
       m.delta_ids = std::make_shared<const std::vector<DocId>>(std::move(ids));
     }
   }
+  lap("delta index (columns, device index, doc map, filter columns)");
   // ---- table-wide statistics in both ------------------------------------------------------------------------------------
   uint64_t n_docs = m.main_docs, total_len = m.main_len;
   im->absent_grams.clear();
@@ -803,6 +813,7 @@ std::string Index::ApplyMutations(bool force) const {
     if (mgx_index_invalidate_statistics(dm->dev) != MGX_OK) return fail(mgx_last_error());
   }
   if (mgx_index_invalidate_statistics(im->dev) != MGX_OK) return fail(mgx_last_error());
+  lap("statistics");
   m.dirty = false;
   m.epoch += 1;
   return "";
@@ -1084,10 +1095,13 @@ std::string Index::Finalize() const {
   }
   impl_->pending.clear();
   mgx_build_params bp{sizeof(mgx_build_params), MGX_ABI_VERSION, ngram_size_, kanji_ngram_size_, cross_boundary_ ? 1 : 0, 0};
+  static const bool kTraceBuild = std::getenv("MGX_TRACE_HOST") != nullptr;
+  const auto tb0 = std::chrono::steady_clock::now();
   if (mgx_columns_build(&bp, bytes.data(), off.data(), first, n, &impl_->cols) != MGX_OK) {
     impl_->last_error = mgx_last_error();
     return impl_->last_error;
   }
+  const auto tb1 = std::chrono::steady_clock::now();
   mgx_columns_view_get(impl_->cols, &impl_->view);
   const auto& v = impl_->view;
   mgx_index_desc d{sizeof(mgx_index_desc), MGX_ABI_VERSION, impl_->device, 0, v.first_doc_id, v.n_docs, v.n_grams,
@@ -1099,9 +1113,15 @@ std::string Index::Finalize() const {
     return impl_->last_error;
   }
   impl_->Publish();
+  const auto tb2 = std::chrono::steady_clock::now();
   // the shim's Index is also the DocumentStore of the texts it was given: BM25 terms longer than one n-gram are
   // counted in the text on the device
   if (mgx_index_attach_text(impl_->dev, bytes.data(), off.data()) != MGX_OK) impl_->last_error = mgx_last_error();
+  if (kTraceBuild)
+    fprintf(stderr, "[shim] Finalize of %llu docs: columns %.2f ms, device index %.2f ms, texts %.2f ms\n",
+            static_cast<unsigned long long>(n), std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
+            std::chrono::duration<double, std::milli>(tb2 - tb1).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb2).count());
   // DocumentStore::GetAllDocIds (the NOT universe of boolean expressions) is the set of ids that were added
   if (impl_->has_gaps &&
       mgx_index_add_filter_bitmap(impl_->dev, existing.data(), existing.size(), &impl_->exists_bitmap) != MGX_OK)

@@ -380,6 +380,12 @@ int mgxs_table_update_filters(mgxs_table* table, uint32_t doc_id, uint32_t n_fil
   }
 }
 
+int mgxs_table_set_mutation_staleness(mgxs_table* table, uint64_t microseconds) {
+  if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_set_mutation_staleness: null argument");
+  table->index->SetMutationStaleness(std::chrono::microseconds(microseconds));
+  return MGX_OK;
+}
+
 int mgxs_table_compact(mgxs_table* table) {
   if (!table) return Fail(MGX_ERR_INVALID_ARGUMENT, "mgxs_table_compact: null argument");
   try {

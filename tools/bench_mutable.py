@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--deltas", default="1000,10000,100000")
     ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--write-rate", type=float, default=0.0, help="steady writer: changes per second (0: skip)")
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
@@ -114,6 +115,44 @@ def main():
                           "queries_per_s": args.batch * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
                           "vs_static": args.batch * args.steps / dt / static_qps,
                           "host_ms_plan_compile_enqueue_wait": HOST_MS.round(3).tolist()}), flush=True)
+    # a steady writer: changes keep arriving (a thread, ~args.write_rate per second) while the executor serves; with a
+    # staleness bound the delta is rebuilt once per bound, not once per batch
+    if args.write_rate > 0:
+        import threading
+        for bound in (0.0, 0.25, 1.0):
+            shim_table.set_mutation_staleness(bound)
+            stop = threading.Event()
+            made = [0]
+
+            def writer():
+                nonlocal next_id
+                r = np.random.default_rng(11)
+                t_next = time.perf_counter()
+                while not stop.is_set():
+                    new = corpus.text(int(r.integers(0, args.docs)))
+                    shim_table.add_document(next_id, new)
+                    texts[next_id] = new
+                    next_id += 1
+                    made[0] += 1
+                    t_next += 1.0 / args.write_rate
+                    d = t_next - time.perf_counter()
+                    if d > 0:
+                        time.sleep(d)
+            th = threading.Thread(target=writer)
+            th.start()
+            t0 = time.perf_counter()
+            steps = 0
+            while time.perf_counter() - t0 < 4.0:
+                run(ex, qbs, 20, depth, outs)
+                steps += 20
+            dt = time.perf_counter() - t0
+            stop.set()
+            th.join()
+            print(json.dumps({"table": "steady writer", "staleness_s": bound, "changes_per_s": made[0] / dt,
+                              "queries_per_s": args.batch * steps / dt, "ms_per_step": 1e3 * dt / steps,
+                              "vs_static": args.batch * steps / dt / static_qps,
+                              "delta_documents": shim_table.mutation_stats()["delta_documents"]}), flush=True)
+        shim_table.set_mutation_staleness(0.0)
     # compaction: the main index rebuilt from the current documents (texts back from HBM, columns rebuilt, uploaded)
     t0 = time.perf_counter()
     shim_table.compact()
