@@ -295,6 +295,12 @@ struct Index::Impl {
     std::chrono::steady_clock::time_point last_apply{};     // when the device state was last brought up to date
     uint32_t live_bitmap = 0;
     bool have_live = false;
+    std::vector<uint64_t> applied_live;         // main_live as of the last application: what the DEVICE's live row says
+    // background application (SetMutationStaleness > 0): a snapshot's delta is built by `builder` while queries keep
+    // running on the old state; the result waits (build_ready) for the next entry point to install it
+    std::thread builder;
+    bool build_running = false, build_ready = false;
+    std::shared_ptr<void> bg_snapshot, bg_built;  // (MutationSnapshot / BuiltDelta of the running build)
     std::shared_ptr<Index> delta;               // the delta index the device holds (nullptr: none)
     std::shared_ptr<const std::vector<DocId>> delta_ids;  // its doc map: local id - 1 -> table id, ascending
     std::vector<std::pair<uint32_t, uint64_t>> delta_contrib;  // (main gram id, the delta's posting count) inside global_sizes
@@ -305,6 +311,13 @@ struct Index::Impl {
     if (!mut.active || doc < view.first_doc_id || doc - view.first_doc_id >= view.n_docs) return false;
     const uint64_t slot = doc - view.first_doc_id;
     return (mut.main_live[slot >> 6] >> (slot & 63)) & 1;
+  }
+  // ... as the device's live row has it (changes recorded but not yet applied do not count): what the single operators
+  // must filter by, so that they agree with the delta index the device holds
+  bool LiveApplied(DocId doc) const {
+    if (!mut.active || doc < view.first_doc_id || doc - view.first_doc_id >= view.n_docs) return false;
+    const uint64_t slot = doc - view.first_doc_id;
+    return (mut.applied_live[slot >> 6] >> (slot & 63)) & 1;
   }
 
   // ---- filter columns (DocumentStore filter values + FilterIndex, on the device by doc slot) -------------------------
@@ -355,6 +368,7 @@ Index::Index(int ngram_size, int kanji_ngram_size, double roaring_threshold, boo
 }
 
 Index::~Index() {
+  if (impl_->mut.builder.joinable()) impl_->mut.builder.join();  // (a delta build in flight reads this object's configuration)
   if (tl_last_index == this) tl_last_index = nullptr;
   const Index* me = this;
   g_last_finalized.compare_exchange_strong(me, nullptr);
@@ -468,6 +482,7 @@ std::string EnsureMutable(Index::Impl* im) {
     m.main_live.assign((n + 63) / 64, ~0ull);
     if (n & 63) m.main_live.back() = (1ull << (n & 63)) - 1;
   }
+  m.applied_live = m.main_live;
   m.main_docs = im->view.bm25_doc_count;
   m.main_len = im->view.bm25_total_len;
   im->global_sizes.resize(im->view.n_grams);
@@ -680,21 +695,103 @@ Index::MutationStats Index::GetMutationStats() const {
 
 // The recorded changes reach the device: live row, delta index, table-wide statistics. The caller guarantees that no
 // batch of this Index is being planned, compiled or run by another thread (header note).
-void Index::SetMutationStaleness(std::chrono::microseconds max_staleness) {
-  std::lock_guard<std::mutex> lock(impl_->mu);
-  impl_->mut.staleness = max_staleness;
+namespace {
+// What one application works from: everything recorded up to one moment, taken under the index lock.
+struct MutationSnapshot {
+  std::vector<DocId> clear, dead_docs;
+  std::vector<uint32_t> dead_grams;
+  bool delta_changed = false;
+  std::map<DocId, std::string> docs;  // (copies, only when the delta changed)
+  std::map<DocId, storage::FilterMap> filters;
+  std::vector<std::string> column_names;
+  uint64_t main_docs = 0, main_len = 0;
+};
+struct BuiltDelta {
+  bool rebuilt = false;
+  std::shared_ptr<Index> delta;  // nullptr with rebuilt: the delta is empty now
+  std::shared_ptr<const std::vector<DocId>> ids;
+  std::string error;
+};
+
+MutationSnapshot TakeSnapshot(Index::Impl* im) {  // im->mu held
+  Index::Impl::Mutable& m = im->mut;
+  MutationSnapshot snap;
+  snap.clear.swap(m.pending_clear);
+  snap.dead_docs.swap(m.pending_dead_docs);
+  snap.dead_grams.swap(m.pending_dead_grams);
+  snap.delta_changed = m.delta_changed;
+  if (m.delta_changed) {
+    snap.docs = m.delta_docs;
+    snap.filters = m.delta_filters;
+  }
+  snap.main_docs = m.main_docs;
+  snap.main_len = m.main_len;
+  {
+    std::lock_guard<std::mutex> fl(im->filter_mu);
+    for (const auto& c : im->filter_columns) snap.column_names.push_back(c.name);
+  }
+  m.delta_changed = false;
+  m.dirty = false;
+  return snap;
 }
 
-std::string Index::ApplyMutations(bool force) const {
-  Impl* im = impl_.get();
-  std::unique_lock<std::mutex> lock(im->mu);
-  Impl::Mutable& m = im->mut;
-  if (!m.dirty) return "";
-  const auto now = std::chrono::steady_clock::now();
-  if (!force && m.staleness.count() > 0 && m.epoch > 0 && now - m.last_apply < m.staleness) return "";
-  m.last_apply = now;
+// The delta index of a snapshot: column build, device index, doc map, filter columns. Touches nothing of `self` that changes
+// (its configuration only), so it runs with or without the index lock — in a builder thread when changes may wait.
+BuiltDelta BuildDelta(const Index& self, const MutationSnapshot& snap) {
+  BuiltDelta out;
+  if (!snap.delta_changed) return out;
+  out.rebuilt = true;
+  if (snap.docs.empty()) return out;
+  Index::Impl* im = self.impl();
+  auto nd = std::make_shared<Index>(self.GetNgramSize(), im->query_kanji, im->dense_threshold, self.GetCrossBoundaryNgrams(),
+                                    self.GetNormalizeNfkc(), self.GetNormalizeWidth(), self.GetNormalizeLower(), im->device);
+  std::vector<DocId> ids;
+  ids.reserve(snap.docs.size());
+  DocId local = 1;
+  for (const auto& kv : snap.docs) {  // (ascending table id -> ascending local id: rank order and ties are kept)
+    nd->AddDocument(local++, kv.second);
+    ids.push_back(kv.first);
+  }
+  const std::string err = nd->Finalize();
+  if (!err.empty() || !nd->impl()->dev) {
+    out.error = "the delta index failed to build: " + err;
+    return out;
+  }
+  if (mgx_index_set_doc_map(nd->impl()->dev, ids.data(), ids.size()) != MGX_OK) {
+    out.error = mgx_last_error();
+    return out;
+  }
+  std::vector<std::string> names = snap.column_names;
+  for (const auto& kv : snap.filters)
+    for (const auto& f : kv.second)
+      if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);
+  for (const auto& name : names) {
+    std::vector<storage::FilterValue> values(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) {
+      const auto fm = snap.filters.find(ids[i]);
+      if (fm == snap.filters.end()) continue;
+      const auto fv = fm->second.find(name);
+      if (fv != fm->second.end()) values[i] = fv->second;
+    }
+    const std::string ferr = nd->AddFilterColumn(name, values);
+    if (!ferr.empty()) {
+      out.error = ferr;
+      return out;
+    }
+  }
+  nd->impl()->fallback = im;
+  out.delta = std::move(nd);
+  out.ids = std::make_shared<const std::vector<DocId>>(std::move(ids));
+  return out;
+}
+
+// A snapshot and its delta reach the device: cleaned bitmaps, live row, the delta's handles, table-wide statistics. im->mu
+// held; no batch of this Index is planned, compiled or in flight (the callers' contract).
+std::string InstallMutations(Index::Impl* im, MutationSnapshot& snap, BuiltDelta& built) {
+  Index::Impl::Mutable& m = im->mut;
   static const bool kTrace = std::getenv("MGX_TRACE_HOST") != nullptr;
-  auto t_prev = now;
+  auto t_prev = std::chrono::steady_clock::now();
+  m.last_apply = t_prev;
   auto lap = [&](const char* what) {
     if (!kTrace) return;
     const auto t = std::chrono::steady_clock::now();
@@ -705,83 +802,45 @@ std::string Index::ApplyMutations(bool force) const {
     im->last_error = "ApplyMutations: " + msg;
     return im->last_error;
   };
+  if (!built.error.empty()) return fail(built.error);
   if (mgx_index_synchronize(im->dev) != MGX_OK) return fail(mgx_last_error());
   // ---- the dead documents' postings leave the bitmap form of their dense grams (a query over bitmap-form grams then
   // needs no live-row operand), then their live bits go --------------------------------------------------------------
-  if (!m.pending_dead_grams.empty() &&
-      mgx_index_clear_postings(im->dev, m.pending_dead_docs.data(), m.pending_dead_grams.data(), m.pending_dead_grams.size()) != MGX_OK)
+  if (!snap.dead_grams.empty() &&
+      mgx_index_clear_postings(im->dev, snap.dead_docs.data(), snap.dead_grams.data(), snap.dead_grams.size()) != MGX_OK)
     return fail(mgx_last_error());
-  m.pending_dead_docs.clear();
+  for (DocId d : snap.clear) {
+    const uint64_t slot = d - im->view.first_doc_id;
+    m.applied_live[slot >> 6] &= ~(1ull << (slot & 63));
+  }
   // ---- the live row of the main index ---------------------------------------------------------------------------------
   if (!m.have_live) {
     std::vector<DocId> live;
     live.reserve(im->view.n_docs);
     for (uint64_t slot = 0; slot < im->view.n_docs; ++slot)
-      if ((m.main_live[slot >> 6] >> (slot & 63)) & 1) live.push_back(im->view.first_doc_id + static_cast<DocId>(slot));
+      if ((m.applied_live[slot >> 6] >> (slot & 63)) & 1) live.push_back(im->view.first_doc_id + static_cast<DocId>(slot));
     if (mgx_index_add_filter_bitmap(im->dev, live.data(), live.size(), &m.live_bitmap) != MGX_OK) return fail(mgx_last_error());
     if (mgx_index_set_live_bitmap(im->dev, m.live_bitmap, MGX_LIVE_BITMAPS_CLEAN) != MGX_OK) return fail(mgx_last_error());
     m.have_live = true;
     im->has_gaps = false;  // (the live row is also the NOT universe: ids never added are not in it)
-  } else if (!m.pending_clear.empty()) {
-    if (mgx_index_update_filter_bitmap(im->dev, m.live_bitmap, nullptr, 0, m.pending_clear.data(), m.pending_clear.size()) != MGX_OK)
+  } else if (!snap.clear.empty()) {
+    if (mgx_index_update_filter_bitmap(im->dev, m.live_bitmap, nullptr, 0, snap.clear.data(), snap.clear.size()) != MGX_OK)
       return fail(mgx_last_error());
   }
-  m.pending_clear.clear();
   lap("sync + live row + cleaned bitmaps");
   // ---- posting sizes: the main index's live postings, then the delta's on top -------------------------------------------
   for (const auto& c : m.delta_contrib) im->global_sizes[c.first] -= c.second;
   m.delta_contrib.clear();
-  for (uint32_t gid : m.pending_dead_grams)
+  for (uint32_t gid : snap.dead_grams)
     if (im->global_sizes[gid] > 0) im->global_sizes[gid] -= 1;
-  m.pending_dead_grams.clear();
   // ---- the delta index ------------------------------------------------------------------------------------------------
-  if (m.delta_changed) {
-    m.delta_changed = false;
-    if (m.delta_docs.empty()) {
-      m.delta.reset();
-      m.delta_ids.reset();
-    } else {
-      auto nd = std::make_shared<Index>(ngram_size_, im->query_kanji, im->dense_threshold, cross_boundary_, normalize_nfkc_,
-                                        normalize_width_, normalize_lower_, im->device);
-      std::vector<DocId> ids;
-      ids.reserve(m.delta_docs.size());
-      DocId local = 1;
-      for (const auto& kv : m.delta_docs) {  // (ascending table id -> ascending local id: rank order and ties are kept)
-        nd->AddDocument(local++, kv.second);
-        ids.push_back(kv.first);
-      }
-      // (this Index's lock stays held: a writer thread recording a change meanwhile would otherwise see it marked applied;
-      //  Finalize / AddFilterColumn of the NEW index take that index's own locks)
-      const std::string err = nd->Finalize();
-      if (!err.empty() || !nd->impl()->dev) return fail("the delta index failed to build: " + err);
-      if (mgx_index_set_doc_map(nd->impl()->dev, ids.data(), ids.size()) != MGX_OK) return fail(mgx_last_error());
-      std::vector<std::string> names;
-      {
-        std::lock_guard<std::mutex> fl(im->filter_mu);
-        for (const auto& c : im->filter_columns) names.push_back(c.name);
-      }
-      for (const auto& kv : m.delta_filters)
-        for (const auto& f : kv.second)
-          if (std::find(names.begin(), names.end(), f.first) == names.end()) names.push_back(f.first);
-      for (const auto& name : names) {
-        std::vector<storage::FilterValue> values(ids.size());
-        for (size_t i = 0; i < ids.size(); ++i) {
-          const auto fm = m.delta_filters.find(ids[i]);
-          if (fm == m.delta_filters.end()) continue;
-          const auto fv = fm->second.find(name);
-          if (fv != fm->second.end()) values[i] = fv->second;
-        }
-        const std::string ferr = nd->AddFilterColumn(name, values);
-        if (!ferr.empty()) return fail(ferr);
-      }
-      nd->impl()->fallback = im;
-      m.delta = std::move(nd);
-      m.delta_ids = std::make_shared<const std::vector<DocId>>(std::move(ids));
-    }
+  if (built.rebuilt) {
+    m.delta = built.delta;
+    m.delta_ids = built.ids;
   }
-  lap("delta index (columns, device index, doc map, filter columns)");
+  lap("delta index handles");
   // ---- table-wide statistics in both ------------------------------------------------------------------------------------
-  uint64_t n_docs = m.main_docs, total_len = m.main_len;
+  uint64_t n_docs = snap.main_docs, total_len = snap.main_len;
   im->absent_grams.clear();
   std::vector<uint64_t> delta_sizes;
   if (m.delta) {
@@ -806,7 +865,7 @@ std::string Index::ApplyMutations(bool force) const {
   im->global_docs = n_docs;
   im->global_avgdl = n_docs ? static_cast<double>(total_len) / static_cast<double>(n_docs) : 0.0;
   if (m.delta) {
-    Impl* dm = m.delta->impl();
+    Index::Impl* dm = m.delta->impl();
     dm->global_sizes = std::move(delta_sizes);
     dm->global_docs = im->global_docs;
     dm->global_avgdl = im->global_avgdl;
@@ -814,9 +873,66 @@ std::string Index::ApplyMutations(bool force) const {
   }
   if (mgx_index_invalidate_statistics(im->dev) != MGX_OK) return fail(mgx_last_error());
   lap("statistics");
-  m.dirty = false;
   m.epoch += 1;
   return "";
+}
+}  // namespace
+
+void Index::SetMutationStaleness(std::chrono::microseconds max_staleness) {
+  std::lock_guard<std::mutex> lock(impl_->mu);
+  impl_->mut.staleness = max_staleness;
+}
+
+// With no staleness bound (and always the first time): snapshot, build, install — in this call, under the lock. With a
+// bound: the snapshot's delta is built by a thread while queries keep running on the old state, and installed by the first
+// entry point that finds it ready — the stall a steady writer causes is the few milliseconds of the installation, not the
+// delta build.
+std::string Index::ApplyMutations(bool force) const {
+  Impl* im = impl_.get();
+  std::unique_lock<std::mutex> lock(im->mu);
+  Impl::Mutable& m = im->mut;
+  if (m.staleness.count() == 0) force = true;  // (no bound: every change recorded before this call is applied by it)
+  auto install_background = [&]() -> std::string {
+    if (m.builder.joinable()) {
+      lock.unlock();  // (the builder takes the lock to publish its result)
+      m.builder.join();
+      lock.lock();
+    }
+    auto snap = std::static_pointer_cast<MutationSnapshot>(m.bg_snapshot);
+    auto built = std::static_pointer_cast<BuiltDelta>(m.bg_built);
+    m.bg_snapshot.reset();
+    m.bg_built.reset();
+    m.build_running = m.build_ready = false;
+    return snap && built ? InstallMutations(im, *snap, *built) : std::string();
+  };
+  if (m.build_running && (m.build_ready || force)) {
+    const std::string e = install_background();
+    if (!e.empty()) return e;
+  }
+  if (m.build_running) return "";  // (a build is under way: its result is installed by a later call)
+  if (!m.dirty) return "";
+  const auto now = std::chrono::steady_clock::now();
+  const bool background = !force && m.staleness.count() > 0 && m.epoch > 0;
+  if (background && now - m.last_apply < m.staleness) return "";
+  if (background) {
+    auto snap = std::make_shared<MutationSnapshot>(TakeSnapshot(im));
+    m.bg_snapshot = snap;
+    m.build_running = true;
+    m.build_ready = false;
+    const Index* self = this;
+    m.builder = std::thread([self, im, snap] {
+      pthread_setname_np(pthread_self(), "mgx-delta");
+      auto built = std::make_shared<BuiltDelta>(BuildDelta(*self, *snap));
+      std::lock_guard<std::mutex> l(im->mu);
+      im->mut.bg_built = built;
+      im->mut.build_ready = true;
+    });
+    return "";
+  }
+  MutationSnapshot snap = TakeSnapshot(im);
+  // (the lock stays held through the build: a writer thread recording a change meanwhile waits, and is not marked applied)
+  BuiltDelta built = BuildDelta(*this, snap);
+  return InstallMutations(im, snap, built);
 }
 
 // The main index rebuilt from the table's current documents: live documents of the old main index (their texts come back
@@ -1253,7 +1369,7 @@ std::vector<DocId> OverBoth(const Index& index, Op op) {
   Index::Impl* im = index.impl();
   {
     std::lock_guard<std::mutex> lock(im->mu);
-    a.erase(std::remove_if(a.begin(), a.end(), [&](DocId d) { return !im->LiveInMain(d); }), a.end());
+    a.erase(std::remove_if(a.begin(), a.end(), [&](DocId d) { return !im->LiveApplied(d); }), a.end());
   }
   const DeltaView dv = ViewOfDelta(index);
   if (!dv.delta) return a;
@@ -1276,7 +1392,7 @@ struct SplitCandidates {
     std::lock_guard<std::mutex> lock(im->mu);
     for (size_t i = 0; i < candidates.size(); ++i) {
       const DocId c = candidates[i];
-      if (im->LiveInMain(c)) {
+      if (im->LiveApplied(c)) {
         main_docs.push_back(c);
         main_pos.push_back(i);
       } else if (view.ids) {
@@ -2724,16 +2840,20 @@ Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& querie
   if (!im->dev) return MakeUnexpected(MakeError(ErrorCode::kInternalError, im->last_error));
   // a mutable table: changes recorded since the last batch reach the device now — once nothing of this executor is
   // being planned or compiled (batches already on the device finish first: ApplyMutations waits for it)
-  bool dirty = false, mutable_table = false;
+  // install: something is about to change on the device (a finished background build, or — without a staleness bound, and
+  // the first time — everything recorded so far): nothing of this executor may be being planned or compiled meanwhile.
+  // kick: with a staleness bound that has passed, a background build of the recorded changes starts; nothing changes yet.
+  bool install = false, kick = false, mutable_table = false;
   {
     std::lock_guard<std::mutex> il(im->mu);
     const auto& mm = im->mut;
-    // (with a staleness bound, recorded changes wait — and the pipeline is not drained — until the bound has passed)
-    dirty = mm.dirty && (mm.staleness.count() == 0 || mm.epoch == 0 ||
-                         std::chrono::steady_clock::now() - mm.last_apply >= mm.staleness);
+    const bool immediate = mm.staleness.count() == 0 || mm.epoch == 0;
+    install = mm.build_ready || (immediate && (mm.dirty || mm.build_running));
+    kick = !install && mm.dirty && !mm.build_running &&
+           std::chrono::steady_clock::now() - mm.last_apply >= mm.staleness;
     mutable_table = mm.active;
   }
-  if (dirty) {
+  if (install) {
     if (impl_->opt.comm)
       return MakeUnexpected(MakeError(ErrorCode::kNotImplemented, "a sharded table (Options::comm) is static"));
     {
@@ -2745,6 +2865,9 @@ Expected<uint64_t, Error> BatchExecutor::Submit(std::vector<BatchQuery>&& querie
         return true;
       });
     }
+    const std::string merr = impl_->index.ApplyMutations();
+    if (!merr.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, merr));
+  } else if (kick) {
     const std::string merr = impl_->index.ApplyMutations();
     if (!merr.empty()) return MakeUnexpected(MakeError(ErrorCode::kInternalError, merr));
   }

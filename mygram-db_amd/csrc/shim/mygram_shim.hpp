@@ -195,7 +195,9 @@ class Index {
   // A table under a steady stream of changes would rebuild its delta index for every batch (0.07-0.2 s each). With a
   // staleness bound, recorded changes become visible to queries at most that long after they were made (they are applied
   // by the first query entry point after the bound has passed): the reference's binlog applier is asynchronous to
-  // queries in the same way. 0 (default): every query sees every change recorded before it.
+  // queries in the same way. Under a bound the delta of the recorded changes is built by a background thread while
+  // queries run on the old state, and installed (a few milliseconds) by the next entry point that finds it ready.
+  // 0 (default): every query sees every change recorded before it.
   void SetMutationStaleness(std::chrono::microseconds max_staleness);
   // Folds the delta back: the main index is rebuilt from the table's current documents (the texts of its live documents come
   // back from the device, where BM25 keeps them; filter values likewise) and the delta and the live row go. What the

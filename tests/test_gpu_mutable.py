@@ -310,3 +310,95 @@ def test_a_table_changes_while_a_micro_batcher_serves_it():
                 assert np.array_equal(scores, ws), terms
     st = b.stats()
     assert st["queries"] >= 20 and st["batches"] >= 5, st  # (every batch formed while the writer ran applied changes first)
+
+
+def test_changes_applied_in_the_background_under_a_staleness_bound():
+    """Index::SetMutationStaleness: the delta of the recorded changes is built by a thread while queries run on the old state
+    and installed by a later entry point — queries see the old table or the new one, never a mixture, and the new one within
+    the bound (plus the build)."""
+    import threading
+    import time
+    S = _shim()
+    n = 30_000
+    corpus = mg.Corpus.synthetic(n, seed=71)
+    p = Pair(corpus=corpus)
+    p.dev.ensure_text()
+    t = S.Table(p.dev)
+    m = Mirror(corpus)
+    c = p.dev.columns
+    sizes = np.diff(c.offsets.astype(np.int64))
+    grams = [c.gram(g).decode() for g in np.argsort(-sizes)[:30] if b" " not in c.gram(g)]
+    rng = np.random.default_rng(72)
+    probe = [grams[0]]
+    # the first application is synchronous (it creates the live row); from then on changes wait for the bound
+    t.remove_document(1, m.docs[1])
+    del m.docs[1]
+    before = m.rebuilt()
+    assert t.search(probe, limit=5)[0] == before.oracle_query(Query(probe, limit=5))[0]
+    t.set_mutation_staleness(0.05)
+    for k in range(400):
+        d = int(rng.integers(2, n))
+        if d not in m.docs:
+            continue
+        if k % 2:
+            t.remove_document(d, m.docs[d])
+            del m.docs[d]
+        else:
+            new = corpus.text(int(rng.integers(0, n)))
+            t.update_document(d, m.docs[d], new)
+            m.docs[d] = new
+    after = m.rebuilt()
+    want_before = before.oracle_query(Query(probe, sort_score=True, limit=10))
+    want_after = after.oracle_query(Query(probe, sort_score=True, limit=10))
+    assert want_before[0] != want_after[0]
+    deadline = time.time() + 20.0
+    seen_after = False
+    while time.time() < deadline:
+        total, docs, scores = t.search(probe, sort_by_score=True, limit=10)
+        if total == want_after[0]:
+            assert docs.tolist() == want_after[1].tolist() and np.array_equal(scores, want_after[2])
+            seen_after = True
+            break
+        # not yet installed: exactly the old table
+        assert total == want_before[0] and docs.tolist() == want_before[1].tolist() and np.array_equal(scores, want_before[2])
+        time.sleep(0.01)
+    assert seen_after, "the background application never became visible"
+    # several queries against the final state, and a batcher with searching threads while more changes arrive
+    for terms in ([grams[1], grams[2]], [grams[3]]):
+        total, docs, scores = t.search(terms, sort_by_score=True, limit=10)
+        wt, wp, ws, _ = after.oracle_query(Query(terms, sort_score=True, limit=10))
+        assert total == wt and docs.tolist() == wp.tolist() and np.array_equal(scores, ws), terms
+    b = S.Batcher(t, max_batch=64, max_delay_us=200, depth=2, planner_threads=2)
+    errors, done = [], threading.Event()
+
+    def searcher(seed):
+        r = np.random.default_rng(seed)
+        try:
+            while not done.is_set():
+                terms = [grams[int(r.integers(0, len(grams)))] for _ in range(int(r.integers(1, 3)))]
+                total, docs, _ = b.search(terms, limit=10)
+                assert total >= len(docs)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=searcher, args=(200 + k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    try:
+        for k in range(300):
+            d = int(rng.integers(2, n))
+            if d in m.docs:
+                new = corpus.text(int(rng.integers(0, n)))
+                t.update_document(d, m.docs[d], new)
+                m.docs[d] = new
+            time.sleep(0.001)
+    finally:
+        done.set()
+        for th in threads:
+            th.join()
+    assert not errors, errors[:1]
+    t.set_mutation_staleness(0.0)  # (every change recorded so far is visible to the next query)
+    final = m.rebuilt()
+    for terms in (probe, [grams[4], grams[5]]):
+        total, docs, scores = b.search(terms, limit=10)
+        wt, wp, ws, _ = final.oracle_query(Query(terms, sort_score=True, limit=10))
+        assert total == wt and docs.tolist() == wp.tolist() and np.array_equal(scores, ws), terms
