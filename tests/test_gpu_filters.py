@@ -167,3 +167,39 @@ def test_a_table_loaded_from_a_dump_v2_file_ranks_filters_and_facets():
             c = ["tech", "food", "music"][d % 3].encode()
             cnt[c] = cnt.get(c, 0) + 1
     assert dict(page) == cnt and n_values == 3
+    # the loaded table changes like any other: a document leaves, one changes its text and keeps its dump
+    # filter values, a deleted id comes back with values of its own; then the delta is folded back (texts and values come
+    # from the device, where the loader put them)
+    def check(tag):
+        cur_ids = sorted(cur)
+        total, docs, _ = t.search(["alpha"], conditions=[("status", "=", "1")], descending=False, limit=40)
+        want = [d for d in cur_ids if "alpha" in cur[d] and status_of(d) == 1]
+        assert docs.tolist() == want and total == len(want), (tag, docs.tolist(), want)
+        matched, _, page = t.facet("category")
+        cnt = {}
+        for d in cur_ids:
+            c = category_of(d)
+            if c is not None:
+                cnt[c.encode()] = cnt.get(c.encode(), 0) + 1
+        assert matched == len(cur_ids) and dict(page) == cnt, tag
+    cur = {d: texts[d - 1] for d in exp["ids"]}
+    override = {}
+
+    def status_of(d):
+        return override[d][0] if d in override else (None if d % 10 == 0 else d % 3)
+
+    def category_of(d):
+        return override[d][1] if d in override else (None if d % 10 == 0 else ["tech", "food", "music"][d % 3])
+    victim = next(d for d in exp["ids"] if "alpha" in texts[d - 1] and d % 10 != 0 and d % 3 == 1)
+    t.remove_document(victim, cur[victim])
+    del cur[victim]
+    changed = next(d for d in exp["ids"] if d in cur and "alpha" not in texts[d - 1] and d % 10 != 0 and d % 3 == 1)
+    t.update_document(changed, cur[changed], cur[changed] + " alpha")
+    cur[changed] = cur[changed] + " alpha"
+    t.add_document(7, "alpha returns", filters={"status": ("int32", 1), "category": ("string", "tech")})
+    cur[7] = "alpha returns"
+    override[7] = (1, "tech")
+    check("changed")
+    t.compact()
+    assert t.mutation_stats()["delta_documents"] == 0
+    check("compacted")
