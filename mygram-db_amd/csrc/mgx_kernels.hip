@@ -747,6 +747,15 @@ __device__ __forceinline__ void tile_eval_body(const DevIndex& ix, const DevBatc
     }
     it.tile_begin = a;
     it.n_tiles = max(c, a + 1) - a;
+    // a sparse result's page spans up to `limit` tiles, one full tile evaluation each: the query's page pass is shared by
+    // gridDim.y workgroups (each takes a slice of the tile range; ranks are global, so their outputs do not meet)
+    if (gridDim.y > 1) {
+      const uint32_t per = (it.n_tiles + gridDim.y - 1) / gridDim.y;
+      const uint32_t skip = blockIdx.y * per;
+      if (skip >= it.n_tiles) return;
+      it.tile_begin += skip;
+      it.n_tiles = min(per, it.n_tiles - skip);
+    }
   }
 
   const uint32_t n_leaves = q.n_leaves;
@@ -3831,7 +3840,9 @@ int LaunchTileEval(int mode, const DevIndex& ix, const DevBatch& bt, const LdsPl
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(plan.bytes));
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), plan.bytes, s, ix, bt, plan, n_plain);
+  // (the page pass has one item per query: eight workgroups share each query's tiles)
+  const uint32_t parts = mode == kModeDocPage ? 8u : 1u;
+  hipLaunchKernelGGL(kernel, dim3(static_cast<uint32_t>(grid), parts), dim3(kBlock), plan.bytes, s, ix, bt, plan, n_plain);
   MGX_KCHECK();
   return 0;
 }
