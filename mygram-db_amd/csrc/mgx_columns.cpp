@@ -361,7 +361,9 @@ int BuildColumns(const mgx_build_params& bp, const uint8_t* text_bytes, const ui
   {
     DocScratch s;
     KeyTable probe;
-    const uint64_t d1 = std::min<uint64_t>(n_docs, std::max<uint64_t>(chunk_docs, 1));
+    // (a fixed sample, not "the first chunk": with 512-document chunks a CJK trigram corpus showed 15k distinct grams in its
+    //  first chunk, was taken for a small dictionary, and the dictionary-first build never came back)
+    const uint64_t d1 = std::min<uint64_t>(n_docs, std::max<uint64_t>(chunk_docs, 4096));
     bool big = false;
     for (uint64_t d = 0; d < d1 && !big; ++d) {
       uint32_t dl = 0;

@@ -308,6 +308,32 @@ def test_sort_based_build_equals_the_dictionary_first_build(monkeypatch):
     _check_columns_against_oracle([mg.Corpus.synthetic(800, seed=3).text(i).decode() for i in range(800)], 1, 2, 0, True)
 
 
+def test_a_large_dictionary_is_recognised_whatever_the_chunk_size(monkeypatch):
+    """The choice between the two builds is made from a fixed sample of documents. (It was "the first chunk": when chunks
+    shrank to 512 documents a CJK trigram corpus showed too few distinct grams in it, was taken for a small dictionary, and
+    the dictionary-first build of 18M grams never came back.) 40k CJK docs -> ~1M distinct trigrams must build in seconds."""
+    import time
+    monkeypatch.delenv("MGX_BUILD_SORTED", raising=False)
+    rng = np.random.default_rng(3)
+    n = 40_000
+    cps = np.concatenate([0x4E00 + np.arange(3000), 0x3042 + np.arange(80)]).astype(np.uint32)
+    wi = 1.0 / np.arange(1, 3001)
+    p = np.concatenate([wi / wi.sum() * 0.9, np.full(80, 0.1 / 80)])
+    lens = rng.integers(16, 49, size=n)
+    flat = cps[rng.choice(len(cps), size=int(lens.sum()), p=p)]
+    b = np.empty((len(flat), 3), np.uint8)
+    b[:, 0] = 0xE0 | (flat >> 12)
+    b[:, 1] = 0x80 | ((flat >> 6) & 0x3F)
+    b[:, 2] = 0x80 | (flat & 0x3F)
+    off = np.concatenate([[0], np.cumsum(lens.astype(np.uint64) * 3)]).astype(np.uint64)
+    corpus = mg.Corpus(np.concatenate([b.reshape(-1), np.zeros(16, np.uint8)]), off)
+    t0 = time.perf_counter()
+    cols = mg.Columns(corpus, 1, 3, 3, True, n_threads=4)
+    took = time.perf_counter() - t0
+    assert cols.n_grams > 500_000 and cols.n_postings >= cols.n_grams
+    assert took < 30.0, took
+
+
 def test_dump_v2_table_to_columns_texts_and_filters():
     """mgx_dump_open: a DUMP SAVE file ("MGDB" v2) -> one table's columns (built from the stored texts, cross-checked with
     the dump's own MGIX index), normalized texts by slot, the store's id set and its filter values. The fixture is written
